@@ -1,0 +1,69 @@
+"""ctypes binding of libfmatch_hip.so (the C ABI declared in include/fmatch.h).
+
+The library is mandatory: there is no CPU or eager fallback.  ``load()`` raises if the
+shared object is missing (build it with ``python -c 'import __graft_entry__ as g;
+g.build()'`` or ``make -C featurematching_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfmatch_hip.so")
+
+FM_OK = 0
+FM_E_CAPACITY = -5
+FM_E_CANDIDATES = -6
+FM_E_RANGE = -7
+
+_lib = None
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+# name -> (restype, argtypes); mirrors include/fmatch.h one to one
+SIGNATURES = {
+    "fm_version": (_i, []),
+    "fm_strerror": (C.c_char_p, [_i]),
+    "fm_default_cand_slots": (_i, [_f]),
+    "fm_coarse_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
+    "fm_coarse_match": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
+                             _p, C.c_size_t, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
+    "fm_read_count": (_i, [_p, _i, C.POINTER(C.c_int32), _p]),
+    "fm_gather_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
+    "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
+}
+
+
+class FMatchError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        msg = load().fm_strerror(status).decode()
+        super().__init__(f"{where}: {msg} (status {status})")
+
+
+def load():
+    """Load (once) and return the ctypes handle.  torch must already be imported by the
+    caller so that the HIP runtime the library binds to is the one torch uses."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP library is the product and has no fallback. "
+                "Build it with `make -C featurematching_amd/csrc` (hipcc, --offload-arch=gfx950).")
+        import torch  # noqa: F401  (loads torch's libamdhip64 first; same soname is then reused)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, where: str) -> None:
+    if status != FM_OK:
+        raise FMatchError(status, where)

@@ -1,0 +1,165 @@
+// Host side of the C ABI (include/fmatch.h): argument checks, workspace layout, launch order.
+#include <math.h>
+#include <string.h>
+
+#include "fm_internal.h"
+
+namespace fm {
+
+int choose_splits(int N, int panels, int tiles) {
+  // One workgroup per (sample, panel, split); aim at one full round of the 256 CUs when the
+  // batch alone cannot fill them (a split shorter than 2 tiles is not worth its prologue).
+  const int wg = N * panels;
+  int s = 256 / (wg > 0 ? wg : 1);
+  if (s < 1) s = 1;
+  const int smax = tiles / 2 > 0 ? tiles / 2 : 1;
+  if (s > smax) s = smax;
+  if (s > 32) s = 32;
+  return s;
+}
+
+CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
+  CoarseWs w;
+  memset(&w, 0, sizeof(w));
+  w.N = N; w.L = L; w.S = S; w.C = C; w.slots = slots;
+  w.Lp = round_up(L, kPanelRows);
+  w.Sp = round_up(S, kTileCols);
+  w.panels = w.Lp / kPanelRows;
+  w.tiles = w.Sp / kTileCols;
+  w.splits = choose_splits(N, w.panels, w.tiles);
+  const size_t rows = (size_t)N * w.Lp, cols = (size_t)N * w.Sp;
+  const size_t nblk = (rows * slots + 255) / 256;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o = align256(o + bytes); return at; };
+  w.zero_begin = o;
+  w.cand_count = take(rows * 4);
+  w.colbest = take(cols * 4);
+  w.scalars = take(sizeof(Scalars));
+  w.zero_end = o;
+  w.blocktot = take(nblk * 4);
+  w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);
+  w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
+  w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
+  w.bmax0 = take(rows / kPrepRows * 4); w.bmax1 = take(cols / kPrepRows * 4);
+  w.rowA = take(rows * w.splits * 4); w.colA = take(cols * w.panels * 8 * 4);
+  w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * 8 * 4);
+  w.nmr = take(rows * 4); w.nmc = take(cols * 4);
+  w.rsum = take(rows * 4); w.csum = take(cols * 4);
+  w.cand_j = take(rows * slots * 4); w.cand_conf = take(rows * slots * 4); w.rowbest = take(rows * 4);
+  w.keep_j = take(rows * slots * 4); w.keep_conf = take(rows * slots * 4); w.rowcnt = take(rows * 4);
+  w.total = o;
+  return w;
+}
+
+}  // namespace fm
+
+using namespace fm;
+
+extern "C" int fm_version(void) { return FM_VERSION; }
+
+extern "C" const char* fm_strerror(int s) {
+  switch (s) {
+    case FM_OK: return "ok";
+    case FM_E_NULL: return "required pointer is NULL";
+    case FM_E_SHAPE: return "inconsistent or non-positive shape";
+    case FM_E_UNSUPPORTED: return "unsupported configuration (C in {64,128,256}, Cf = 64, W in {5,7}, thr in (0,1))";
+    case FM_E_WORKSPACE: return "workspace too small or not 256-byte aligned";
+    case FM_E_CAPACITY: return "more matches than the output capacity";
+    case FM_E_CANDIDATES: return "a coarse row exceeded its candidate slots (raise cand_slots)";
+    case FM_E_RANGE: return "descriptor not finite or |x| >= 32768";
+    default: return s > 0 ? hipGetErrorString((hipError_t)s) : "unknown fmatch status";
+  }
+}
+
+extern "C" int fm_default_cand_slots(float thr) {
+  if (!(thr > 0.f)) return 64;
+  int need = (int)ceilf(1.0f / thr) + 3;
+  int s = 8;
+  while (s < need && s < 64) s <<= 1;
+  return s;
+}
+
+static bool valid_slots(int s) { return s >= 1 && s <= 64 && (s & (s - 1)) == 0; }
+
+extern "C" int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t* bytes) {
+  if (!bytes) return FM_E_NULL;
+  if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
+  if ((C != 64 && C != 128 && C != 256) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
+  *bytes = coarse_layout(N, L, S, C, cand_slots).total;
+  return FM_OK;
+}
+
+// Diagnostic: the workspace layout (ints then byte offsets), so that tests can inspect the
+// intermediate statistics of a run.  out[0..9] = N,L,S,C,Lp,Sp,panels,tiles,splits,slots;
+// out[10..] = cand_count, colbest, scalars, blocktot, hi0, lo0, hi1, lo1, norm0, norm1, bmax0, bmax1,
+// rowA, colA, rowB, colB, nmr, nmc, rsum, csum, cand_j, cand_conf, rowbest, keep_j, keep_conf, rowcnt, total.
+extern "C" int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out) {
+  if (!out) return FM_E_NULL;
+  if (n_out < 37) return FM_E_SHAPE;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  const int64_t v[37] = {w.N, w.L, w.S, w.C, w.Lp, w.Sp, w.panels, w.tiles, w.splits, w.slots,
+                         (int64_t)w.cand_count, (int64_t)w.colbest, (int64_t)w.scalars, (int64_t)w.blocktot,
+                         (int64_t)w.hi0, (int64_t)w.lo0, (int64_t)w.hi1, (int64_t)w.lo1, (int64_t)w.norm0,
+                         (int64_t)w.norm1, (int64_t)w.bmax0, (int64_t)w.bmax1, (int64_t)w.rowA, (int64_t)w.colA,
+                         (int64_t)w.rowB, (int64_t)w.colB, (int64_t)w.nmr, (int64_t)w.nmc, (int64_t)w.rsum,
+                         (int64_t)w.csum, (int64_t)w.cand_j, (int64_t)w.cand_conf, (int64_t)w.rowbest,
+                         (int64_t)w.keep_j, (int64_t)w.keep_conf, (int64_t)w.rowcnt, (int64_t)w.total};
+  for (int i = 0; i < 37; ++i) out[i] = v[i];
+  return FM_OK;
+}
+
+extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S, int C, int h0c, int w0c,
+                               int h1c, int w1c, float temperature, float thr, int border_rm, float scale_px,
+                               const float* scale0, const float* scale1, void* workspace, size_t workspace_bytes,
+                               int cand_slots, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mkpts0_c,
+                               float* mkpts1_c, float* mconf, int cap, int32_t* d_count, float* conf_matrix,
+                               void* stream) {
+  if (!feat0 || !feat1 || !workspace || !d_count) return FM_E_NULL;
+  if (cap > 0 && (!b_ids || !i_ids || !j_ids || !mkpts0_c || !mkpts1_c || !mconf)) return FM_E_NULL;
+  if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
+  if ((C != 64 && C != 128 && C != 256) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
+  if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
+  if (conf_matrix) return FM_E_UNSUPPORTED;   // dense conf_matrix (training surface) not built yet
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return FM_E_WORKSPACE;
+  char* base = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_ct = 1.0f / ((float)C * temperature);
+
+  hipError_t e = hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, st);
+  if (e != hipSuccess) return (int)e;
+  unsigned* flags = (unsigned*)(base + w.scalars);
+  e = launch_prep(feat0, N, L, w.Lp, C, (_Float16*)(base + w.hi0), (_Float16*)(base + w.lo0),
+                  (float*)(base + w.norm0), (float*)(base + w.bmax0), flags, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_prep(feat1, N, S, w.Sp, C, (_Float16*)(base + w.hi1), (_Float16*)(base + w.lo1),
+                  (float*)(base + w.norm1), (float*)(base + w.bmax1), flags, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_corr(0, w, base, inv_ct, thr, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_reduce(0, w, base, inv_ct, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_corr(1, w, base, inv_ct, thr, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_reduce(1, w, base, inv_ct, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_select(w, base, feat0, feat1, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
+                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, st);
+  return (int)e;
+}
+
+extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, void* stream) {
+  if (!d_count || !m_out) return FM_E_NULL;
+  int32_t h[2] = {0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(h, d_count, sizeof(h), hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return (int)e;
+  *m_out = h[0];
+  if (h[1] & FM_DEV_RANGE) return FM_E_RANGE;
+  if (h[1] & FM_DEV_CANDIDATES) return FM_E_CANDIDATES;
+  if (h[1] & FM_DEV_CAPACITY) return FM_E_CAPACITY;
+  if (h[0] > cap) return FM_E_CAPACITY;
+  return FM_OK;
+}

@@ -1,0 +1,285 @@
+// Coarse stage, the two correlation sweeps (the hot kernels).
+//
+// Reproduces network/utils/coarse_matching_new.py:64-68 (all-pairs correlation + dual
+// softmax statistics) without ever writing the L x S matrix:
+//
+//   pass A (MODE 0): raw = hi0 . hi1^T on the f16 matrix cores; per-row and per-column
+//                    maxima (partial over column splits / row panels).
+//   pass B (MODE 1): raw = hi0.hi1 + lo0.hi1 + hi0.lo1 (float32-accurate product);
+//                    row sums  sum_j exp(s_ij - m^_i), column sums sum_i exp(s_ij - c^_j)
+//                    with the stabilisers of k_reduce_max, and the sparse candidate list
+//                    {(i,j): s_ij - m^_i > ln thr  and  s_ij - c^_j > ln thr}, a superset
+//                    of every entry with conf > thr (coarse_matching_new.py:99).
+//
+// Structure (one workgroup = 8 waves = 256 rows of image 0; cf. SURVEY.md 7, hard part 2):
+//   * each wave keeps its 32 rows x C of image-0 descriptors as MFMA A-fragments in
+//     registers for the whole sweep (no K loop, no re-read);
+//   * image-1 descriptors stream through LDS in 64-column tiles, double buffered,
+//     filled by LDS-DMA (global_load_lds_dwordx4) with an XOR swizzle applied on the
+//     SOURCE address so that the ds_read_b128 fragment reads are bank-conflict free;
+//   * the f32 accumulator tile (32 rows x 32 cols per wave and unit) never leaves registers:
+//     the epilogue turns it into exp2 terms, accumulates row sums in registers across
+//     the whole sweep and reduces column sums lane-locally (rows live in registers,
+//     columns on lanes: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5));
+//     each wave writes the column partial of its own 32 rows (8 partials per panel).
+#include "fm_internal.h"
+
+namespace fm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct CorrArgs {
+  const _Float16* hi0; const _Float16* lo0; const _Float16* hi1; const _Float16* lo1;
+  const float* nmr; const float* nmc;
+  float* rowpart; float* colpart;
+  int* cand_count; int* cand_j; unsigned* flags;
+  int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, slots;
+  float k;    // log2(e) / (C*T): raw dot product -> log2-domain similarity
+  float lt;   // log2(thr)
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of
+// logical ids so that the workgroups sharing a column stream share an L2 (speed only).
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, rem = n & 7, x = bid & 7, y = bid >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + y;
+}
+
+template <int C>
+__device__ __forceinline__ int swz(int col) {
+  constexpr int CHUNKS = C / 8;
+  return CHUNKS >= 16 ? (col & 15) : ((col >> 1) & (CHUNKS - 1));
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+#ifndef FM_NO_GLDS
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#else
+  const uint4 v = *reinterpret_cast<const uint4*>(gsrc);
+  *reinterpret_cast<uint4*>(lds_wave_base + (threadIdx.x & 63) * 16) = v;
+#endif
+}
+
+template <int C, int MODE>
+__global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
+  constexpr int KSTEPS = C / 16;
+  constexpr int ROWB = C * 2;
+  constexpr int CHUNKS = C / 8;
+  constexpr int PLANES = MODE ? 2 : 1;
+  constexpr int PLANE_BYTES = kTileCols * ROWB;
+  constexpr int BUF_BYTES = PLANES * PLANE_BYTES;
+  constexpr int INSTR_PER_WAVE = PLANE_BYTES / 1024 / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  int kk = xcd_remap(blockIdx.x, gridDim.x);
+  const int panel = kk % a.panels; kk /= a.panels;
+  const int split = kk % a.splits;
+  const int b = kk / a.splits;
+  const int t0 = split * a.tiles_per_split;
+  const int t1 = min(t0 + a.tiles_per_split, a.tiles);
+
+  const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};
+
+  auto stage = [&](int t, int buf) {
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) {
+#pragma unroll
+      for (int n = 0; n < INSTR_PER_WAVE; ++n) {
+        const int instr = wv * INSTR_PER_WAVE + n;
+        const int byte = instr * 1024 + lane * 16;
+        const int col = byte / ROWB;
+        const int q = ((byte % ROWB) >> 4) ^ swz<C>(col);
+        const _Float16* src = planes1[p] + (long)(t * kTileCols + col) * C + q * 8;
+        glds16(src, smem + buf * BUF_BYTES + p * PLANE_BYTES + instr * 1024);
+      }
+    }
+  };
+
+  if (t0 < t1) stage(t0, 0);
+
+  // ---- this wave's 32 rows as A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7) ----
+  const int wrow0 = panel * kPanelRows + wv * 32;
+  half8 ahi[KSTEPS], alo[MODE ? KSTEPS : 1];
+  {
+    const long off = ((long)b * a.Lp + wrow0 + r) * C + h * (C / 2);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) ahi[ks] = *reinterpret_cast<const half8*>(a.hi0 + off + ks * 8);
+    if (MODE) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) alo[ks] = *reinterpret_cast<const half8*>(a.lo0 + off + ks * 8);
+    }
+  }
+
+  // row statistics, one per accumulator register (row = wrow0 + (g&3) + 8*(g>>2) + 4*h)
+  float rstat[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) rstat[g] = MODE ? 0.f : -INFINITY;
+  // row stabilisers of this wave's 32 rows, parked in LDS (read back 4 at a time in the epilogue)
+  float* nmr_lds = reinterpret_cast<float*>(smem + 2 * BUF_BYTES) + wv * 32;
+  if (MODE && lane < 32) nmr_lds[lane] = a.nmr[(long)b * a.Lp + wrow0 + lane];
+  const bool row_edge = (wrow0 + 32 > a.L);     // wave-uniform: some of this wave's rows are padding
+
+  const int lanebase0 = r * ROWB + (((h * (CHUNKS / 2)) ^ swz<C>(r)) << 4);              // columns 0..31 of a tile
+  const int lanebase1 = (32 + r) * ROWB + (((h * (CHUNKS / 2)) ^ swz<C>(32 + r)) << 4);  // columns 32..63
+  float* colout = a.colpart + (((long)b * a.panels + panel) * 8 + wv) * a.Sp;
+
+  f32x16 acc;
+
+  // one unit = 32 rows x 32 columns x C: the accumulator tile of this wave
+  auto mfma_unit = [&](int u) {
+    const char* buf = smem + (((u >> 1) - t0) & 1) * BUF_BYTES;
+    const int lb = (u & 1) ? lanebase1 : lanebase0;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int la = lb ^ (ks << 4);
+      const half8 bh = *reinterpret_cast<const half8*>(buf + la);
+      if (ks == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) z[g] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bh, z, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bh, acc, 0, 0, 0);
+      }
+      if (MODE) {
+        const half8 bl = *reinterpret_cast<const half8*>(buf + PLANE_BYTES + la);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl, acc, 0, 0, 0);
+      }
+    }
+  };
+
+  // epilogue of unit u: fold the accumulator into the row / column statistics
+  auto epilogue = [&](int u) {
+    const int col = (u >> 1) * kTileCols + (u & 1) * 32 + r;     // this lane's column
+    const bool col_edge = (col - r + 32 > a.S);                  // wave-uniform
+    const bool cvalid = col < a.S;
+    float cstat;
+    if (MODE == 0) {
+      cstat = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float x = acc[g];
+        if (col_edge && !cvalid) x = -INFINITY;
+        if (row_edge && (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L)) x = -INFINITY;
+        rstat[g] = fmaxf(rstat[g], x);
+        cstat = fmaxf(cstat, x);
+      }
+      cstat = fmaxf(cstat, __shfl_xor(cstat, 32));
+    } else {
+      const float nmc = a.nmc[(long)b * a.Sp + col];
+      float best = -INFINITY;
+      cstat = 0.f;
+      float nmr[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(nmr_lds + 8 * q + 4 * h);
+        nmr[4 * q] = v.x; nmr[4 * q + 1] = v.y; nmr[4 * q + 2] = v.z; nmr[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float x = acc[g];
+        float rr = __builtin_fmaf(x, a.k, nmr[g]);
+        float cc = __builtin_fmaf(x, a.k, nmc);
+        if (col_edge && !cvalid) { rr = -INFINITY; cc = -INFINITY; }
+        if (row_edge && (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L)) { rr = -INFINITY; cc = -INFINITY; }
+        rstat[g] += __builtin_amdgcn_exp2f(rr);
+        cstat += __builtin_amdgcn_exp2f(cc);
+        best = fmaxf(best, fminf(rr, cc));
+      }
+      cstat += __shfl_xor(cstat, 32);
+      if (__any(best > a.lt)) {      // rare: some lane holds a candidate in this unit
+        int rbase = wrow0 + 4 * h;
+        asm volatile("" : "+v"(rbase));   // keep the 16 per-row addresses from being hoisted (and spilled)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float x = acc[g];
+          const float rr = __builtin_fmaf(x, a.k, nmr[g]);
+          const float cc = __builtin_fmaf(x, a.k, nmc);
+          const int row = rbase + (g & 3) + 8 * (g >> 2);
+          if (rr > a.lt && cc > a.lt && row < a.L && cvalid) {
+            const long grow = (long)b * a.Lp + row;
+            const int pos = atomicAdd(&a.cand_count[grow], 1);
+            if (pos < a.slots) a.cand_j[grow * a.slots + pos] = col;
+            else atomicOr(a.flags, (unsigned)FM_DEV_CANDIDATES);
+          }
+        }
+      }
+    }
+    if (h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
+  };
+
+  __syncthreads();
+
+  // Waves w and w+4 share a SIMD.  The second half of the workgroup runs one epilogue behind the
+  // first, so that on every SIMD one wave's exp/add epilogue overlaps the other's MFMA chain.
+  const bool late = wv >= 4;
+  for (int u = 2 * t0; u < 2 * t1; ++u) {
+    if ((u & 1) == 0 && (u >> 1) + 1 < t1) stage((u >> 1) + 1, (((u >> 1) - t0) & 1) ^ 1);
+    if (late && u > 2 * t0) epilogue(u - 1);
+    mfma_unit(u);
+    if (!late) epilogue(u);
+    if (u & 1) __syncthreads();   // tile consumed by every wave; next tile landed (LDS-DMA drained)
+  }
+  if (late && t1 > t0) epilogue(2 * t1 - 1);
+
+  // ---- row statistics of this workgroup's column range: reduce over the 32 lanes of each half ----
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    float v = rstat[g];
+#pragma unroll
+    for (int m = 1; m <= 16; m <<= 1) {
+      const float o = __shfl_xor(v, m);
+      v = MODE ? v + o : fmaxf(v, o);
+    }
+    rstat[g] = v;
+  }
+  if (r == 0) {
+    float* out = a.rowpart + ((long)b * a.splits + split) * a.Lp + wrow0 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) out[(g & 3) + 8 * (g >> 2)] = rstat[g];
+  }
+}
+
+template <int C, int MODE>
+static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
+  constexpr int BUF_BYTES = (MODE ? 2 : 1) * kTileCols * C * 2;
+  constexpr int SMEM = 2 * BUF_BYTES + 8 * 32 * 4;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr<C, MODE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_corr<C, MODE>), dim3(blocks), dim3(512), SMEM, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st) {
+  CorrArgs a;
+  a.hi0 = (const _Float16*)(base + w.hi0); a.lo0 = (const _Float16*)(base + w.lo0);
+  a.hi1 = (const _Float16*)(base + w.hi1); a.lo1 = (const _Float16*)(base + w.lo1);
+  a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
+  a.rowpart = (float*)(base + (mode ? w.rowB : w.rowA));
+  a.colpart = (float*)(base + (mode ? w.colB : w.colA));
+  a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
+  a.flags = (unsigned*)(base + w.scalars);
+  a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
+  a.splits = w.splits; a.tiles_per_split = (w.tiles + w.splits - 1) / w.splits; a.slots = w.slots;
+  a.k = inv_ct * kLog2e; a.lt = log2f(thr);
+  const int blocks = w.N * w.splits * w.panels;
+#define FM_CORR_CASE(CC)                                                     \
+  case CC: return mode ? launch_corr_t<CC, 1>(a, blocks, st) : launch_corr_t<CC, 0>(a, blocks, st);
+  switch (w.C) {
+    FM_CORR_CASE(64)
+    FM_CORR_CASE(128)
+    FM_CORR_CASE(256)
+    default: return hipErrorInvalidValue;
+  }
+#undef FM_CORR_CASE
+}
+
+}  // namespace fm

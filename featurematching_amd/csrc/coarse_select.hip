@@ -1,0 +1,182 @@
+// Coarse stage, sparse assignment on the candidate list of pass B:
+//   k_cand_conf : exact float32 conf of every candidate, best conf per row / column
+//   k_cand_keep : threshold + mutual nearest neighbour + border, sort a row's matches by j
+//   k_emit      : deterministic prefix offsets -> outputs in (b, i, j) order
+//
+// Follows network/utils/coarse_matching_new.py:99-141.  Every entry of the L x S matrix
+// that is not a candidate has conf <= thr, so it can neither pass :99 nor beat a surviving
+// candidate in the row / column maxima of :105-106 - the maxima over candidates decide.
+// The border mask (:100-102) is applied last: border cells still compete in the maxima.
+#include "fm_internal.h"
+
+namespace fm {
+
+struct SelArgs {
+  const float* feat0; const float* feat1;
+  const float* nmr; const float* nmc; const float* rsum; const float* csum;
+  const int* cand_count; const int* cand_j;
+  float* cand_conf; float* rowbest; unsigned* colbest;
+  int* keep_j; float* keep_conf; int* rowcnt; int* blocktot; Scalars* scal;
+  int N, L, S, C, Lp, Sp, splits, panels, slots;
+  int h0c, w0c, h1c, w1c, border;
+  float k, thr, scale_px;
+  const float* scale0; const float* scale1;
+  int64_t* b_ids; int64_t* i_ids; int64_t* j_ids; float* k0; float* k1; float* mconf;
+  int cap; int32_t* d_count;
+};
+
+// one thread per (row, slot); a row's `slots` threads are adjacent lanes of one wave
+__global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long grow = gid / a.slots;                 // b*Lp + i
+  const int slot = (int)(gid - grow * a.slots);
+  const int b = (int)(grow / a.Lp);
+  const int i = (int)(grow - (long)b * a.Lp);
+  float conf = 0.f;
+  const int cnt = (b < a.N && i < a.L) ? min(a.cand_count[grow], a.slots) : 0;
+  if (slot < cnt) {
+    const int j = a.cand_j[grow * a.slots + slot];
+    const float4* p0 = reinterpret_cast<const float4*>(a.feat0 + ((long)b * a.L + i) * a.C);
+    const float4* p1 = reinterpret_cast<const float4*>(a.feat1 + ((long)b * a.S + j) * a.C);
+    double dot = 0.0;
+    for (int c = 0; c < a.C / 4; ++c) {
+      const float4 u = p0[c], v = p1[c];
+      dot += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * v.z + (double)u.w * v.w;
+    }
+    const float x = (float)dot;
+    const float rs = a.rsum[grow], cs = a.csum[(long)b * a.Sp + j];
+    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmr[grow])) / rs;
+    const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmc[(long)b * a.Sp + j])) / cs;
+    conf = pr * pc;
+    a.cand_conf[grow * a.slots + slot] = conf;
+    atomicMax(&a.colbest[(long)b * a.Sp + j], __float_as_uint(conf));
+  }
+  float best = conf;
+  for (int m = 1; m < a.slots; m <<= 1) best = fmaxf(best, __shfl_xor(best, m));
+  if (slot == 0 && b < a.N) a.rowbest[grow] = best;
+}
+
+__device__ __forceinline__ bool interior(int id, int hh, int ww, int bd) {
+  if (bd <= 0) return true;
+  const int y = id / ww, x = id - y * ww;
+  return y >= bd && y < hh - bd && x >= bd && x < ww - bd;
+}
+
+__global__ __launch_bounds__(256) void k_cand_keep(SelArgs a) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long grow = gid / a.slots;
+  const int slot = (int)(gid - grow * a.slots);
+  const int b = (int)(grow / a.Lp);
+  const int i = (int)(grow - (long)b * a.Lp);
+  const int cnt = (b < a.N && i < a.L) ? min(a.cand_count[grow], a.slots) : 0;
+  bool keep = false;
+  int j = 0x7fffffff;
+  float conf = 0.f;
+  if (slot < cnt) {
+    j = a.cand_j[grow * a.slots + slot];
+    conf = a.cand_conf[grow * a.slots + slot];
+    keep = conf > a.thr && conf == a.rowbest[grow] &&
+           __float_as_uint(conf) == a.colbest[(long)b * a.Sp + j] &&
+           interior(i, a.h0c, a.w0c, a.border) && interior(j, a.h1c, a.w1c, a.border);
+  }
+  // rank among the row's kept entries by ascending j (torch.where order, :109)
+  const int kj = keep ? j : 0x7fffffff;
+  int rank = 0, nkeep = 0;
+  const int lane = threadIdx.x & 63;
+  const int base = lane - slot;
+  for (int s = 0; s < a.slots; ++s) {
+    const int oj = __shfl(kj, base + s);
+    rank += (oj < kj) ? 1 : 0;
+    nkeep += (oj != 0x7fffffff) ? 1 : 0;
+  }
+  if (keep) {
+    a.keep_j[grow * a.slots + rank] = j;
+    a.keep_conf[grow * a.slots + rank] = conf;
+  }
+  if (slot == 0 && b < a.N) a.rowcnt[grow] = nkeep;
+  // matches of this workgroup's rows
+  __shared__ int sm[4];
+  int tot = (slot == 0) ? nkeep : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
+  if (lane == 0) sm[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) a.blocktot[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void k_emit(SelArgs a) {
+  __shared__ int sm[4];
+  __shared__ int rowoff[256];
+  const int lane = threadIdx.x & 63;
+  // exclusive prefix of the workgroup totals before this one (fixed order -> deterministic)
+  int pre = 0;
+  for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) pre += a.blocktot[k];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m);
+  if (lane == 0) sm[threadIdx.x >> 6] = pre;
+  __syncthreads();
+  pre = sm[0] + sm[1] + sm[2] + sm[3];
+
+  const int rows_per_block = 256 / a.slots;
+  const long row0 = (long)blockIdx.x * rows_per_block;
+  const long total_rows = (long)a.N * a.Lp;
+  if (threadIdx.x == 0) {
+    int run = pre;
+    for (int q = 0; q < rows_per_block; ++q) {
+      rowoff[q] = run;
+      if (row0 + q < total_rows) run += a.rowcnt[row0 + q];
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+      a.d_count[0] = run;
+      a.d_count[1] = (int)(a.scal->flags | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
+    }
+  }
+  __syncthreads();
+  const int q = threadIdx.x / a.slots;
+  const int slot = threadIdx.x - q * a.slots;
+  const long grow = row0 + q;
+  if (grow >= total_rows) return;
+  if (slot >= a.rowcnt[grow]) return;
+  const long o = (long)rowoff[q] + slot;
+  if (o >= a.cap) return;
+  const int b = (int)(grow / a.Lp);
+  const int i = (int)(grow - (long)b * a.Lp);
+  const int j = a.keep_j[grow * a.slots + slot];
+  a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = j;
+  a.mconf[o] = a.keep_conf[grow * a.slots + slot];
+  // coarse_matching_new.py:126-134: (x, y) = (id % w, id // w) * scale [* scale{0,1}[b]]
+  float s0x = a.scale_px, s0y = a.scale_px, s1x = a.scale_px, s1y = a.scale_px;
+  if (a.scale0) { s0x = a.scale_px * a.scale0[b * 2]; s0y = a.scale_px * a.scale0[b * 2 + 1]; }
+  if (a.scale1) { s1x = a.scale_px * a.scale1[b * 2]; s1y = a.scale_px * a.scale1[b * 2 + 1]; }
+  a.k0[o * 2] = (float)(i % a.w0c) * s0x; a.k0[o * 2 + 1] = (float)(i / a.w0c) * s0y;
+  a.k1[o * 2] = (float)(j % a.w1c) * s1x; a.k1[o * 2 + 1] = (float)(j / a.w1c) * s1y;
+}
+
+hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, const float* feat1, int h0c, int w0c,
+                         int h1c, int w1c, float inv_ct, float thr, int border, float scale_px,
+                         const float* scale0, const float* scale1, int64_t* b_ids, int64_t* i_ids,
+                         int64_t* j_ids, float* k0, float* k1, float* mconf, int cap, int32_t* d_count,
+                         hipStream_t st) {
+  SelArgs a;
+  a.feat0 = feat0; a.feat1 = feat1;
+  a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
+  a.rsum = (const float*)(base + w.rsum); a.csum = (const float*)(base + w.csum);
+  a.cand_count = (const int*)(base + w.cand_count); a.cand_j = (const int*)(base + w.cand_j);
+  a.cand_conf = (float*)(base + w.cand_conf); a.rowbest = (float*)(base + w.rowbest);
+  a.colbest = (unsigned*)(base + w.colbest);
+  a.keep_j = (int*)(base + w.keep_j); a.keep_conf = (float*)(base + w.keep_conf);
+  a.rowcnt = (int*)(base + w.rowcnt); a.blocktot = (int*)(base + w.blocktot);
+  a.scal = (Scalars*)(base + w.scalars);
+  a.N = w.N; a.L = w.L; a.S = w.S; a.C = w.C; a.Lp = w.Lp; a.Sp = w.Sp; a.splits = w.splits; a.panels = w.panels;
+  a.slots = w.slots; a.h0c = h0c; a.w0c = w0c; a.h1c = h1c; a.w1c = w1c; a.border = border;
+  a.k = inv_ct * kLog2e; a.thr = thr; a.scale_px = scale_px; a.scale0 = scale0; a.scale1 = scale1;
+  a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.k0 = k0; a.k1 = k1; a.mconf = mconf;
+  a.cap = cap; a.d_count = d_count;
+  const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
+  hipLaunchKernelGGL(k_cand_conf, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_cand_keep, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace fm

@@ -1,0 +1,207 @@
+// Fine stage: window crop (network/module/fine_preprocess.py:43-50) and the dual-direction
+// local-window correlation + soft-argmax (network/utils/fine_matching_new.py:50-79).
+#include "fm_internal.h"
+
+namespace fm {
+
+// ----------------------------------------------------------------------------------------
+// k_gather_nchw: one workgroup per window.  The reference unfolds EVERY coarse cell's window
+// (60 MB per image at 640x480) and then selects M of them; here only the M selected windows are
+// read, straight from the NCHW map (runs of W floats along x), transposed to [WW][Cf] through
+// LDS (pitch Cf+1: conflict-free both ways) and written as one contiguous 12.5 KB record.
+// Window origin = stride*cell - pad with the reference's literal pad = 2, zero outside the map.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_nchw(const float* __restrict__ feat, int Cf, int Hf, int Wf, int W,
+                                                     int stride, int pad, int w_c, const int64_t* __restrict__ b_ids,
+                                                     const int64_t* __restrict__ ids, const int32_t* __restrict__ d_count,
+                                                     int m_max, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [WW][Cf+1]
+  const int m = blockIdx.x;
+  const int M = d_count ? min(d_count[0], m_max) : m_max;
+  if (m >= M) return;
+  const int WW = W * W;
+  const int b = (int)b_ids[m];
+  const int id = (int)ids[m];
+  const int oy = (id / w_c) * stride - pad;
+  const int ox = (id % w_c) * stride - pad;
+  const float* src = feat + (long)b * Cf * Hf * Wf;
+  const int total = Cf * WW;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int c = idx / WW;
+    const int rem = idx - c * WW;
+    const int wy = rem / W, wx = rem - wy * W;
+    const int y = oy + wy, x = ox + wx;
+    float v = 0.f;
+    if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)c * Hf + y) * Wf + x];
+    tile[rem * (Cf + 1) + c] = v;
+  }
+  __syncthreads();
+  float* dst = out + (long)m * total;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int rpos = idx / Cf;
+    const int c = idx - rpos * Cf;
+    dst[idx] = tile[rpos * (Cf + 1) + c];
+  }
+}
+
+// NHWC storage: every window row is W*Cf contiguous floats - a straight float4 copy.
+__global__ __launch_bounds__(256) void k_gather_nhwc(const float* __restrict__ feat, int Cf, int Hf, int Wf, int W,
+                                                     int stride, int pad, int w_c, const int64_t* __restrict__ b_ids,
+                                                     const int64_t* __restrict__ ids, const int32_t* __restrict__ d_count,
+                                                     int m_max, float* __restrict__ out) {
+  const int m = blockIdx.x;
+  const int M = d_count ? min(d_count[0], m_max) : m_max;
+  if (m >= M) return;
+  const int WW = W * W;
+  const int b = (int)b_ids[m];
+  const int id = (int)ids[m];
+  const int oy = (id / w_c) * stride - pad;
+  const int ox = (id % w_c) * stride - pad;
+  const int c4 = Cf / 4;
+  const float4* src = reinterpret_cast<const float4*>(feat + (long)b * Hf * Wf * Cf);
+  float4* dst = reinterpret_cast<float4*>(out + (long)m * WW * Cf);
+  for (int idx = threadIdx.x; idx < WW * c4; idx += 256) {
+    const int rpos = idx / c4;
+    const int c = idx - rpos * c4;
+    const int wy = rpos / W, wx = rpos - wy * W;
+    const int y = oy + wy, x = ox + wx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)y * Wf + x) * c4 + c];
+    dst[idx] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// k_fine: one wave per match, lane = channel (Cf = 64).
+//   q0[c]   = b0 + sum_r w0[r] F0[r][c]            (Linear over the POSITION axis, :50,53)
+//   sim0[r] = sum_c q0[c] F1[r][c]                 (:56)   -> refines keypoint 0
+//   q1 / sim1 symmetrically (:51,54,57)            -> refines keypoint 1
+//   heat = softmax(sim / sqrt(C)); coords = E[grid]; std = sum sqrt(clamp(var, 1e-10))  (:58-73)
+//   out  = mkpts_c + (coords * (W//2) * scale + W//2), std                              (:75-79)
+// The WW cross-lane sums of sim are done with one butterfly "transpose-reduce": after the six
+// exchange steps lane r holds sim[r], so the softmax runs with lane = window position.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// in: p[k] = this lane's term of sum k (k < 64).  out: lane l returns sum_lanes p[l].
+__device__ __forceinline__ float transpose_reduce64(float (&p)[64], int lane) {
+#pragma unroll
+  for (int half = 32; half >= 1; half >>= 1) {
+    const bool up = (lane & half) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const float keep = up ? p[k + half] : p[k];
+      const float send = up ? p[k] : p[k + half];
+      p[k] = keep + __shfl_xor(send, half);
+    }
+  }
+  return p[0];
+}
+
+template <int W>
+__device__ __forceinline__ void soft_argmax(float sim, int lane, float inv_sqrt_c, float scale_f, float kx, float ky,
+                                            float* out) {
+  constexpr int WW = W * W;
+  const bool on = lane < WW;
+  const float x = on ? sim * inv_sqrt_c : -INFINITY;
+  const float mx = wave_max(x);
+  const float e = on ? __expf(x - mx) : 0.f;
+  const float heat = e / wave_sum(e);
+  const int wy = lane / W, wx = lane - wy * W;
+  const float gx = ((float)wx / (float)(W - 1) - 0.5f) * 2.f;     // kornia create_meshgrid, normalised
+  const float gy = ((float)wy / (float)(W - 1) - 0.5f) * 2.f;
+  const float cx = wave_sum(gx * heat), cy = wave_sum(gy * heat);
+  const float vx = wave_sum(gx * gx * heat) - cx * cx;
+  const float vy = wave_sum(gy * gy * heat) - cy * cy;
+  if (lane == 0) {
+    const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
+    out[0] = kx + (cx * (float)(W / 2) * scale_f + (float)(W / 2));
+    out[1] = ky + (cy * (float)(W / 2) * scale_f + (float)(W / 2));
+    out[2] = sd;
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_fine(const float* __restrict__ win0, const float* __restrict__ win1, int m_max,
+                                              const int32_t* __restrict__ d_count, const float* __restrict__ mix0,
+                                              const float* __restrict__ mix1, const float* __restrict__ kc0,
+                                              const float* __restrict__ kc1, float scale_f, float* __restrict__ out0,
+                                              float* __restrict__ out1) {
+  constexpr int WW = W * W;
+  constexpr int CF = 64;
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int M = d_count ? min(d_count[0], m_max) : m_max;
+  if (m >= M) return;
+  const float* p0 = win0 + (long)m * WW * CF + lane;
+  const float* p1 = win1 + (long)m * WW * CF + lane;
+  float f0[WW], f1[WW];
+#pragma unroll
+  for (int r = 0; r < WW; ++r) { f0[r] = p0[r * CF]; f1[r] = p1[r * CF]; }
+  float q0 = mix0[WW], q1 = mix1[WW];
+#pragma unroll
+  for (int r = 0; r < WW; ++r) { q0 = __builtin_fmaf(mix0[r], f0[r], q0); q1 = __builtin_fmaf(mix1[r], f1[r], q1); }
+
+  const float inv_sqrt_c = 1.0f / sqrtf((float)CF);
+  float p[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) p[r] = r < WW ? q0 * f1[r] : 0.f;
+  const float sim0 = transpose_reduce64(p, lane);
+#pragma unroll
+  for (int r = 0; r < 64; ++r) p[r] = r < WW ? q1 * f0[r] : 0.f;
+  const float sim1 = transpose_reduce64(p, lane);
+
+  soft_argmax<W>(sim0, lane, inv_sqrt_c, scale_f, kc0[m * 2], kc0[m * 2 + 1], out0 + (long)m * 3);
+  soft_argmax<W>(sim1, lane, inv_sqrt_c, scale_f, kc1[m * 2], kc1[m * 2 + 1], out1 + (long)m * 3);
+}
+
+}  // namespace fm
+
+using namespace fm;
+
+extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int layout, int W, int stride,
+                                 int pad, int w_c, const int64_t* b_ids, const int64_t* ids, const int32_t* d_count,
+                                 int m_max, float* out, void* stream) {
+  if (m_max == 0) return FM_OK;
+  if (!feat_f || !b_ids || !ids || !out) return FM_E_NULL;
+  if (N <= 0 || Cf <= 0 || Hf <= 0 || Wf <= 0 || W <= 0 || stride <= 0 || w_c <= 0 || m_max < 0) return FM_E_SHAPE;
+  if (W > 15 || Cf > 512 || (layout == 1 && Cf % 4) || (layout != 0 && layout != 1)) return FM_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == 0) {
+    const size_t smem = (size_t)W * W * (Cf + 1) * sizeof(float);
+    if (smem > 64 * 1024) return FM_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_gather_nchw, dim3(m_max), dim3(256), smem, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c,
+                       b_ids, ids, d_count, m_max, out);
+  } else {
+    hipLaunchKernelGGL(k_gather_nhwc, dim3(m_max), dim3(256), 0, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c, b_ids,
+                       ids, d_count, m_max, out);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
+                             const float* mix0, const float* mix1, const float* mkpts0_c, const float* mkpts1_c,
+                             float scale_f, float* out0, float* out1, void* stream) {
+  if (m_max == 0) return FM_OK;
+  if (!win0 || !win1 || !mix0 || !mix1 || !mkpts0_c || !mkpts1_c || !out0 || !out1) return FM_E_NULL;
+  if (m_max < 0) return FM_E_SHAPE;
+  if (Cf != 64 || (WW != 25 && WW != 49)) return FM_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (m_max + 3) / 4;
+  if (WW == 49)
+    hipLaunchKernelGGL(k_fine<7>, dim3(blocks), dim3(256), 0, st, win0, win1, m_max, d_count, mix0, mix1, mkpts0_c,
+                       mkpts1_c, scale_f, out0, out1);
+  else
+    hipLaunchKernelGGL(k_fine<5>, dim3(blocks), dim3(256), 0, st, win0, win1, m_max, d_count, mix0, mix1, mkpts0_c,
+                       mkpts1_c, scale_f, out0, out1);
+  return (int)hipGetLastError();
+}

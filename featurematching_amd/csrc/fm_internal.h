@@ -1,0 +1,59 @@
+// Internal declarations shared by the translation units of libfmatch_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "fmatch.h"
+
+namespace fm {
+
+constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup owns
+constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
+constexpr int kPrepRows = 32;     // rows one prep workgroup converts
+constexpr float kLog2e = 1.4426950408889634f;
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// Device workspace of the coarse stage; all offsets in bytes from the base.
+struct CoarseWs {
+  int N, L, S, C, Lp, Sp, panels, tiles, splits, slots;
+  // zeroed on every call (contiguous, starts at the base)
+  size_t zero_begin, cand_count, colbest, blocktot, scalars, zero_end;
+  // float16 planes
+  size_t hi0, lo0, hi1, lo1;
+  // per-row / per-column statistics
+  size_t norm0, norm1, bmax0, bmax1;          // row norms, per-prep-block max norms
+  size_t rowA, colA, rowB, colB;              // partial max (pass A) / sum-exp (pass B): rows [N][splits][Lp],
+                                              // columns [N][panels*8][Sp] (one partial per wave)
+  size_t nmr, nmc;                            // -stabiliser*log2e per row / column
+  size_t rsum, csum;                          // softmax denominators per row / column
+  size_t cand_j, cand_conf, rowbest;          // candidate columns, exact conf, best conf per row
+  size_t keep_j, keep_conf, rowcnt;           // selected matches per row (sorted by j)
+  size_t total;
+};
+
+// splits of the column sweep so that panels*splits*N fills the chip once
+int choose_splits(int N, int panels, int tiles);
+CoarseWs coarse_layout(int N, int L, int S, int C, int slots);
+
+struct Scalars {          // lives at ws.scalars (zeroed per call)
+  unsigned flags;         // FM_DEV_* bits
+  int total_matches;
+};
+
+// ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
+hipError_t launch_prep(const float* feat, int N, int rows, int rows_pad, int C,
+                       _Float16* hi, _Float16* lo, float* norms, float* blockmax, unsigned* flags,
+                       hipStream_t st);
+hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st);
+hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);
+hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, const float* feat1,
+                         int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,
+                         float scale_px, const float* scale0, const float* scale1,
+                         int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* k0, float* k1,
+                         float* mconf, int cap, int32_t* d_count, hipStream_t st);
+hipError_t launch_conf_dense(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
+
+}  // namespace fm

@@ -1,0 +1,123 @@
+"""Drop-in stage modules with the reference's names, signatures and ``data``-dict protocol.
+
+    CoarseMatching.forward(feat_c0, feat_c1, data, mask_c0=None, mask_c1=None) -> None
+        (network/utils/coarse_matching_new.py:43)
+    FinePreprocess.forward(feat_f0, feat_f1, feat_c0, feat_c1, data) -> (Tensor, Tensor)
+        (network/module/fine_preprocess.py:32)
+    FineMatching.forward(feat_f0, feat_f1, data) -> None
+        (network/utils/fine_matching_new.py:22)
+
+Constructors take the same lower-cased config sub-dicts as network/net.py:29-32.  The
+computation runs in the HIP kernels of libfmatch_hip.so (see ops.py); only the learned
+``nn.Linear`` layers of FinePreprocess stay on PyTorch-ROCm.
+"""
+from __future__ import annotations
+
+import logging
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+logger = logging.getLogger("featurematching_amd")
+
+
+class CoarseMatching(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.thr = config['thr']
+        self.border_rm = config['border_rm']
+        self.train_coarse_percent = config.get('train_coarse_percent', 1.0)
+        self.train_pad_num_gt_min = config.get('train_pad_num_gt_min', 200)
+        self.temperature = config['dsmax_temperature']
+
+    @torch.no_grad()
+    def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
+        """Writes b_ids, i_ids, j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf into ``data``
+        (coarse_matching_new.py:118-141).  mask_c0/mask_c1 are accepted and ignored, as in the
+        reference.  The dense ``conf_matrix`` (:70) is not materialised: it is consumed only by
+        the training loss, which is outside this path."""
+        if self.training:
+            raise NotImplementedError("training-mode coarse matching (GT id substitution + dense "
+                                      "conf_matrix for the loss) is not part of the inference hot path")
+        scale = data['hw0_i'][0] / data['hw0_c'][0]
+        out = ops.coarse_match(feat_c0, feat_c1, data['hw0_c'], data['hw1_c'], scale, self.thr, self.border_rm,
+                               self.temperature, data.get('scale0'), data.get('scale1'))
+        mconf = out['mconf']
+        data.update({'b_ids': out['b_ids'], 'i_ids': out['i_ids'], 'j_ids': out['j_ids'],
+                     'gt_mask': mconf == 0, 'm_bids': out['b_ids'],
+                     'mkpts0_c': out['mkpts0_c'], 'mkpts1_c': out['mkpts1_c'], 'mconf': mconf})
+
+
+class FinePreprocess(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.cat_c_feat = config['fine_concat_coarse_feat']
+        self.W = config['fine_window_size']
+        d_model_c = config['coarse']['d_model']
+        d_model_f = config['fine']['d_model']
+        self.d_model_f = d_model_f
+        if self.cat_c_feat:
+            self.down_proj = nn.Linear(d_model_c, d_model_f, bias=True)
+            self.merge_feat = nn.Linear(2 * d_model_f, d_model_f, bias=True)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
+        W = self.W
+        stride = data['hw0_f'][0] // data['hw0_c'][0]
+        data.update({'W': W})
+        b_ids, i_ids, j_ids = data['b_ids'], data['i_ids'], data['j_ids']
+        if b_ids.shape[0] == 0:
+            feat0 = torch.empty(0, W ** 2, self.d_model_f, device=feat_f0.device)
+            feat1 = torch.empty(0, W ** 2, self.d_model_f, device=feat_f0.device)
+            return feat0, feat1
+        # windows of the matched cells only (the reference unfolds all L cells, then selects)
+        with torch.no_grad():
+            win0 = ops.gather_windows(feat_f0, b_ids, i_ids, W, stride, data['hw0_c'][1])
+            win1 = ops.gather_windows(feat_f1, b_ids, j_ids, W, stride, data['hw1_c'][1])
+        if self.cat_c_feat:
+            feat_c_win = self.down_proj(torch.cat([feat_c0[b_ids, i_ids], feat_c1[b_ids, j_ids]], 0))
+            feat_cf_win = self.merge_feat(torch.cat([
+                torch.cat([win0, win1], 0),
+                feat_c_win[:, None, :].expand(-1, W ** 2, -1)], -1))
+            win0, win1 = torch.chunk(feat_cf_win, 2, dim=0)
+        return win0, win1
+
+
+class FineMatching(nn.Module):
+    """FineMatching with s2d paradigm; ``window`` fixes the length of the position-mix weights
+    (the reference hard-codes Linear(49, 1), i.e. window 7)."""
+
+    def __init__(self, config=None, window: int = 7):
+        super().__init__()
+        ww = window * window
+        self.mix_feat_0 = nn.Linear(ww, 1, bias=True)
+        self.mix_feat_1 = nn.Linear(ww, 1, bias=True)
+
+    def _mix(self, lin):
+        return torch.cat([lin.weight.reshape(-1), lin.bias.reshape(-1)]).float().contiguous()
+
+    @torch.no_grad()
+    def forward(self, feat_f0, feat_f1, data):
+        M, WW, C = feat_f0.shape
+        W = int(math.sqrt(WW))
+        scale = data['hw0_i'][0] / data['hw0_f'][0]
+        self.M, self.W, self.WW, self.C, self.scale = M, W, WW, C, scale
+        if M == 0:
+            assert self.training is False, "M is always >0, when training, see coarse_matching.py"
+            logger.warning('No matches found in coarse-level.')
+            data.update({'expec_f': torch.empty(0, 3, device=feat_f0.device),
+                         'mkpts0_f': data['mkpts0_c'], 'mkpts1_f': data['mkpts1_c']})
+            return
+        k0, k1 = ops.fine_match(feat_f0, feat_f1, self._mix(self.mix_feat_0), self._mix(self.mix_feat_1),
+                                data['mkpts0_c'], data['mkpts1_c'], scale)
+        data.update({"mkpts0_f": k0, "mkpts1_f": k1})

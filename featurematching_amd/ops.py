@@ -1,0 +1,174 @@
+"""Functional wrappers over the C ABI: torch tensors in, torch tensors out.
+
+torch is used for device memory and streams only; every computation below happens in
+the hand-written HIP kernels of libfmatch_hip.so.  All functions enqueue on the current
+torch stream of the inputs' device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+@dataclass
+class CoarseBuffers:
+    """Capacity-sized device outputs of the coarse stage plus the device-side count."""
+    b_ids: torch.Tensor
+    i_ids: torch.Tensor
+    j_ids: torch.Tensor
+    mkpts0_c: torch.Tensor
+    mkpts1_c: torch.Tensor
+    mconf: torch.Tensor
+    count: torch.Tensor       # int32[2] on device: {M, status bits}
+    cap: int
+    workspace: torch.Tensor   # kept alive until the stream has consumed it
+
+    def read_count(self) -> int:
+        """The single host sync of the path: returns M (raises on a device-side status)."""
+        lib = _lib.load()
+        m = C.c_int32(0)
+        st = lib.fm_read_count(_ptr(self.count), self.cap, C.byref(m), _stream(self.count.device))
+        if st != _lib.FM_OK:
+            err = _lib.FMatchError(st, "fm_coarse_match")
+            err.required = int(m.value)
+            raise err
+        return int(m.value)
+
+    def sliced(self, m: int) -> dict:
+        return dict(b_ids=self.b_ids[:m], i_ids=self.i_ids[:m], j_ids=self.j_ids[:m],
+                    mkpts0_c=self.mkpts0_c[:m], mkpts1_c=self.mkpts1_c[:m], mconf=self.mconf[:m])
+
+
+def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_c, scale_px: float,
+                       thr: float = 0.2, border_rm: int = 2, temperature: float = 0.1,
+                       scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
+                       cap: Optional[int] = None, cand_slots: Optional[int] = None) -> CoarseBuffers:
+    """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
+    capacity-sized device buffers without synchronising."""
+    lib = _lib.load()
+    f0 = _f32c(feat_c0, "feat_c0")
+    f1 = _f32c(feat_c1, "feat_c1")
+    n, l, c = f0.shape
+    s = f1.shape[1]
+    if f1.shape[0] != n or f1.shape[2] != c:
+        raise ValueError(f"feat_c0 {tuple(f0.shape)} and feat_c1 {tuple(f1.shape)} disagree")
+    dev = f0.device
+    if cap is None:
+        cap = n * min(l, s)
+    if cand_slots is None:
+        cand_slots = lib.fm_default_cand_slots(float(thr))
+    nbytes = C.c_size_t(0)
+    _lib.check(lib.fm_coarse_workspace_bytes(n, l, s, c, cand_slots, C.byref(nbytes)), "fm_coarse_workspace_bytes")
+    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    ws_ptr = C.c_void_p(ws.data_ptr() + off)
+    i64 = dict(dtype=torch.int64, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = CoarseBuffers(torch.empty(cap, **i64), torch.empty(cap, **i64), torch.empty(cap, **i64),
+                        torch.empty(cap, 2, **f32), torch.empty(cap, 2, **f32), torch.empty(cap, **f32),
+                        torch.empty(2, dtype=torch.int32, device=dev), cap, ws)
+    sc0 = None if scale0 is None else _f32c(scale0.to(dev), "scale0")
+    sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
+    st = lib.fm_coarse_match(_ptr(f0), _ptr(f1), n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
+                             int(hw1_c[1]), float(temperature), float(thr), int(border_rm), float(scale_px),
+                             _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots,
+                             _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids), _ptr(out.mkpts0_c),
+                             _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), None, _stream(dev))
+    _lib.check(st, "fm_coarse_match")
+    out._keep = (f0, f1, sc0, sc1)   # inputs must outlive the enqueued kernels
+    return out
+
+
+def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
+                 scale0=None, scale1=None) -> dict:
+    """Synchronous form: sliced outputs.  Retries once with a larger capacity (exact ties can
+    exceed N*min(L,S)) or more candidate slots when the device reports either overflow."""
+    kw = dict(cap=None, cand_slots=None)
+    for _ in range(4):
+        buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
+                                 scale0, scale1, **kw)
+        try:
+            m = buf.read_count()
+        except _lib.FMatchError as e:
+            if e.status == _lib.FM_E_CAPACITY:
+                kw['cap'] = int(e.required)
+                continue
+            if e.status == _lib.FM_E_CANDIDATES and (kw['cand_slots'] or 8) < 64:
+                base = kw['cand_slots'] or _lib.load().fm_default_cand_slots(float(thr))
+                kw['cand_slots'] = min(64, base * 2)
+                continue
+            raise
+        return buf.sliced(m)
+    raise RuntimeError("coarse_match: overflow persisted after retries")
+
+
+def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor, w: int, stride: int,
+                   w_c: int, pad: int = 2, count: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Window crop (fine_preprocess.py:43-50) of the selected coarse cells only.
+    feat_f is the logical [N,Cf,Hf,Wf] tensor, stored NCHW-contiguous or channels_last."""
+    lib = _lib.load()
+    if not feat_f.is_cuda:
+        raise RuntimeError("feat_f must live on the GPU: the HIP path has no CPU fallback")
+    n, cf, hf, wf = feat_f.shape
+    if feat_f.dtype != torch.float32:
+        feat_f = feat_f.float()
+    if feat_f.is_contiguous():
+        layout = 0
+    elif feat_f.is_contiguous(memory_format=torch.channels_last):
+        layout = 1
+    else:
+        feat_f, layout = feat_f.contiguous(), 0
+    m_max = int(b_ids.shape[0])
+    if out is None:
+        out = torch.empty(m_max, w * w, cf, dtype=torch.float32, device=feat_f.device)
+    if m_max == 0:
+        return out
+    st = lib.fm_gather_windows(_ptr(feat_f), n, cf, hf, wf, layout, w, stride, pad, w_c, _ptr(b_ids), _ptr(ids),
+                               _ptr(count), m_max, _ptr(out), _stream(feat_f.device))
+    _lib.check(st, "fm_gather_windows")
+    return out
+
+
+def fine_match(win0: torch.Tensor, win1: torch.Tensor, mix0: torch.Tensor, mix1: torch.Tensor,
+               mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor, scale_f: float,
+               count: Optional[torch.Tensor] = None):
+    """Fine stage (fine_matching_new.py:50-79).  mix0/mix1 = float32 [WW+1] (weight, bias).
+    Returns (mkpts0_f, mkpts1_f), each [M,3] = (x, y, std)."""
+    lib = _lib.load()
+    win0 = _f32c(win0, "win0")
+    win1 = _f32c(win1, "win1")
+    m_max, ww, cf = win0.shape
+    dev = win0.device
+    out0 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
+    out1 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
+    if m_max == 0:
+        return out0, out1
+    k0 = _f32c(mkpts0_c, "mkpts0_c")
+    k1 = _f32c(mkpts1_c, "mkpts1_c")
+    st = lib.fm_fine_match(_ptr(win0), _ptr(win1), m_max, _ptr(count), ww, cf, _ptr(_f32c(mix0, "mix0")),
+                           _ptr(_f32c(mix1, "mix1")), _ptr(k0), _ptr(k1), float(scale_f), _ptr(out0), _ptr(out1),
+                           _stream(dev))
+    _lib.check(st, "fm_fine_match")
+    return out0, out1

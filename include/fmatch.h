@@ -1,0 +1,125 @@
+/*
+ * fmatch.h - C ABI of libfmatch_hip.so: the MI355X (gfx950) coarse-to-fine matching
+ * hot path.  This is the drop-in boundary for the three stage modules the reference
+ * calls from network/net.py:75,78,83 (paths relative to the reference repository):
+ *
+ *   fm_coarse_match    <- CoarseMatching.forward + get_coarse_match
+ *                         network/utils/coarse_matching_new.py:43-143
+ *   fm_gather_windows  <- FinePreprocess.forward, window crop + select
+ *                         network/module/fine_preprocess.py:43-50
+ *   fm_fine_match      <- FineMatching.forward
+ *                         network/utils/fine_matching_new.py:22-79
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no framework types.  Every pointer
+ *     marked [dev] is device memory owned by the caller; the library never
+ *     allocates or frees device memory and keeps no global state.
+ *   - All work is enqueued on the caller's stream (a hipStream_t passed as void*;
+ *     NULL = the default stream); no call synchronises the host except
+ *     fm_read_count.  The caller has made the target device current.
+ *   - Return value: 0 = FM_OK, < 0 = invalid use (see enum), > 0 = a hipError_t
+ *     passed through.  Functions never throw.
+ *   - Data-dependent conditions discovered on the device (capacity overflow,
+ *     candidate-slot overflow, non-finite / out-of-range descriptors) are
+ *     reported through the status word next to the match count (fm_read_count).
+ */
+#ifndef FMATCH_H_
+#define FMATCH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FM_VERSION 100 /* 0.1.0 */
+
+enum fm_status {
+  FM_OK = 0,
+  FM_E_NULL = -1,        /* a required pointer is NULL */
+  FM_E_SHAPE = -2,       /* L != h0c*w0c, S != h1c*w1c, non-positive size ... */
+  FM_E_UNSUPPORTED = -3, /* C not in {64,128,256}, Cf != 64, W not in {5,7}, thr <= 0 ... */
+  FM_E_WORKSPACE = -4,   /* workspace too small / misaligned */
+  FM_E_CAPACITY = -5,    /* (device status) more matches than `cap`; M_out = required */
+  FM_E_CANDIDATES = -6,  /* (device status) a row produced more than cand_slots candidates */
+  FM_E_RANGE = -7        /* (device status) descriptor not finite or |x| >= 32768 */
+};
+
+/* device status bits stored in d_count[1] */
+#define FM_DEV_CAPACITY 1
+#define FM_DEV_CANDIDATES 2
+#define FM_DEV_RANGE 4
+
+int fm_version(void);
+const char* fm_strerror(int status);
+
+/* Candidate slots per coarse row the sparse assignment keeps: conf > thr implies
+ * softmax(row) > thr, so at most ceil(1/thr)-1 entries of a row can qualify; the
+ * default adds head-room for the float16 screening margin. */
+int fm_default_cand_slots(float thr);
+
+/* Bytes of device workspace fm_coarse_match needs (256-byte aligned base). */
+int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t* bytes);
+
+/*
+ * Coarse stage (coarse_matching_new.py:43-143, eval mode).
+ *   feat0 [N,L,C], feat1 [N,S,C]     [dev] float32, row-major (l = y*w0c + x)
+ *   sim = feat0.feat1^T / (C*temperature); conf = softmax(sim,1)*softmax(sim,2)
+ *   keep (b,i,j): conf > thr, both cells >= border_rm from their image border,
+ *   conf == row max == column max; emitted sorted by (b,i,j) like torch.where.
+ *   scale_px = hw0_i[0]/hw0_c[0] (:126); scale0/scale1 optional [dev] float32 [N,2]
+ *   per-sample multipliers (:127-128) or NULL.
+ * Outputs (capacity `cap` matches, all [dev]):
+ *   b_ids,i_ids,j_ids int64[cap]; mkpts0_c,mkpts1_c float32[cap,2] (x,y px);
+ *   mconf float32[cap]; d_count int32[2] = {M, status bits}.
+ *   conf_matrix: optional [dev] float32 [N,L,S] (data['conf_matrix'], :70) or NULL.
+ */
+int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S, int C,
+                    int h0c, int w0c, int h1c, int w1c,
+                    float temperature, float thr, int border_rm, float scale_px,
+                    const float* scale0, const float* scale1,
+                    void* workspace, size_t workspace_bytes, int cand_slots,
+                    int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                    float* mkpts0_c, float* mkpts1_c, float* mconf,
+                    int cap, int32_t* d_count, float* conf_matrix, void* stream);
+
+/* Diagnostic only: workspace layout of fm_coarse_match (10 ints, then 27 byte offsets;
+ * order documented in csrc/api.hip) so tests can inspect intermediate statistics. */
+int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out);
+
+/* Copy {M, status} to the host and wait for the stream (the one host sync of the
+ * path, where the reference's torch.where syncs: coarse_matching_new.py:109).
+ * Returns FM_OK or the error the status bits encode; *m_out is min(M, cap) on
+ * success and the required capacity on FM_E_CAPACITY. */
+int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, void* stream);
+
+/*
+ * Window crop (fine_preprocess.py:43-50): out[m, wy*W+wx, c] =
+ * feat_f[b_ids[m], c, stride*y - pad + wy, stride*x - pad + wx] (0 outside the
+ * map) with (y,x) = divmod(ids[m], w_c).  layout 0 = NCHW contiguous (the
+ * reference's), 1 = NHWC (channels-last storage of the same tensor).
+ * The number of windows is min(*d_count, m_max) when d_count != NULL (device
+ * side, no host sync), else m_max.  out [m_max, W*W, Cf] float32.
+ */
+int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int layout,
+                      int W, int stride, int pad, int w_c,
+                      const int64_t* b_ids, const int64_t* ids,
+                      const int32_t* d_count, int m_max, float* out, void* stream);
+
+/*
+ * Fine stage (fine_matching_new.py:50-79): dual-direction window correlation,
+ * softmax heat-map, spatial expectation, std.  win0/win1 [m_max, WW, Cf];
+ * mix0/mix1 [dev] float32 [WW+1] = Linear(WW,1) weight then bias;
+ * out0/out1 [m_max,3] = (x_px, y_px, std) with
+ *   xy = mkpts_c + coords*(W/2)*scale_f + W/2        (:75-76)
+ */
+int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t* d_count,
+                  int WW, int Cf, const float* mix0, const float* mix1,
+                  const float* mkpts0_c, const float* mkpts1_c, float scale_f,
+                  float* out0, float* out1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMATCH_H_ */

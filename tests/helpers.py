@@ -34,10 +34,6 @@ def case_inputs(meta, dist, with_fine=True, ww=49):
     return out
 
 
-def guard_band_ok(conf_ref_dense_row_fn=None):
-    raise NotImplementedError
-
-
 def compare_match_sets(got, ref, conf_tol=1e-5):
     """got/ref: dicts with b_ids,i_ids,j_ids,mconf (numpy).  Returns (only_got, only_ref, max_conf_err)
     where the first two are lists of (b,i,j,conf) present on one side only."""

@@ -1,0 +1,83 @@
+"""The C-ABI library: loads, exports every symbol include/fmatch.h declares, and validates
+arguments on the host.  No compute call is made (runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from featurematching_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fmatch.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert {"fm_coarse_match", "fm_gather_windows", "fm_fine_match", "fm_read_count",
+            "fm_coarse_workspace_bytes", "fm_version", "fm_strerror"} <= set(syms)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in fmatch.h but not exported"
+    assert set(_lib.SIGNATURES) == set(syms)
+
+
+def test_version_and_messages():
+    lib = _lib.load()
+    assert lib.fm_version() == 100
+    assert lib.fm_strerror(0) == b"ok"
+    for code in range(-7, 0):
+        assert lib.fm_strerror(code) not in (b"", b"unknown fmatch status")
+    assert lib.fm_default_cand_slots(0.2) == 8
+    assert lib.fm_default_cand_slots(0.05) == 32
+    assert lib.fm_default_cand_slots(0.01) == 64
+
+
+def test_workspace_query_and_argument_checks():
+    lib = _lib.load()
+    n = C.c_size_t(0)
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n)) == 0
+    per_pair = n.value
+    assert 15e6 < per_pair < 60e6          # 4 float16 planes (9.96 MB) + partial statistics
+    assert lib.fm_coarse_workspace_bytes(64, 4800, 4800, 256, 8, C.byref(n)) == 0
+    assert n.value < 64 * per_pair * 1.2
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 100, 8, C.byref(n)) == -3     # C unsupported
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 7, C.byref(n)) == -3     # slots not a power of 2
+    assert lib.fm_coarse_workspace_bytes(0, 4800, 4800, 256, 8, C.byref(n)) == -2
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, None) == -1
+    # NULL / shape checks return before any device work
+    null = None
+    args = [null, null, 1, 64, 64, 64, 8, 8, 8, 8, 0.1, 0.2, 2, 8.0, null, null, null, 0, 8,
+            null, null, null, null, null, null, 0, null, null, null]
+    assert lib.fm_coarse_match(*args) == -1
+    assert lib.fm_gather_windows(null, 1, 64, 8, 8, 0, 7, 4, 2, 2, null, null, null, 4, null, null) == -1
+    assert lib.fm_gather_windows(null, 1, 64, 8, 8, 0, 7, 4, 2, 2, null, null, null, 0, null, null) == 0   # M == 0
+    assert lib.fm_fine_match(null, null, 0, null, 49, 64, null, null, null, null, 2.0, null, null, null) == 0
+    assert lib.fm_fine_match(null, null, 3, null, 49, 64, null, null, null, null, 2.0, null, null, null) == -1
+
+
+def test_layout_query_is_consistent():
+    lib = _lib.load()
+    arr = (C.c_int64 * 37)()
+    assert lib.fm_debug_coarse_layout(1, 4800, 4800, 256, 8, arr, 37) == 0
+    v = list(arr)
+    assert v[:4] == [1, 4800, 4800, 256]
+    assert v[4] == 4864 and v[5] == 4800 and v[6] == 19 and v[7] == 75      # Lp, Sp, panels, tiles
+    assert 1 <= v[8] <= 32 and v[6] * v[8] <= 256                            # one round of the 256 CUs
+    offs = v[10:]
+    assert all(o % 256 == 0 for o in offs)
+    n = C.c_size_t(0)
+    lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n))
+    assert offs[-1] == n.value
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from featurematching_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.coarse_match(torch.zeros(1, 64, 64), torch.zeros(1, 64, 64), (8, 8), (8, 8), 8.0)

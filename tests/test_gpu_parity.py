@@ -1,0 +1,248 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference-generated golden
+fixtures, the CPU oracle on fresh seeded inputs, and size-independent properties.
+
+Bars: identical (b,i,j) inlier sets outside a guard band around thr,
+mconf within 1e-5 (abs) of the reference, coarse keypoints bit-exact, fine keypoints within
+1e-3 px (north star: 0.5 px).  Guard band: a reference/HIP disagreement is tolerated only when
+the entry's conf lies within GUARD of thr, where float32 re-orderings of the reference's own
+sums already flip the decision (hard part 3).
+"""
+import numpy as np
+import pytest
+import torch
+
+from featurematching_amd import modules, ops, synth
+from featurematching_amd import _lib
+from oracle import matcher_ref as orc
+from helpers import load_golden, load_kats, case_inputs, compare_match_sets
+
+pytestmark = pytest.mark.gpu
+
+GUARD = 2e-5
+CONF_TOL = 1e-5
+FINE_TOL_PX = 1e-3
+DEV = "cuda:0"
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def _assert_coarse(got, ref, thr=0.2):
+    got, ref = _np(got), _np(ref)
+    only_g, only_r, err = compare_match_sets(got, ref)
+    bad = [(k, v) for k, v in only_g + only_r if abs(v - thr) > GUARD]
+    assert not bad, f"match sets differ outside the guard band: {bad[:5]} (+{len(bad) - 5 if len(bad) > 5 else 0})"
+    assert err <= CONF_TOL, f"mconf differs by {err}"
+    if not only_g and not only_r:
+        assert np.array_equal(got['i_ids'], ref['i_ids']) and np.array_equal(got['j_ids'], ref['j_ids'])
+        assert np.array_equal(got['b_ids'], ref['b_ids'])                      # same (b,i,j) order
+        assert np.array_equal(got['mkpts0_c'], ref['mkpts0_c']) and np.array_equal(got['mkpts1_c'], ref['mkpts1_c'])
+    assert got['i_ids'].dtype == np.int64 and got['mkpts0_c'].dtype == np.float32
+    return len(only_g) + len(only_r)
+
+
+def _run_coarse(f0, f1, hw_i, hw0_c, hw1_c, thr=0.2, border=2, temp=0.1, scale0=None, scale1=None):
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    s0 = None if scale0 is None else torch.as_tensor(scale0, device=DEV)
+    s1 = None if scale1 is None else torch.as_tensor(scale1, device=DEV)
+    return ops.coarse_match(t0, t1, hw0_c, hw1_c, hw_i[0] / hw0_c[0], thr, border, temp, s0, s1)
+
+
+# ------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("name,dist", [("cfg1_peaky", "peaky"), ("cfg1_borderline", "borderline"),
+                                       ("cfg2_peaky", "peaky"), ("cfg2_borderline", "borderline"),
+                                       ("cfg3_first2_peaky", "peaky")])
+def test_full_path_against_reference_fixture(name, dist):
+    g = load_golden(name)
+    inp = case_inputs(g['meta'], dist)
+    out = _run_coarse(inp['f0'], inp['f1'], inp['hw_i'], inp['hw_c'], inp['hw_c'])
+    ndiff = _assert_coarse(out, g)
+    if ndiff:
+        pytest.skip(f"{ndiff} guard-band flips: fine outputs not comparable index by index")
+    ff0 = torch.as_tensor(inp['ff0'], device=DEV)
+    ff1 = torch.as_tensor(inp['ff1'], device=DEV)
+    wc = inp['hw_c'][1]
+    win0 = ops.gather_windows(ff0, out['b_ids'], out['i_ids'], 7, 4, wc)
+    win1 = ops.gather_windows(ff1, out['b_ids'], out['j_ids'], 7, 4, wc)
+    pos = torch.arange(1, 50, dtype=torch.float64, device=DEV).view(1, 49, 1)
+    ch = torch.arange(1, 65, dtype=torch.float64, device=DEV).view(1, 1, -1)
+    np.testing.assert_allclose((win0.double() * pos * ch).sum((1, 2)).cpu().numpy(), g['win0_sum'], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose((win1.double() * pos * ch).sum((1, 2)).cpu().numpy(), g['win1_sum'], rtol=1e-12, atol=1e-9)
+    w0, b0, w1, b1 = inp['mix']
+    mix0 = torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=DEV)
+    mix1 = torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=DEV)
+    k0, k1 = ops.fine_match(win0, win1, mix0, mix1, out['mkpts0_c'], out['mkpts1_c'], inp['hw_i'][0] / inp['hw_f'][0])
+    assert np.abs(k0.cpu().numpy()[:, :2] - g['mkpts0_f'][:, :2]).max() <= FINE_TOL_PX
+    assert np.abs(k1.cpu().numpy()[:, :2] - g['mkpts1_f'][:, :2]).max() <= FINE_TOL_PX
+    np.testing.assert_allclose(k0.cpu().numpy()[:, 2], g['mkpts0_f'][:, 2], atol=1e-4)
+    np.testing.assert_allclose(k1.cpu().numpy()[:, 2], g['mkpts1_f'][:, 2], atol=1e-4)
+
+
+def test_cfg5_coarse_against_reference_fixture():
+    g = load_golden("cfg5_peaky")                       # 1024x1024 -> L = S = 16384
+    inp = case_inputs(g['meta'], "peaky", with_fine=False)
+    out = _run_coarse(inp['f0'], inp['f1'], inp['hw_i'], inp['hw_c'], inp['hw_c'])
+    _assert_coarse(out, g)
+
+
+def test_kats_against_reference_fixture():
+    for name, k in load_kats().items():
+        hw = [int(v) for v in k['hw']]
+        thr, brm, temp = float(k['cfg'][0]), int(k['cfg'][1]), float(k['cfg'][2])
+        out = _run_coarse(k['f0'], k['f1'], hw[0:2], hw[4:6], hw[6:8], thr, brm, temp, k.get('scale0'), k.get('scale1'))
+        assert _assert_coarse(out, k, thr) == 0, name
+        if name == "tie":       # both tied entries kept, same conf bits
+            i = out['i_ids'].cpu().numpy()
+            assert len(i) != len(set(i.tolist()))
+        if 'fine_seed' in k and out['i_ids'].shape[0]:
+            seed = int(k['fine_seed'])
+            ff0, ff1 = synth.fine_maps(seed, k['f0'].shape[0], 64, hw[4] * 4, hw[5] * 4)
+            w0, b0, w1, b1 = synth.mix_weights(seed, 49)
+            win0 = ops.gather_windows(torch.as_tensor(ff0, device=DEV), out['b_ids'], out['i_ids'], 7, 4, hw[5])
+            win1 = ops.gather_windows(torch.as_tensor(ff1, device=DEV), out['b_ids'], out['j_ids'], 7, 4, hw[7])
+            mix0 = torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=DEV)
+            mix1 = torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=DEV)
+            k0, k1 = ops.fine_match(win0, win1, mix0, mix1, out['mkpts0_c'], out['mkpts1_c'], hw[0] / (hw[4] * 4))
+            assert np.abs(k0.cpu().numpy() - k['mkpts0_f']).max() <= FINE_TOL_PX, name
+            assert np.abs(k1.cpu().numpy() - k['mkpts1_f']).max() <= FINE_TOL_PX, name
+
+
+# ------------------------------------------------------------------ oracle on fresh inputs
+@pytest.mark.parametrize("hc,wc,c,n,dist", [(7, 9, 64, 3, "peaky"), (15, 17, 128, 2, "borderline"),
+                                            (33, 20, 256, 1, "borderline"), (16, 16, 256, 5, "peaky")])
+def test_coarse_ragged_shapes_vs_oracle(hc, wc, c, n, dist):
+    """L not a multiple of the 256-row panel, S not a multiple of the 64-column tile, every C."""
+    f0, f1 = synth.coarse_descriptors(100 + hc, n, hc * wc, c, dist)
+    ref = orc.coarse_match(f0, f1, (hc * 8, wc * 8), (hc, wc), (hc, wc), 0.2, 1, 0.1)
+    out = _run_coarse(f0, f1, (hc * 8, wc * 8), (hc, wc), (hc, wc), border=1)
+    _assert_coarse(out, ref)
+
+
+def test_coarse_rectangular_l_ne_s():
+    f0 = 3.0 * synth.normal(31, 1, (2, 40 * 50, 128))
+    f1 = f0[:, synth.permutation(31, 3, 2000)[:1500]] + 0.3 * synth.normal(31, 2, (2, 1500, 128))
+    ref = orc.coarse_match(f0, f1, (320, 400), (40, 50), (30, 50), 0.2, 2, 0.1)
+    out = _run_coarse(f0, f1, (320, 400), (40, 50), (30, 50))
+    _assert_coarse(out, ref)
+    assert ref['i_ids'].shape[0] > 500
+
+
+def test_small_magnitude_and_temperature():
+    """Descriptors far below 1 (float16 'lo' plane goes subnormal) and another temperature."""
+    f0, f1 = synth.coarse_descriptors(41, 1, 400, 256, "borderline")
+    f0, f1 = f0 * 0.02, f1 * 0.02
+    ref = orc.coarse_match(f0, f1, (160, 160), (20, 20), (20, 20), 0.1, 2, 0.0005)
+    out = _run_coarse(f0, f1, (160, 160), (20, 20), (20, 20), thr=0.1, temp=0.0005)
+    _assert_coarse(out, ref, 0.1)
+    assert ref['i_ids'].shape[0] > 50
+
+
+def test_non_finite_input_is_reported():
+    f0, f1 = synth.coarse_descriptors(42, 1, 64, 64, "peaky")
+    f0[0, 3, 5] = np.inf
+    with pytest.raises(_lib.FMatchError) as e:
+        _run_coarse(f0, f1, (64, 64), (8, 8), (8, 8))
+    assert e.value.status == _lib.FM_E_RANGE
+
+
+@pytest.mark.parametrize("w", [5, 7])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_gather_windows_vs_oracle(w, channels_last):
+    ff0, _ = synth.fine_maps(51, 2, 64, 48, 64)
+    wc = 16
+    ids = torch.tensor([0, 15, 11 * 16 + 15, 11 * 16, 37, 100, 191, 5, 16], dtype=torch.int64)
+    b = torch.tensor([0, 1, 0, 1, 1, 0, 1, 0, 0], dtype=torch.int64)
+    ref = orc.crop_windows(ff0, b, ids, w, 4, wc)
+    t = torch.as_tensor(ff0, device=DEV)
+    if channels_last:
+        t = t.contiguous(memory_format=torch.channels_last)
+    got = ops.gather_windows(t, b.to(DEV), ids.to(DEV), w, 4, wc)
+    assert torch.equal(got.cpu(), ref)                   # a gather is bit-exact
+
+
+@pytest.mark.parametrize("w", [5, 7])
+def test_fine_match_vs_oracle(w):
+    m, ww = 1000, w * w
+    win0 = synth.normal(61, 1, (m, ww, 64))
+    win1 = synth.normal(61, 2, (m, ww, 64))
+    win1[:200] = win0[:200] * 3.0                        # sharp heat-maps too
+    w0, b0, w1, b1 = synth.mix_weights(61, ww)
+    kc0 = (synth.uniform(61, 3, m * 2).reshape(m, 2) * 600).astype(np.float32)
+    kc1 = (synth.uniform(61, 4, m * 2).reshape(m, 2) * 600).astype(np.float32)
+    r0, r1 = orc.fine_match(win0, win1, w0, b0, w1, b1, kc0, kc1, 2.0)
+    mix0 = torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=DEV)
+    mix1 = torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=DEV)
+    g0, g1 = ops.fine_match(torch.as_tensor(win0, device=DEV), torch.as_tensor(win1, device=DEV), mix0, mix1,
+                            torch.as_tensor(kc0, device=DEV), torch.as_tensor(kc1, device=DEV), 2.0)
+    assert (g0.cpu() - r0).abs().max().item() <= FINE_TOL_PX
+    assert (g1.cpu() - r1).abs().max().item() <= FINE_TOL_PX
+
+
+# ------------------------------------------------------------------ drop-in modules
+def test_modules_follow_the_data_dict_protocol():
+    g = load_golden("cfg1_peaky")
+    inp = case_inputs(g['meta'], "peaky")
+    cfg = {'fine_concat_coarse_feat': True, 'fine_window_size': 7, 'coarse': {'d_model': 64}, 'fine': {'d_model': 64}}
+    cm = modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1,
+                                 'train_coarse_percent': 1.0, 'train_pad_num_gt_min': 200}).eval()
+    fp = modules.FinePreprocess(cfg).to(DEV).eval()
+    fm = modules.FineMatching({'d_model': 64}).to(DEV).eval()
+    w0, b0, w1, b1 = inp['mix']
+    with torch.no_grad():
+        fm.mix_feat_0.weight.copy_(torch.as_tensor(w0).view(1, -1)); fm.mix_feat_0.bias.fill_(float(b0))
+        fm.mix_feat_1.weight.copy_(torch.as_tensor(w1).view(1, -1)); fm.mix_feat_1.bias.fill_(float(b1))
+        fp.down_proj.weight.zero_(); fp.down_proj.bias.zero_()          # identity context merge, as in the
+        fp.merge_feat.weight.zero_(); fp.merge_feat.bias.zero_()        # fixture generator
+        fp.merge_feat.weight[:, :64] = torch.eye(64)
+    data = {'hw0_i': inp['hw_i'], 'hw1_i': inp['hw_i'], 'hw0_c': inp['hw_c'], 'hw1_c': inp['hw_c'],
+            'hw0_f': inp['hw_f'], 'hw1_f': inp['hw_f'], 'bs': 1}
+    fc0, fc1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    cm(fc0, fc1, data)
+    for key in ('b_ids', 'i_ids', 'j_ids', 'gt_mask', 'm_bids', 'mkpts0_c', 'mkpts1_c', 'mconf'):
+        assert key in data
+    assert data['gt_mask'].dtype == torch.bool and data['b_ids'].dtype == torch.int64
+    with torch.no_grad():
+        u0, u1 = fp(torch.as_tensor(inp['ff0'], device=DEV), torch.as_tensor(inp['ff1'], device=DEV), fc0, fc1, data)
+    assert data['W'] == 7 and u0.shape == (data['b_ids'].shape[0], 49, 64)
+    fm(u0, u1, data)
+    assert data['mkpts0_f'].shape == (u0.shape[0], 3)
+    assert np.abs(data['mkpts0_f'].cpu().numpy()[:, :2] - g['mkpts0_f'][:, :2]).max() <= 2e-3
+    assert np.abs(data['mkpts1_f'].cpu().numpy()[:, :2] - g['mkpts1_f'][:, :2]).max() <= 2e-3
+    # M == 0 branch (fine_matching_new.py:40-48)
+    d0 = dict(data, mkpts0_c=data['mkpts0_c'][:0], mkpts1_c=data['mkpts1_c'][:0], b_ids=data['b_ids'][:0],
+              i_ids=data['i_ids'][:0], j_ids=data['j_ids'][:0])
+    e0, e1 = fp(torch.as_tensor(inp['ff0'], device=DEV), torch.as_tensor(inp['ff1'], device=DEV), fc0, fc1, d0)
+    assert e0.shape == (0, 49, 64)
+    fm(e0, e1, d0)
+    assert d0['expec_f'].shape == (0, 3) and d0['mkpts0_f'].shape == (0, 2)
+
+
+# ------------------------------------------------------------------ properties at full size
+def test_properties_at_cfg2_size():
+    cfg = synth.CONFIGS['cfg2']
+    sh = synth.config_shapes(cfg)
+    f0, f1 = synth.coarse_descriptors(77, 2, sh['l'], 256, "peaky")
+    hw_c = (sh['hc'], sh['wc'])
+    a = _np(_run_coarse(f0, f1, (480, 640), hw_c, hw_c))
+    b = _np(_run_coarse(f0, f1, (480, 640), hw_c, hw_c))
+    for k in a:                                           # deterministic, bit for bit
+        assert np.array_equal(a[k], b[k]), k
+    key = a['b_ids'] * (1 << 40) + a['i_ids'] * (1 << 20) + a['j_ids']
+    assert np.all(np.diff(key) > 0)                       # torch.where order, no duplicates
+    assert a['mconf'].min() > 0.2
+    # border cells never match
+    for ids in (a['i_ids'], a['j_ids']):
+        y, x = ids // sh['wc'], ids % sh['wc']
+        assert y.min() >= 2 and y.max() < sh['hc'] - 2 and x.min() >= 2 and x.max() < sh['wc'] - 2
+    # batch of two == the two pairs run alone
+    s0 = _np(_run_coarse(f0[:1], f1[:1], (480, 640), hw_c, hw_c))
+    s1 = _np(_run_coarse(f0[1:], f1[1:], (480, 640), hw_c, hw_c))
+    m0 = (a['b_ids'] == 0).sum()
+    assert np.array_equal(a['i_ids'][:m0], s0['i_ids']) and np.array_equal(a['j_ids'][m0:], s1['j_ids'])
+    assert np.array_equal(a['mconf'][:m0], s0['mconf']) and np.array_equal(a['mconf'][m0:], s1['mconf'])
+    # swapping the two images transposes the match set (dual softmax is symmetric)
+    t = _np(_run_coarse(f1[:1], f0[:1], (480, 640), hw_c, hw_c))
+    fwd = set(zip(s0['i_ids'].tolist(), s0['j_ids'].tolist()))
+    bwd = set(zip(t['j_ids'].tolist(), t['i_ids'].tolist()))
+    assert len(fwd ^ bwd) <= 2                            # conf differs in the last bits only

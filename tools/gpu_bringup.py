@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Bring-up diagnostics for the coarse stage on a real GPU: runs fm_coarse_match on small
+seeded cases and compares every intermediate statistic in the workspace (float16 planes,
+pass-A maxima, stabilisers, pass-B sums, candidate lists) with a float64 numpy computation,
+then the final matches with the CPU oracle.  Prints a report; exits non-zero on mismatch.
+
+    python tools/gpu_bringup.py [--case small|cfg1|cfg2] [--dist peaky|borderline]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from featurematching_amd import _lib, ops, synth  # noqa: E402
+from oracle import matcher_ref as orc  # noqa: E402  (checker only)
+
+NAMES = ["cand_count", "colbest", "scalars", "blocktot", "hi0", "lo0", "hi1", "lo1", "norm0", "norm1", "bmax0",
+         "bmax1", "rowA", "colA", "rowB", "colB", "nmr", "nmc", "rsum", "csum", "cand_j", "cand_conf", "rowbest",
+         "keep_j", "keep_conf", "rowcnt", "total"]
+
+
+def layout(n, l, s, c, slots):
+    lib = _lib.load()
+    arr = (C.c_int64 * 37)()
+    _lib.check(lib.fm_debug_coarse_layout(n, l, s, c, slots, arr, 37), "layout")
+    v = list(arr)
+    d = dict(zip(["N", "L", "S", "C", "Lp", "Sp", "panels", "tiles", "splits", "slots"], v[:10]))
+    d.update(dict(zip(NAMES, v[10:])))
+    return d
+
+
+def view(ws, base_off, off, count, dtype):
+    nbytes = count * torch.empty(0, dtype=dtype).element_size()
+    return ws[base_off + off: base_off + off + nbytes].view(dtype).cpu().numpy()
+
+
+def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
+    ok = True
+    n, l, c = f0.shape
+    s = f1.shape[1]
+    dev = torch.device("cuda:0")
+    t0, t1 = torch.as_tensor(f0, device=dev), torch.as_tensor(f1, device=dev)
+    buf = ops.coarse_match_async(t0, t1, hw_c0, hw_c1, 8.0, thr, border, temp)
+    torch.cuda.synchronize()
+    slots = _lib.load().fm_default_cand_slots(thr)
+    lay = layout(n, l, s, c, slots)
+    ws = buf.workspace
+    base = (-ws.data_ptr()) % 256
+    Lp, Sp, splits, panels = lay["Lp"], lay["Sp"], lay["splits"], lay["panels"]
+    print(f"== {label}: N={n} L={l} S={s} C={c} Lp={Lp} Sp={Sp} panels={panels} tiles={lay['tiles']} splits={splits}")
+    cnt = buf.count.cpu().numpy()
+    print("   d_count =", cnt)
+
+    inv_ct = 1.0 / (c * temp)
+    # planes
+    hi0 = view(ws, base, lay["hi0"], n * Lp * c, torch.float16).reshape(n, Lp, c)
+    lo0 = view(ws, base, lay["lo0"], n * Lp * c, torch.float16).reshape(n, Lp, c)
+    hi1 = view(ws, base, lay["hi1"], n * Sp * c, torch.float16).reshape(n, Sp, c)
+    lo1 = view(ws, base, lay["lo1"], n * Sp * c, torch.float16).reshape(n, Sp, c)
+    e_hi = np.abs(hi0[:, :l].astype(np.float32) - f0.astype(np.float16).astype(np.float32)).max()
+    rec = np.abs(hi0[:, :l].astype(np.float64) + lo0[:, :l].astype(np.float64) - f0).max()
+    rec1 = np.abs(hi1[:, :s].astype(np.float64) + lo1[:, :s].astype(np.float64) - f1).max()
+    pad = max(np.abs(hi0[:, l:]).max() if Lp > l else 0, np.abs(hi1[:, s:]).max() if Sp > s else 0)
+    print(f"   planes: hi err {e_hi:.2e}  hi+lo recon err {rec:.2e}/{rec1:.2e}  pad max {pad}")
+    ok &= e_hi == 0 and rec < 1e-5 and pad == 0
+
+    norm0 = view(ws, base, lay["norm0"], n * Lp, torch.float32).reshape(n, Lp)
+    ok_n = np.allclose(norm0[:, :l], np.linalg.norm(f0, axis=2), rtol=1e-5)
+    print("   norms ok:", ok_n)
+    ok &= ok_n
+
+    rowA = view(ws, base, lay["rowA"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).max(1)
+    colA = view(ws, base, lay["colA"], n * panels * 8 * Sp, torch.float32).reshape(n, panels * 8, Sp).max(1)
+    nmr = view(ws, base, lay["nmr"], n * Lp, torch.float32).reshape(n, Lp)
+    nmc = view(ws, base, lay["nmc"], n * Sp, torch.float32).reshape(n, Sp)
+    rsum = view(ws, base, lay["rsum"], n * Lp, torch.float32).reshape(n, Lp)
+    csum = view(ws, base, lay["csum"], n * Sp, torch.float32).reshape(n, Sp)
+    ccount = view(ws, base, lay["cand_count"], n * Lp, torch.int32).reshape(n, Lp)
+    cand_j = view(ws, base, lay["cand_j"], n * Lp * slots, torch.int32).reshape(n, Lp, slots)
+    log2e = 1.4426950408889634
+    for b in range(n):
+        dot_hi = hi0[b, :l].astype(np.float64) @ hi1[b, :s].astype(np.float64).T
+        dot = f0[b].astype(np.float64) @ f1[b].astype(np.float64).T
+        sim = dot * inv_ct
+        ea = np.abs(rowA[b, :l] - dot_hi.max(1)).max() / max(1.0, np.abs(dot_hi).max())
+        ec = np.abs(colA[b, :s] - dot_hi.max(0)).max() / max(1.0, np.abs(dot_hi).max())
+        print(f"   [b={b}] passA rel err rows {ea:.2e} cols {ec:.2e}")
+        ok &= ea < 1e-5 and ec < 1e-5
+        mhat_r = -nmr[b, :l] / log2e
+        mhat_c = -nmc[b, :s] / log2e
+        gap_r = sim.max(1) - mhat_r
+        gap_c = sim.max(0) - mhat_c
+        print(f"   [b={b}] stabiliser gap rows [{gap_r.min():.3e}, {gap_r.max():.3e}] cols [{gap_c.min():.3e}, {gap_c.max():.3e}] (must be >= 0)")
+        ok &= gap_r.min() >= 0 and gap_c.min() >= 0
+        rs_ref = np.exp(sim - mhat_r[:, None]).sum(1)
+        cs_ref = np.exp(sim - mhat_c[None, :]).sum(0)
+        er = np.abs(rsum[b, :l] / rs_ref - 1).max()
+        ec2 = np.abs(csum[b, :s] / cs_ref - 1).max()
+        print(f"   [b={b}] passB sums rel err rows {er:.2e} cols {ec2:.2e}")
+        ok &= er < 2e-5 and ec2 < 2e-5
+        # candidate superset: every (i,j) with conf > thr must be listed
+        pr = np.exp(sim - sim.max(1, keepdims=True)); pr /= pr.sum(1, keepdims=True)
+        pc = np.exp(sim - sim.max(0, keepdims=True)); pc /= pc.sum(0, keepdims=True)
+        conf = pr * pc
+        need = np.argwhere(conf > thr)
+        missing = [(i, j) for i, j in need if j not in cand_j[b, i, :min(ccount[b, i], slots)]]
+        print(f"   [b={b}] candidates: {int(ccount[b, :l].sum())} listed, max/row {ccount[b, :l].max()}, "
+              f"{len(need)} needed, {len(missing)} missing")
+        ok &= not missing
+    # final
+    hw_i = (hw_c0[0] * 8, hw_c0[1] * 8)
+    ref = orc.coarse_match(f0, f1, hw_i, hw_c0, hw_c1, thr, border, temp)
+    m = int(cnt[0])
+    got = {k: v.cpu().numpy() for k, v in buf.sliced(m).items()}
+    same = (m == ref['i_ids'].shape[0] and np.array_equal(got['b_ids'], ref['b_ids'].numpy())
+            and np.array_equal(got['i_ids'], ref['i_ids'].numpy()) and np.array_equal(got['j_ids'], ref['j_ids'].numpy()))
+    print(f"   final: M={m} ref M={ref['i_ids'].shape[0]} ids identical: {same}")
+    if same and m:
+        print(f"   mconf max err {np.abs(got['mconf'] - ref['mconf'].numpy()).max():.2e}; "
+              f"kpts equal: {np.array_equal(got['mkpts0_c'], ref['mkpts0_c'].numpy()) and np.array_equal(got['mkpts1_c'], ref['mkpts1_c'].numpy())}")
+    ok &= same
+    return ok
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="small")
+    ap.add_argument("--dist", default="peaky")
+    a = ap.parse_args()
+    ok = True
+    if a.case == "small":
+        for (hc, wc, c) in [(8, 8, 64), (16, 16, 64), (12, 20, 128), (20, 30, 256)]:
+            f0, f1 = synth.coarse_descriptors(7, 2, hc * wc, c, a.dist)
+            ok &= run(f0, f1, (hc, wc), (hc, wc), label=f"{hc}x{wc} C={c}")
+    else:
+        cfg = synth.CONFIGS[a.case]
+        sh = synth.config_shapes(cfg)
+        f0, f1 = synth.coarse_descriptors(cfg['seed'], 1, sh['l'], cfg['c'], a.dist)
+        ok &= run(f0, f1, (sh['hc'], sh['wc']), (sh['hc'], sh['wc']), label=a.case)
+    print("BRINGUP", "OK" if ok else "FAILED")
+    sys.exit(0 if ok else 1)
