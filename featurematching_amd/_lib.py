@@ -32,6 +32,8 @@ SIGNATURES = {
     "fm_coarse_match": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
                              _p, C.c_size_t, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
+    "fm_debug_launch_corr": (_i, [_p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "fm_read_count": (_i, [_p, _i, C.POINTER(C.c_int32), _p]),
     "fm_gather_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),

@@ -21,6 +21,7 @@ int choose_splits(int N, int panels, int tiles) {
 CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   CoarseWs w;
   memset(&w, 0, sizeof(w));
+  C = padded_channels(C);
   w.N = N; w.L = L; w.S = S; w.C = C; w.slots = slots;
   w.Lp = round_up(L, kPanelRows);
   w.Sp = round_up(S, kTileCols);
@@ -40,11 +41,12 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
   w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
-  w.bmax0 = take(rows / kPrepRows * 4); w.bmax1 = take(cols / kPrepRows * 4);
+  w.bmax0 = take(rows / prep_rows(C) * 4); w.bmax1 = take(cols / prep_rows(C) * 4);
   w.rowA = take(rows * w.splits * 4); w.colA = take(cols * w.panels * 8 * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * 8 * 4);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
   w.rsum = take(rows * 4); w.csum = take(cols * 4);
+  w.nmr2 = take(rows * 4); w.nmc2 = take(cols * 4);
   w.cand_j = take(rows * slots * 4); w.cand_conf = take(rows * slots * 4); w.rowbest = take(rows * 4);
   w.keep_j = take(rows * slots * 4); w.keep_conf = take(rows * slots * 4); w.rowcnt = take(rows * 4);
   w.total = o;
@@ -62,7 +64,7 @@ extern "C" const char* fm_strerror(int s) {
     case FM_OK: return "ok";
     case FM_E_NULL: return "required pointer is NULL";
     case FM_E_SHAPE: return "inconsistent or non-positive shape";
-    case FM_E_UNSUPPORTED: return "unsupported configuration (C in {64,128,256}, Cf = 64, W in {5,7}, thr in (0,1))";
+    case FM_E_UNSUPPORTED: return "unsupported configuration (C % 4 == 0 and C <= 256, Cf = 64, W in {5,7}, thr in (0,1))";
     case FM_E_WORKSPACE: return "workspace too small or not 256-byte aligned";
     case FM_E_CAPACITY: return "more matches than the output capacity";
     case FM_E_CANDIDATES: return "a coarse row exceeded its candidate slots (raise cand_slots)";
@@ -84,7 +86,7 @@ static bool valid_slots(int s) { return s >= 1 && s <= 64 && (s & (s - 1)) == 0;
 extern "C" int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t* bytes) {
   if (!bytes) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
-  if ((C != 64 && C != 128 && C != 256) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
+  if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   *bytes = coarse_layout(N, L, S, C, cand_slots).total;
   return FM_OK;
 }
@@ -117,7 +119,7 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   if (!feat0 || !feat1 || !workspace || !d_count) return FM_E_NULL;
   if (cap > 0 && (!b_ids || !i_ids || !j_ids || !mkpts0_c || !mkpts1_c || !mconf)) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
-  if ((C != 64 && C != 128 && C != 256) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
+  if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
   if (conf_matrix) return FM_E_UNSUPPORTED;   // dense conf_matrix (training surface) not built yet
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
@@ -129,10 +131,10 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   hipError_t e = hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, st);
   if (e != hipSuccess) return (int)e;
   unsigned* flags = (unsigned*)(base + w.scalars);
-  e = launch_prep(feat0, N, L, w.Lp, C, (_Float16*)(base + w.hi0), (_Float16*)(base + w.lo0),
+  e = launch_prep(feat0, N, L, w.Lp, C, w.C, (_Float16*)(base + w.hi0), (_Float16*)(base + w.lo0),
                   (float*)(base + w.norm0), (float*)(base + w.bmax0), flags, st);
   if (e != hipSuccess) return (int)e;
-  e = launch_prep(feat1, N, S, w.Sp, C, (_Float16*)(base + w.hi1), (_Float16*)(base + w.lo1),
+  e = launch_prep(feat1, N, S, w.Sp, C, w.C, (_Float16*)(base + w.hi1), (_Float16*)(base + w.lo1),
                   (float*)(base + w.norm1), (float*)(base + w.bmax1), flags, st);
   if (e != hipSuccess) return (int)e;
   e = launch_corr(0, w, base, inv_ct, thr, st);
@@ -143,9 +145,33 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   if (e != hipSuccess) return (int)e;
   e = launch_reduce(1, w, base, inv_ct, st);
   if (e != hipSuccess) return (int)e;
+  e = launch_corr(2, w, base, inv_ct, thr, st);   // exits immediately unless pass B's screening overflowed
+  if (e != hipSuccess) return (int)e;
   e = launch_select(w, base, feat0, feat1, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
                     b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, st);
   return (int)e;
+}
+
+// Diagnostic: launch ONE correlation sweep (mode 0 = pass A, 1 = pass B) on a workspace that a
+// previous fm_coarse_match call with the same shapes has filled, so that a benchmark can bracket
+// exactly that kernel with events.  Pass B's candidate counters are zeroed first (outside any
+// bracket the caller places after this function's memset is enqueued... the memset precedes the kernel).
+extern "C" int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_slots, float temperature,
+                                    float thr, int mode, void* stream) {
+  if (!workspace) return FM_E_NULL;
+  if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
+  if (!valid_channels(C) || !valid_slots(cand_slots) || (mode < 0 || mode > 2)) return FM_E_UNSUPPORTED;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  hipStream_t st = (hipStream_t)stream;
+  return (int)launch_corr(mode, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st);
+}
+
+// Diagnostic: zero the per-call counters (what fm_coarse_match does first).
+extern "C" int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream) {
+  if (!workspace) return FM_E_NULL;
+  if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  return (int)hipMemsetAsync((char*)workspace + w.zero_begin, 0, w.zero_end - w.zero_begin, (hipStream_t)stream);
 }
 
 extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, void* stream) {

@@ -10,6 +10,11 @@
 //                    with the stabilisers of k_reduce_max, and the sparse candidate list
 //                    {(i,j): s_ij - m^_i > ln thr  and  s_ij - c^_j > ln thr}, a superset
 //                    of every entry with conf > thr (coarse_matching_new.py:99).
+//   pass C (MODE 2): only when pass B's screening overflowed a row's candidate slots (flat
+//                    similarity rows, e.g. an untrained network): the same product again, screened
+//                    with the now-known softmax denominators, log2 P_row > log2 thr and
+//                    log2 P_col > log2 thr, which at most 1/thr entries of a row can pass.
+//                    The kernel is always enqueued and exits at once when it is not needed.
 //
 // Structure (one workgroup = 8 waves = 256 rows of image 0; cf. SURVEY.md 7, hard part 2):
 //   * each wave keeps its 32 rows x C of image-0 descriptors as MFMA A-fragments in
@@ -33,7 +38,7 @@ struct CorrArgs {
   const _Float16* hi0; const _Float16* lo0; const _Float16* hi1; const _Float16* lo1;
   const float* nmr; const float* nmc;
   float* rowpart; float* colpart;
-  int* cand_count; int* cand_j; unsigned* flags;
+  int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, slots;
   float k;    // log2(e) / (C*T): raw dot product -> log2-domain similarity
   float lt;   // log2(thr)
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   constexpr int INSTR_PER_WAVE = PLANE_BYTES / 1024 / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  if (MODE == 2 && !(*a.flags & FM_INT_SCREEN_OVERFLOW)) return;   // uniform: fast screening sufficed
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -189,11 +195,13 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         float cc = __builtin_fmaf(x, a.k, nmc);
         if (col_edge && !cvalid) { rr = -INFINITY; cc = -INFINITY; }
         if (row_edge && (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L)) { rr = -INFINITY; cc = -INFINITY; }
-        rstat[g] += __builtin_amdgcn_exp2f(rr);
-        cstat += __builtin_amdgcn_exp2f(cc);
+        if (MODE == 1) {
+          rstat[g] += __builtin_amdgcn_exp2f(rr);
+          cstat += __builtin_amdgcn_exp2f(cc);
+        }
         best = fmaxf(best, fminf(rr, cc));
       }
-      cstat += __shfl_xor(cstat, 32);
+      if (MODE == 1) cstat += __shfl_xor(cstat, 32);
       if (__any(best > a.lt)) {      // rare: some lane holds a candidate in this unit
         int rbase = wrow0 + 4 * h;
         asm volatile("" : "+v"(rbase));   // keep the 16 per-row addresses from being hoisted (and spilled)
@@ -206,13 +214,13 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
           if (rr > a.lt && cc > a.lt && row < a.L && cvalid) {
             const long grow = (long)b * a.Lp + row;
             const int pos = atomicAdd(&a.cand_count[grow], 1);
-            if (pos < a.slots) a.cand_j[grow * a.slots + pos] = col;
-            else atomicOr(a.flags, (unsigned)FM_DEV_CANDIDATES);
+            if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = col; a.cand_x[grow * a.slots + pos] = x; }
+            else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
           }
         }
       }
     }
-    if (h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
+    if (MODE != 2 && h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
   };
 
   __syncthreads();
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   }
   if (late && t1 > t0) epilogue(2 * t1 - 1);
 
+  if (MODE == 2) return;
   // ---- row statistics of this workgroup's column range: reduce over the 32 lanes of each half ----
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -262,17 +271,21 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   CorrArgs a;
   a.hi0 = (const _Float16*)(base + w.hi0); a.lo0 = (const _Float16*)(base + w.lo0);
   a.hi1 = (const _Float16*)(base + w.hi1); a.lo1 = (const _Float16*)(base + w.lo1);
-  a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
+  a.nmr = (const float*)(base + (mode == 2 ? w.nmr2 : w.nmr));
+  a.nmc = (const float*)(base + (mode == 2 ? w.nmc2 : w.nmc));
   a.rowpart = (float*)(base + (mode ? w.rowB : w.rowA));
   a.colpart = (float*)(base + (mode ? w.colB : w.colA));
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
+  a.cand_x = (float*)(base + w.cand_conf);   // raw dot product now, replaced by conf in k_cand_conf
   a.flags = (unsigned*)(base + w.scalars);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
   a.splits = w.splits; a.tiles_per_split = (w.tiles + w.splits - 1) / w.splits; a.slots = w.slots;
-  a.k = inv_ct * kLog2e; a.lt = log2f(thr);
+  a.k = inv_ct * kLog2e;
+  a.lt = log2f(thr) - (mode == 2 ? 2e-4f : 0.f);   // pass C compares rounded log-softmax values: small guard
   const int blocks = w.N * w.splits * w.panels;
 #define FM_CORR_CASE(CC)                                                     \
-  case CC: return mode ? launch_corr_t<CC, 1>(a, blocks, st) : launch_corr_t<CC, 0>(a, blocks, st);
+  case CC: return mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)            \
+                 : (mode ? launch_corr_t<CC, 1>(a, blocks, st) : launch_corr_t<CC, 0>(a, blocks, st));
   switch (w.C) {
     FM_CORR_CASE(64)
     FM_CORR_CASE(128)

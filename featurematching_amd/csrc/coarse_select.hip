@@ -1,5 +1,5 @@
 // Coarse stage, sparse assignment on the candidate list of pass B:
-//   k_cand_conf : exact float32 conf of every candidate, best conf per row / column
+//   k_cand_conf : float32 conf of every candidate from its pass-B dot product, best conf per row / column
 //   k_cand_keep : threshold + mutual nearest neighbour + border, sort a row's matches by j
 //   k_emit      : deterministic prefix offsets -> outputs in (b, i, j) order
 //
@@ -36,14 +36,9 @@ __global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
   const int cnt = (b < a.N && i < a.L) ? min(a.cand_count[grow], a.slots) : 0;
   if (slot < cnt) {
     const int j = a.cand_j[grow * a.slots + slot];
-    const float4* p0 = reinterpret_cast<const float4*>(a.feat0 + ((long)b * a.L + i) * a.C);
-    const float4* p1 = reinterpret_cast<const float4*>(a.feat1 + ((long)b * a.S + j) * a.C);
-    double dot = 0.0;
-    for (int c = 0; c < a.C / 4; ++c) {
-      const float4 u = p0[c], v = p1[c];
-      dot += (double)u.x * v.x + (double)u.y * v.y + (double)u.z * v.z + (double)u.w * v.w;
-    }
-    const float x = (float)dot;
+    // the accumulator value pass B produced for this entry: the same number that entered the row
+    // and column sums, so numerator and denominator are consistent (as in the reference's softmax)
+    const float x = a.cand_conf[grow * a.slots + slot];
     const float rs = a.rsum[grow], cs = a.csum[(long)b * a.Sp + j];
     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmr[grow])) / rs;
     const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmc[(long)b * a.Sp + j])) / cs;
@@ -128,7 +123,7 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
     }
     if (blockIdx.x == gridDim.x - 1) {
       a.d_count[0] = run;
-      a.d_count[1] = (int)(a.scal->flags | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
+      a.d_count[1] = (int)((a.scal->flags & 7u) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
     }
   }
   __syncthreads();

@@ -78,45 +78,99 @@ __global__ __launch_bounds__(256) void k_gather_nhwc(const float* __restrict__ f
 //   q1 / sim1 symmetrically (:51,54,57)            -> refines keypoint 1
 //   heat = softmax(sim / sqrt(C)); coords = E[grid]; std = sum sqrt(clamp(var, 1e-10))  (:58-73)
 //   out  = mkpts_c + (coords * (W//2) * scale + W//2), std                              (:75-79)
-// The WW cross-lane sums of sim are done with one butterfly "transpose-reduce": after the six
-// exchange steps lane r holds sim[r], so the softmax runs with lane = window position.
+// The WW cross-lane sums of sim are done with one butterfly "transpose-reduce" built from DPP and
+// permlane swaps (no LDS): after the exchange steps every lane holds one sim[pos], so the softmax
+// runs with lane = window position.
 // ----------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return v;
+// Cross-lane exchange without LDS: v[lane ^ MASK] via DPP (1, 2, 4, 8) or the gfx950 permlane swaps
+// (16, 32), folded straight into the reduction operator.
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, 0xf, BANK, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-  return v;
+struct OpAdd { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+
+// op(v[lane], v[lane ^ MASK]) in every lane
+template <int MASK, class Op>
+__device__ __forceinline__ float pair_op(float v) {
+  if constexpr (MASK == 1) return Op::f(v, dpp_mov<0xB1, 0xf>(v, v));           // quad_perm [1,0,3,2]
+  else if constexpr (MASK == 2) return Op::f(v, dpp_mov<0x4E, 0xf>(v, v));      // quad_perm [2,3,0,1]
+  else if constexpr (MASK == 4) {
+    float t = dpp_mov<0x104, 0x5>(v, v);      // row_shl:4 into banks 0,2 (lanes with bit 2 clear read lane+4)
+    t = dpp_mov<0x114, 0xA>(t, v);            // row_shr:4 into banks 1,3 (lanes with bit 2 set read lane-4)
+    return Op::f(v, t);
+  } else if constexpr (MASK == 8) return Op::f(v, dpp_mov<0x128, 0xf>(v, v));   // row_ror:8
+  else if constexpr (MASK == 16) {
+    // v_permlane16_swap a, b: odd rows of a <-> even rows of b.  With a = b = v: a = {r0,r0,r2,r2},
+    // b = {r1,r1,r3,r3}, so op(a, b) is the pair result in every lane.  Inline asm because hipcc
+    // (ROCm 7.2) returns the first result twice from the builtin when both operands are one value;
+    // s_nop 1 = the two wait states between a VALU write of an operand and the swap.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return Op::f(a, b);
+  } else {
+    float a = v, b = v;   // lanes 32-63 of a <-> lanes 0-31 of b: a = {lo,lo}, b = {hi,hi}
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return Op::f(a, b);
+  }
 }
 
-// in: p[k] = this lane's term of sum k (k < 64).  out: lane l returns sum_lanes p[l].
-__device__ __forceinline__ float transpose_reduce64(float (&p)[64], int lane) {
+template <class Op>
+__device__ __forceinline__ float wave_all(float v) {
+  v = pair_op<1, Op>(v); v = pair_op<2, Op>(v); v = pair_op<4, Op>(v);
+  v = pair_op<8, Op>(v); v = pair_op<16, Op>(v); v = pair_op<32, Op>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_all<OpAdd>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_all<OpMax>(v); }
+
+// One butterfly step of the transpose-reduce: p[0..2*HALF) -> p[0..HALF); lanes with bit MASK set
+// continue with the upper half of the sums, the others with the lower half.
+template <int HALF, int MASK, int NP>
+__device__ __forceinline__ void tr_step(float (&p)[NP], int lane) {
+  const bool up = (lane & MASK) != 0;
 #pragma unroll
-  for (int half = 32; half >= 1; half >>= 1) {
-    const bool up = (lane & half) != 0;
-#pragma unroll
-    for (int k = 0; k < half; ++k) {
-      const float keep = up ? p[k + half] : p[k];
-      const float send = up ? p[k] : p[k + half];
-      p[k] = keep + __shfl_xor(send, half);
-    }
+  for (int k = 0; k < HALF; ++k) {
+    const float a = pair_op<MASK, OpAdd>(p[k]);
+    const float b = pair_op<MASK, OpAdd>(p[k + HALF]);
+    p[k] = up ? b : a;
+  }
+}
+
+// in: p[k] = this lane's term of sum k.  out: the lane whose tr_index is k returns sum_lanes p[k].
+// The steps with many pairs use the cheapest exchanges (quad permutes); see tr_index for the map.
+template <int NP>
+__device__ __forceinline__ float transpose_reduce(float (&p)[NP], int lane) {
+  if constexpr (NP == 64) {
+    tr_step<32, 1>(p, lane); tr_step<16, 2>(p, lane); tr_step<8, 8>(p, lane);
+    tr_step<4, 4>(p, lane); tr_step<2, 16>(p, lane); tr_step<1, 32>(p, lane);
+  } else {
+    tr_step<16, 1>(p, lane); tr_step<8, 2>(p, lane); tr_step<4, 8>(p, lane);
+    tr_step<2, 4>(p, lane); tr_step<1, 16>(p, lane);
+    p[0] = pair_op<32, OpAdd>(p[0]);     // the two half-waves hold the two halves of the channels
   }
   return p[0];
 }
+template <int NP>
+__device__ __forceinline__ int tr_index(int lane) {
+  if constexpr (NP == 64)
+    return 32 * (lane & 1) + 16 * ((lane >> 1) & 1) + 8 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1) +
+           2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+  else
+    return 16 * (lane & 1) + 8 * ((lane >> 1) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 4) & 1);
+}
 
+// pos = window position this lane holds (sim is that position's similarity), on = lane takes part
 template <int W>
-__device__ __forceinline__ void soft_argmax(float sim, int lane, float inv_sqrt_c, float scale_f, float kx, float ky,
-                                            float* out) {
-  constexpr int WW = W * W;
-  const bool on = lane < WW;
+__device__ __forceinline__ void soft_argmax(float sim, int pos, bool on, int lane, float inv_sqrt_c, float scale_f,
+                                            float kx, float ky, float* out) {
   const float x = on ? sim * inv_sqrt_c : -INFINITY;
   const float mx = wave_max(x);
   const float e = on ? __expf(x - mx) : 0.f;
   const float heat = e / wave_sum(e);
-  const int wy = lane / W, wx = lane - wy * W;
+  const int wy = pos / W, wx = pos - wy * W;
   const float gx = ((float)wx / (float)(W - 1) - 0.5f) * 2.f;     // kornia create_meshgrid, normalised
   const float gy = ((float)wy / (float)(W - 1) - 0.5f) * 2.f;
   const float cx = wave_sum(gx * heat), cy = wave_sum(gy * heat);
@@ -152,16 +206,19 @@ __global__ __launch_bounds__(256) void k_fine(const float* __restrict__ win0, co
   for (int r = 0; r < WW; ++r) { q0 = __builtin_fmaf(mix0[r], f0[r], q0); q1 = __builtin_fmaf(mix1[r], f1[r], q1); }
 
   const float inv_sqrt_c = 1.0f / sqrtf((float)CF);
-  float p[64];
+  constexpr int NP = WW > 32 ? 64 : 32;      // butterfly width
+  float p[NP];
 #pragma unroll
-  for (int r = 0; r < 64; ++r) p[r] = r < WW ? q0 * f1[r] : 0.f;
-  const float sim0 = transpose_reduce64(p, lane);
+  for (int r = 0; r < NP; ++r) p[r] = r < WW ? q0 * f1[r] : 0.f;
+  const float sim0 = transpose_reduce<NP>(p, lane);
 #pragma unroll
-  for (int r = 0; r < 64; ++r) p[r] = r < WW ? q1 * f0[r] : 0.f;
-  const float sim1 = transpose_reduce64(p, lane);
+  for (int r = 0; r < NP; ++r) p[r] = r < WW ? q1 * f0[r] : 0.f;
+  const float sim1 = transpose_reduce<NP>(p, lane);
 
-  soft_argmax<W>(sim0, lane, inv_sqrt_c, scale_f, kc0[m * 2], kc0[m * 2 + 1], out0 + (long)m * 3);
-  soft_argmax<W>(sim1, lane, inv_sqrt_c, scale_f, kc1[m * 2], kc1[m * 2 + 1], out1 + (long)m * 3);
+  const int pos = tr_index<NP>(lane);
+  const bool on = pos < WW && lane < NP;
+  soft_argmax<W>(sim0, pos, on, lane, inv_sqrt_c, scale_f, kc0[m * 2], kc0[m * 2 + 1], out0 + (long)m * 3);
+  soft_argmax<W>(sim1, pos, on, lane, inv_sqrt_c, scale_f, kc1[m * 2], kc1[m * 2 + 1], out1 + (long)m * 3);
 }
 
 }  // namespace fm

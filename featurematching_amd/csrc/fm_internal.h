@@ -10,10 +10,16 @@ namespace fm {
 
 constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup owns
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
-constexpr int kPrepRows = 32;     // rows one prep workgroup converts
+// rows one prep workgroup converts (C = padded channel count)
+inline int prep_rows(int C) { return C >= 128 ? 8 : 16; }
 constexpr float kLog2e = 1.4426950408889634f;
+// internal status bit (not reported): pass B's max-based screening overflowed a row's slots
+constexpr unsigned FM_INT_SCREEN_OVERFLOW = 8u;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// descriptor channels the kernels are instantiated for; smaller C is zero-padded by k_prep_split
+inline int padded_channels(int c) { return c <= 64 ? 64 : (c <= 128 ? 128 : 256); }
+inline bool valid_channels(int c) { return c >= 4 && c <= 256 && c % 4 == 0; }
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 // Device workspace of the coarse stage; all offsets in bytes from the base.
@@ -29,6 +35,7 @@ struct CoarseWs {
                                               // columns [N][panels*8][Sp] (one partial per wave)
   size_t nmr, nmc;                            // -stabiliser*log2e per row / column
   size_t rsum, csum;                          // softmax denominators per row / column
+  size_t nmr2, nmc2;                          // nmr - log2(rsum), nmc - log2(csum): log-softmax offsets
   size_t cand_j, cand_conf, rowbest;          // candidate columns, exact conf, best conf per row
   size_t keep_j, keep_conf, rowcnt;           // selected matches per row (sorted by j)
   size_t total;
@@ -44,7 +51,7 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 };
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
-hipError_t launch_prep(const float* feat, int N, int rows, int rows_pad, int C,
+hipError_t launch_prep(const float* feat, int N, int rows, int rows_pad, int c_in, int C,
                        _Float16* hi, _Float16* lo, float* norms, float* blockmax, unsigned* flags,
                        hipStream_t st);
 hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st);

@@ -39,7 +39,7 @@ enum fm_status {
   FM_OK = 0,
   FM_E_NULL = -1,        /* a required pointer is NULL */
   FM_E_SHAPE = -2,       /* L != h0c*w0c, S != h1c*w1c, non-positive size ... */
-  FM_E_UNSUPPORTED = -3, /* C not in {64,128,256}, Cf != 64, W not in {5,7}, thr <= 0 ... */
+  FM_E_UNSUPPORTED = -3, /* C > 256 or C % 4 != 0, Cf != 64, W not in {5,7}, thr <= 0 ... */
   FM_E_WORKSPACE = -4,   /* workspace too small / misaligned */
   FM_E_CAPACITY = -5,    /* (device status) more matches than `cap`; M_out = required */
   FM_E_CANDIDATES = -6,  /* (device status) a row produced more than cand_slots candidates */
@@ -87,6 +87,13 @@ int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S,
 /* Diagnostic only: workspace layout of fm_coarse_match (10 ints, then 27 byte offsets;
  * order documented in csrc/api.hip) so tests can inspect intermediate statistics. */
 int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out);
+
+/* Diagnostic only: launch one correlation sweep (mode 0 = max pass, 1 = sum pass) on a workspace
+ * filled by a previous fm_coarse_match of the same shapes / zero the per-call counters; used by
+ * bench.py to bracket the dominant kernel with events on its own stream. */
+int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_slots,
+                         float temperature, float thr, int mode, void* stream);
+int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream);
 
 /* Copy {M, status} to the host and wait for the stream (the one host sync of the
  * path, where the reference's torch.where syncs: coarse_matching_new.py:109).

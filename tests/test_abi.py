@@ -46,7 +46,9 @@ def test_workspace_query_and_argument_checks():
     assert 15e6 < per_pair < 60e6          # 4 float16 planes (9.96 MB) + partial statistics
     assert lib.fm_coarse_workspace_bytes(64, 4800, 4800, 256, 8, C.byref(n)) == 0
     assert n.value < 64 * per_pair * 1.2
-    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 100, 8, C.byref(n)) == -3     # C unsupported
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 102, 8, C.byref(n)) == -3     # C % 4 != 0
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 512, 8, C.byref(n)) == -3     # C > 256
+    assert lib.fm_coarse_workspace_bytes(1, 64, 64, 32, 8, C.byref(n)) == 0           # zero-padded to 64
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 7, C.byref(n)) == -3     # slots not a power of 2
     assert lib.fm_coarse_workspace_bytes(0, 4800, 4800, 256, 8, C.byref(n)) == -2
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, None) == -1

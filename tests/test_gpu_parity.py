@@ -128,14 +128,26 @@ def test_coarse_rectangular_l_ne_s():
     assert ref['i_ids'].shape[0] > 500
 
 
-def test_small_magnitude_and_temperature():
-    """Descriptors far below 1 (float16 'lo' plane goes subnormal) and another temperature."""
+def test_small_magnitude_descriptors():
+    """Descriptors far below 1: the float16 'lo' plane goes subnormal."""
     f0, f1 = synth.coarse_descriptors(41, 1, 400, 256, "borderline")
     f0, f1 = f0 * 0.02, f1 * 0.02
-    ref = orc.coarse_match(f0, f1, (160, 160), (20, 20), (20, 20), 0.1, 2, 0.0005)
-    out = _run_coarse(f0, f1, (160, 160), (20, 20), (20, 20), thr=0.1, temp=0.0005)
+    ref = orc.coarse_match(f0, f1, (160, 160), (20, 20), (20, 20), 0.1, 2, 0.1 * 0.02 ** 2)
+    out = _run_coarse(f0, f1, (160, 160), (20, 20), (20, 20), thr=0.1, temp=0.1 * 0.02 ** 2)
     _assert_coarse(out, ref, 0.1)
     assert ref['i_ids'].shape[0] > 50
+
+
+def test_flat_rows_take_the_exact_screening_pass():
+    """Half of the image-0 cells have near-constant similarity rows: every entry of such a row is
+    within ln(thr) of the row maximum, the max-based screening of the sum pass overflows its
+    candidate slots and the (device-side, conditional) third sweep must recover the exact set."""
+    f0, f1 = synth.coarse_descriptors(43, 2, 30 * 40, 128, "peaky")
+    f0[:, ::2] *= 0.01
+    ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
+    out = _run_coarse(f0, f1, (240, 320), (30, 40), (30, 40))
+    _assert_coarse(out, ref)
+    assert 100 < ref['i_ids'].shape[0] < 900
 
 
 def test_non_finite_input_is_reported():

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Per-stage timing of the hot path on one GPU (events on the launch stream, median of --iters).
+
+    python tools/time_kernels.py [--workload cfg2] [--window 5] [--iters 30] [--layout nchw|nhwc]
+"""
+import argparse
+import ctypes as C
+import os
+import statistics
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from featurematching_amd import _lib, ops, synth  # noqa: E402
+import bench  # noqa: E402
+
+
+def timed(fn, iters, pre=None):
+    ts = []
+    for _ in range(iters):
+        if pre:
+            pre()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return statistics.median(ts), min(ts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--window", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--dist", default="peaky")
+    ap.add_argument("--layout", default="nchw")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    wl = bench.WORKLOADS[a.workload]
+    p = bench.Pair(wl, 1017, a.window, dev, a.dist)
+    if a.layout == "nhwc":
+        p.ff0 = p.ff0.contiguous(memory_format=torch.channels_last)
+        p.ff1 = p.ff1.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    buf, k0, k1 = p.step()
+    torch.cuda.synchronize()
+    m = buf.read_count()
+    print(f"workload {a.workload}: N={p.n} L={p.l} C={p.c} window={a.window} M={m}")
+    ws = buf.workspace
+    ptr = C.c_void_p(ws.data_ptr() + ((-ws.data_ptr()) % 256))
+    slots = lib.fm_default_cand_slots(0.2)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w = a.window
+    rows = []
+
+    def reset():
+        lib.fm_debug_reset_counters(ptr, p.n, p.l, p.l, p.c, slots, st)
+
+    rows.append(("coarse (whole fm_coarse_match)",
+                 timed(lambda: ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap), a.iters)))
+    rows.append(("  corr max pass (k_corr<.,0>)",
+                 timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 0, st), a.iters)))
+    rows.append(("  corr sum pass (k_corr<.,1>)",
+                 timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 1, st), a.iters, reset)))
+    rows.append(("gather windows (both images)", timed(lambda: (
+        ops.gather_windows(p.ff0, buf.b_ids, buf.i_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win0),
+        ops.gather_windows(p.ff1, buf.b_ids, buf.j_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win1)), a.iters)))
+    rows.append(("fine match", timed(lambda: ops.fine_match(p.win0, p.win1, p.mix0, p.mix1, buf.mkpts0_c, buf.mkpts1_c,
+                                                              2.0, count=buf.count), a.iters)))
+    rows.append(("whole step (eager)", timed(lambda: p.step(), a.iters)))
+    flops = 2.0 * p.n * p.l * p.l * p.c
+    for name, (med, mn) in rows:
+        extra = ""
+        if "corr" in name:
+            extra = f"   {flops / (med * 1e-6) / 1e12:8.1f} TFLOP/s algorithmic"
+        print(f"{name:36s} median {med:9.1f} us   min {mn:9.1f} us{extra}")
+    wbytes = 2 * m * w * w * 64 * 4
+    print(f"window bytes (both images): {wbytes / 1e6:.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
