@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfmatch_hip.so")
+# FMATCH_LIB lets the tuning tools load an experimental build (same ABI) of the library
+LIB_PATH = os.environ.get("FMATCH_LIB") or os.path.join(_HERE, "lib", "libfmatch_hip.so")
 
 FM_OK = 0
 FM_E_CAPACITY = -5

@@ -34,6 +34,14 @@ namespace fm {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// B-fragment prefetch distance (k-steps) in the sum / max sweeps
+#ifndef FM_PF_SUM
+#define FM_PF_SUM 2
+#endif
+#ifndef FM_PF_MAX
+#define FM_PF_MAX 4
+#endif
+
 struct CorrArgs {
   const _Float16* hi0; const _Float16* lo0; const _Float16* hi1; const _Float16* lo1;
   const float* nmr; const float* nmc;
@@ -108,6 +116,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   };
 
   if (t0 < t1) stage(t0, 0);
+#ifdef FM_ABL_NOSTAGE
+  if (t0 + 1 < t1) stage(t0 + 1, 1);
+#endif
 
   // ---- this wave's 32 rows as A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7) ----
   const int wrow0 = panel * kPanelRows + wv * 32;
@@ -136,27 +147,76 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   float* colout = a.colpart + (((long)b * a.panels + panel) * 8 + wv) * a.Sp;
 
   f32x16 acc;
+#if defined(FM_ABL_NOMFMA)
+#pragma unroll
+  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#endif
 
-  // one unit = 32 rows x 32 columns x C: the accumulator tile of this wave
+  // one unit = 32 rows x 32 columns x C: the accumulator tile of this wave.
+  // B fragments are read PF k-steps ahead into a small register ring so that the LDS latency
+  // (~128 cycles) hides behind the MFMAs in between (96 cycles per k-step in the sum pass, 32 in the
+  // max pass).  hipcc re-sinks plain LDS loads next to their use (one register pair, lgkmcnt(0) per
+  // k-step), so the reads and their counted waits are inline asm; each wait names the fragments it
+  // covers as "+v" operands, which keeps the MFMAs that consume them below it.  LDS returns in order,
+  // so lgkmcnt(N) with N = reads issued after the needed ones is exact for our own reads and only
+  // more conservative if the compiler has LDS/SMEM operations of its own in flight.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto mfma_unit = [&](int u) {
-    const char* buf = smem + (((u >> 1) - t0) & 1) * BUF_BYTES;
-    const int lb = (u & 1) ? lanebase1 : lanebase0;
+    const unsigned base = lds0 + (((u >> 1) - t0) & 1) * BUF_BYTES + ((u & 1) ? lanebase1 : lanebase0);
+    constexpr int PF = MODE ? FM_PF_SUM : FM_PF_MAX;
+    constexpr int RING = PF + 1;
+    constexpr int RPK = MODE ? 2 : 1;       // LDS reads per k-step
+    half8 bh[RING], bl[MODE ? RING : 1];
+    auto issue = [&](int ks) {
+      const unsigned la = base ^ (unsigned)(ks << 4);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(bh[ks % RING]) : "v"(la));
+      if (MODE) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[ks % RING]) : "v"(la), "i"(PLANE_BYTES));
+    };
+#pragma unroll
+    for (int ks = 0; ks < PF && ks < KSTEPS; ++ks) issue(ks);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int la = lb ^ (ks << 4);
-      const half8 bh = *reinterpret_cast<const half8*>(buf + la);
+      if (ks + PF < KSTEPS) issue(ks + PF);
+      const int ahead = (KSTEPS - 1 - ks) < PF ? (KSTEPS - 1 - ks) : PF;   // k-steps issued beyond ks
+      if (MODE) {
+        if (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[ks % RING]), "+v"(bl[ks % RING]));
+        else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[ks % RING]), "+v"(bl[ks % RING]));
+        else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[ks % RING]), "+v"(bl[ks % RING]));
+        else if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bh[ks % RING]), "+v"(bl[ks % RING]));
+        else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bh[ks % RING]), "+v"(bl[ks % RING]));
+      } else {
+        if (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[ks % RING]));
+        else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bh[ks % RING]));
+        else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[ks % RING]));
+        else if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bh[ks % RING]));
+        else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[ks % RING]));
+        else if (ahead == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(bh[ks % RING]));
+        else if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bh[ks % RING]));
+        else if (ahead == 7) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bh[ks % RING]));
+        else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bh[ks % RING]));
+      }
+      static_assert(PF * RPK <= 8, "lgkmcnt ladder above covers at most 8 reads in flight");
+      const half8 h8 = bh[ks % RING];
       if (ks == 0) {
+        // The accumulator starts at 0, or at -inf for padded rows (>= L) / padded columns (>= S):
+        // such entries then stay -inf through the whole chain, so the epilogue needs no masks
+        // (max ignores them, exp2 gives 0, the candidate test fails).  Only edge waves pay for it.
         f32x16 z;
 #pragma unroll
         for (int g = 0; g < 16; ++g) z[g] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bh, z, 0, 0, 0);
+        const int ucol0 = (u >> 1) * kTileCols + (u & 1) * 32;
+        if (row_edge || ucol0 + 32 > a.S) {
+          const float cb = (ucol0 + r < a.S) ? 0.f : -INFINITY;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) z[g] = (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h < a.L) ? cb : -INFINITY;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], h8, z, 0, 0, 0);
       } else {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], h8, acc, 0, 0, 0);
       }
       if (MODE) {
-        const half8 bl = *reinterpret_cast<const half8*>(buf + PLANE_BYTES + la);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], h8, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl[ks % RING], acc, 0, 0, 0);
       }
     }
   };
@@ -164,16 +224,13 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   // epilogue of unit u: fold the accumulator into the row / column statistics
   auto epilogue = [&](int u) {
     const int col = (u >> 1) * kTileCols + (u & 1) * 32 + r;     // this lane's column
-    const bool col_edge = (col - r + 32 > a.S);                  // wave-uniform
     const bool cvalid = col < a.S;
     float cstat;
     if (MODE == 0) {
       cstat = -INFINITY;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        float x = acc[g];
-        if (col_edge && !cvalid) x = -INFINITY;
-        if (row_edge && (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L)) x = -INFINITY;
+        const float x = acc[g];          // -inf for padded rows / columns (accumulator bias)
         rstat[g] = fmaxf(rstat[g], x);
         cstat = fmaxf(cstat, x);
       }
@@ -191,10 +248,8 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const float x = acc[g];
-        float rr = __builtin_fmaf(x, a.k, nmr[g]);
-        float cc = __builtin_fmaf(x, a.k, nmc);
-        if (col_edge && !cvalid) { rr = -INFINITY; cc = -INFINITY; }
-        if (row_edge && (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L)) { rr = -INFINITY; cc = -INFINITY; }
+        const float rr = __builtin_fmaf(x, a.k, nmr[g]);   // x = -inf for padded rows / columns
+        const float cc = __builtin_fmaf(x, a.k, nmc);
         if (MODE == 1) {
           rstat[g] += __builtin_amdgcn_exp2f(rr);
           cstat += __builtin_amdgcn_exp2f(cc);
@@ -227,12 +282,27 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 
   // Waves w and w+4 share a SIMD.  The second half of the workgroup runs one epilogue behind the
   // first, so that on every SIMD one wave's exp/add epilogue overlaps the other's MFMA chain.
+#ifdef FM_ABL_NOSTAGGER
+  const bool late = false;
+#else
   const bool late = wv >= 4;
+#endif
   for (int u = 2 * t0; u < 2 * t1; ++u) {
+#ifndef FM_ABL_NOSTAGE
     if ((u & 1) == 0 && (u >> 1) + 1 < t1) stage((u >> 1) + 1, (((u >> 1) - t0) & 1) ^ 1);
+#endif
+#ifdef FM_ABL_NOEPI
+    mfma_unit(u);
+    asm volatile("" :: "v"(acc));
+#elif defined(FM_ABL_NOMFMA)
+    if (late && u > 2 * t0) epilogue(u - 1);
+    asm volatile("" : "+v"(acc));
+    if (!late) epilogue(u);
+#else
     if (late && u > 2 * t0) epilogue(u - 1);
     mfma_unit(u);
     if (!late) epilogue(u);
+#endif
     if (u & 1) __syncthreads();   // tile consumed by every wave; next tile landed (LDS-DMA drained)
   }
   if (late && t1 > t0) epilogue(2 * t1 - 1);

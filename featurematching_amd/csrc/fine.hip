@@ -4,13 +4,67 @@
 
 namespace fm {
 
+// Workgroups are dealt round-robin over the 8 XCDs (private L2s).  Give each XCD a contiguous range
+// of windows: matches are sorted by coarse cell, so neighbouring windows share cache lines of the
+// fine map and one XCD then pulls only its part of the map over the fabric (speed only).
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+  const int q = n >> 3, rem = n & 7, x = bid & 7, y = bid >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + y;
+}
+
 // ----------------------------------------------------------------------------------------
-// k_gather_nchw: one workgroup per window.  The reference unfolds EVERY coarse cell's window
-// (60 MB per image at 640x480) and then selects M of them; here only the M selected windows are
-// read, straight from the NCHW map (runs of W floats along x), transposed to [WW][Cf] through
-// LDS (pitch Cf+1: conflict-free both ways) and written as one contiguous 12.5 KB record.
-// Window origin = stride*cell - pad with the reference's literal pad = 2, zero outside the map.
+// k_gather_nchw64<W>: one workgroup per window (Cf = 64, W compile-time).
+// The reference unfolds EVERY coarse cell's window (60 MB per image at 640x480) and then selects M
+// of them; here only the M selected windows are read, straight from the NCHW map.  Lanes run along
+// (channel, window row, x) with x fastest, so one wave-load touches ~64/W short runs in 2-3 channel
+// planes.  (Lane = channel would put the 64 lanes of a load one plane stride apart - 307200 B at
+// 240x320 - which lands on a handful of L2/HBM channels; measured 2x slower.)  The [c][r] -> [r][c]
+// transpose goes through LDS (pitch 65: conflict-free both ways) and the window leaves as one
+// contiguous record.  Window origin = stride*cell - pad with the reference's literal pad = 2, zero
+// outside the map.
 // ----------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_gather_nchw64(const float* __restrict__ feat, int Hf, int Wf, int stride,
+                                                       int pad, int w_c, const int64_t* __restrict__ b_ids,
+                                                       const int64_t* __restrict__ ids,
+                                                       const int32_t* __restrict__ d_count, int m_max,
+                                                       float* __restrict__ out) {
+  constexpr int CF = 64, WW = W * W, TOTAL = CF * WW;
+  __shared__ float tile[WW * (CF + 1)];
+  const int M = d_count ? min(d_count[0], m_max) : m_max;
+  // spread the M live windows (not the m_max launched ones) contiguously over the XCDs
+  const int per = (M + 7) >> 3;
+  const int m = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || m >= M) return;
+  const int b = (int)b_ids[m];
+  const int id = (int)ids[m];
+  const int cy = id / w_c;
+  const int oy = cy * stride - pad;
+  const int ox = (id - cy * w_c) * stride - pad;
+  const float* src = feat + (long)b * CF * Hf * Wf;
+#pragma unroll
+  for (int it = 0; it < (TOTAL + 255) / 256; ++it) {
+    const int idx = it * 256 + threadIdx.x;
+    if (idx < TOTAL) {
+      const int c = idx / WW;
+      const int rem = idx - c * WW;
+      const int wy = rem / W, wx = rem - wy * W;
+      const int y = oy + wy, x = ox + wx;
+      float v = 0.f;
+      if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)c * Hf + y) * Wf + x];
+      tile[rem * (CF + 1) + c] = v;
+    }
+  }
+  __syncthreads();
+  float* dst = out + (long)m * TOTAL;
+#pragma unroll
+  for (int it = 0; it < (TOTAL + 255) / 256; ++it) {
+    const int idx = it * 256 + threadIdx.x;
+    if (idx < TOTAL) dst[idx] = tile[(idx >> 6) * (CF + 1) + (idx & 63)];
+  }
+}
+
+// generic fallback (any Cf / W): one workgroup per window, transposed through LDS
 __global__ __launch_bounds__(256) void k_gather_nchw(const float* __restrict__ feat, int Cf, int Hf, int Wf, int W,
                                                      int stride, int pad, int w_c, const int64_t* __restrict__ b_ids,
                                                      const int64_t* __restrict__ ids, const int32_t* __restrict__ d_count,
@@ -233,7 +287,14 @@ extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int
   if (N <= 0 || Cf <= 0 || Hf <= 0 || Wf <= 0 || W <= 0 || stride <= 0 || w_c <= 0 || m_max < 0) return FM_E_SHAPE;
   if (W > 15 || Cf > 512 || (layout == 1 && Cf % 4) || (layout != 0 && layout != 1)) return FM_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (layout == 0) {
+  if (layout == 0 && Cf == 64 && (W == 5 || W == 7)) {
+    if (W == 5)
+      hipLaunchKernelGGL(k_gather_nchw64<5>, dim3((m_max + 7) / 8 * 8), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
+                         ids, d_count, m_max, out);
+    else
+      hipLaunchKernelGGL(k_gather_nchw64<7>, dim3((m_max + 7) / 8 * 8), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
+                         ids, d_count, m_max, out);
+  } else if (layout == 0) {
     const size_t smem = (size_t)W * W * (Cf + 1) * sizeof(float);
     if (smem > 64 * 1024) return FM_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_gather_nchw, dim3(m_max), dim3(256), smem, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c,

@@ -70,6 +70,10 @@ def main():
     rows.append(("gather windows (both images)", timed(lambda: (
         ops.gather_windows(p.ff0, buf.b_ids, buf.i_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win0),
         ops.gather_windows(p.ff1, buf.b_ids, buf.j_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win1)), a.iters)))
+    rows.append(("  gather image 0 (sorted cells)", timed(lambda: ops.gather_windows(
+        p.ff0, buf.b_ids, buf.i_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win0), a.iters)))
+    rows.append(("  gather image 1 (permuted cells)", timed(lambda: ops.gather_windows(
+        p.ff1, buf.b_ids, buf.j_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win1), a.iters)))
     rows.append(("fine match", timed(lambda: ops.fine_match(p.win0, p.win1, p.mix0, p.mix1, buf.mkpts0_c, buf.mkpts1_c,
                                                               2.0, count=buf.count), a.iters)))
     rows.append(("whole step (eager)", timed(lambda: p.step(), a.iters)))
