@@ -1,0 +1,63 @@
+"""Pair-parallel sharding across the GPUs of a node and the gather of match lists.
+
+Every pair is independent in all three stages, so ranks take contiguous blocks of
+pairs and nothing is exchanged on the data path.  The only collective is the gather of the
+resulting match lists: one all-gather of the per-rank counts and one all-gather of records padded
+to the largest count - the pad-to-largest scheme of the reference's utils/comm.py:113-176, but
+with raw float32 records over RCCL (backend "nccl" on ROCm) instead of pickles over gloo.
+
+Record = [pair_id, x0, y0, x1, y1, conf] float32 (pair ids are exact in float32 up to 2**24).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+RECORD = 6
+
+
+def shard_range(num_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of pairs owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(num_pairs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_records(b_ids: torch.Tensor, kpts0: torch.Tensor, kpts1: torch.Tensor, conf: torch.Tensor,
+                 pair_offset: int = 0) -> torch.Tensor:
+    """[M, 6] float32 records; local batch ids become global pair ids."""
+    m = b_ids.shape[0]
+    rec = torch.empty(m, RECORD, dtype=torch.float32, device=conf.device)
+    rec[:, 0] = (b_ids + pair_offset).to(torch.float32)
+    rec[:, 1:3] = kpts0[:, :2]
+    rec[:, 3:5] = kpts1[:, :2]
+    rec[:, 5] = conf
+    return rec
+
+
+def gather_match_lists(records: torch.Tensor, group=None) -> torch.Tensor:
+    """All ranks receive the concatenation (rank-major, each rank's order preserved) of every
+    rank's records - identical to a single process run on the concatenated batch."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return records
+    world = dist.get_world_size(group)
+    if world == 1:
+        return records
+    dev = records.device
+    count = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(counts)
+    padded = torch.zeros(cap, RECORD, dtype=torch.float32, device=dev)
+    padded[:records.shape[0]] = records
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def unpack_records(rec: torch.Tensor):
+    """-> (pair_ids int64 [M], kpts0 [M,2], kpts1 [M,2], conf [M])"""
+    return rec[:, 0].round().to(torch.int64), rec[:, 1:3], rec[:, 3:5], rec[:, 5]

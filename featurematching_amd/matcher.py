@@ -1,0 +1,102 @@
+"""`match(img0, img1) -> (kpts0, kpts1, conf)`: the facade the reference exposes as
+`net.forward(data)` + `data['mkpts0_f'][:, :2], data['mkpts1_f'][:, :2], data['mconf']`
+(network/net.py:40-92, demo/demo.py:108-113).
+
+The feature extractor is NOT part of the accelerated path ("CNN/FPN backbone runs
+on PyTorch-ROCm"); `SmallFPN` is a plain torch stand-in with the reference's resolutions (coarse
+1/8 with d_model 256, fine 1/2 with d_model 64) so that the pipeline runs end to end with
+seeded-random weights.  No checkpoint of the reference exists, so there is no parity claim for it.
+The context transformers (network/module/transformer.py) are the first "next" row and are skipped.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .modules import CoarseMatching, FineMatching, FinePreprocess
+
+DEFAULT_CONFIG = {
+    'fine_window_size': 7, 'fine_concat_coarse_feat': True, 'resolution': (8, 2),
+    'coarse': {'d_model': 256}, 'fine': {'d_model': 64},
+    'match_coarse': {'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1,
+                     'train_coarse_percent': 1.0, 'train_pad_num_gt_min': 200},
+}
+
+
+def _block(cin, cout, stride):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                         nn.Conv2d(cout, cout, 3, 1, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class SmallFPN(nn.Module):
+    """1/2 -> 1/4 -> 1/8 encoder with a top-down path back to 1/2 (ResNetFPN_8_2 shaped)."""
+
+    def __init__(self, in_ch=3, d_coarse=256, d_fine=64):
+        super().__init__()
+        self.l1 = _block(in_ch, 64, 2)
+        self.l2 = _block(64, 128, 2)
+        self.l3 = _block(128, d_coarse, 2)
+        self.up2 = nn.Conv2d(d_coarse, 128, 1)
+        self.up1 = nn.Conv2d(128, 64, 1)
+        self.out_f = nn.Conv2d(64, d_fine, 3, 1, 1)
+
+    def forward(self, x):
+        x1 = self.l1(x)
+        x2 = self.l2(x1)
+        x3 = self.l3(x2)
+        y2 = x2 + F.interpolate(self.up2(x3), scale_factor=2.0, mode='bilinear', align_corners=True)
+        y1 = x1 + F.interpolate(self.up1(y2), scale_factor=2.0, mode='bilinear', align_corners=True)
+        return x3, self.out_f(y1)
+
+
+class Matcher(nn.Module):
+    """backbone -> CoarseMatching -> FinePreprocess -> FineMatching with the reference's `data`
+    dict protocol (same keys as network/net.py:51-62,89-92)."""
+
+    def __init__(self, config=None, backbone: nn.Module = None):
+        super().__init__()
+        cfg = dict(DEFAULT_CONFIG)
+        cfg.update(config or {})
+        self.config = cfg
+        self.backbone = backbone or SmallFPN(3, cfg['coarse']['d_model'], cfg['fine']['d_model'])
+        self.coarse_matching = CoarseMatching(cfg['match_coarse'])
+        self.fine_preprocess = FinePreprocess(cfg)
+        self.fine_matching = FineMatching(cfg['fine'], window=cfg['fine_window_size'])
+
+    @torch.no_grad()
+    def forward(self, data):
+        data.update({'bs': data['image0'].size(0),
+                     'hw0_i': data['image0'].shape[2:], 'hw1_i': data['image1'].shape[2:]})
+        feats_c, feats_f = self.backbone(torch.cat([data['image0'], data['image1']], dim=0))
+        (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(data['bs']), feats_f.split(data['bs'])
+        data.update({'hw0_c': feat_c0.shape[2:], 'hw1_c': feat_c1.shape[2:],
+                     'hw0_f': feat_f0.shape[2:], 'hw1_f': feat_f1.shape[2:]})
+        feat_c0 = feat_c0.flatten(2).transpose(1, 2).contiguous()       # n c h w -> n (h w) c
+        feat_c1 = feat_c1.flatten(2).transpose(1, 2).contiguous()
+        self.coarse_matching(feat_c0, feat_c1, data)
+        win0, win1 = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
+        self.fine_matching(win0, win1, data)
+        data.update({'feat_c0': feat_c0, 'feat_c1': feat_c1, 'feat_f0': feat_f0, 'feat_f1': feat_f1})
+        return data
+
+    def match(self, img0: torch.Tensor, img1: torch.Tensor):
+        """img0, img1: [N,C,H,W] (or [C,H,W]) float tensors on the GPU, H and W multiples of 8.
+        Returns kpts0 [M,2], kpts1 [M,2] (pixels, x then y), conf [M]; batch ids are in
+        `self.last['m_bids']`."""
+        if img0.dim() == 3:
+            img0, img1 = img0[None], img1[None]
+        data = self.forward({'image0': img0, 'image1': img1})
+        self.last = data
+        return data['mkpts0_f'][:, :2], data['mkpts1_f'][:, :2], data['mconf']
+
+
+def match(img0, img1, matcher: Matcher = None):
+    """Functional form with a lazily built default matcher (seeded-random weights)."""
+    global _DEFAULT
+    if matcher is None:
+        if '_DEFAULT' not in globals():
+            torch.manual_seed(0)
+            _DEFAULT = Matcher().to(img0.device).eval()
+        matcher = _DEFAULT
+    return matcher.match(img0, img1)

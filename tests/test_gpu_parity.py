@@ -258,3 +258,25 @@ def test_properties_at_cfg2_size():
     fwd = set(zip(s0['i_ids'].tolist(), s0['j_ids'].tolist()))
     bwd = set(zip(t['j_ids'].tolist(), t['i_ids'].tolist()))
     assert len(fwd ^ bwd) <= 2                            # conf differs in the last bits only
+
+
+# ------------------------------------------------------------------ match(img0, img1) facade
+def test_matcher_end_to_end_on_warped_images():
+    """Seeded-random backbone, image1 = image0 shifted by (16, 8) px: the matcher must run end to
+    end, honour the API surface and recover the shift for the bulk of its matches."""
+    from featurematching_amd.matcher import Matcher
+    torch.manual_seed(3)
+    m = Matcher().to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(1, 3, 60, 80, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(480 + 32, 640 + 32), mode='bicubic', align_corners=False) * 255
+    img0 = img[:, :, 0:480, 0:640].contiguous().to(DEV)
+    img1 = img[:, :, 8:488, 16:656].contiguous().to(DEV)
+    k0, k1, conf = m.match(img0, img1)
+    assert k0.shape == k1.shape and k0.shape[1] == 2 and conf.shape[0] == k0.shape[0]
+    assert k0.shape[0] > 100
+    d = (k0 - k1).cpu().numpy()
+    good = (np.abs(d[:, 0] - 16) < 4) & (np.abs(d[:, 1] - 8) < 4)
+    assert good.mean() > 0.8
+    for key in ('mkpts0_f', 'mkpts1_f', 'mconf', 'm_bids', 'feat_c0', 'feat_f1', 'hw0_c', 'W'):
+        assert key in m.last
