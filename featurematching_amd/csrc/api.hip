@@ -41,7 +41,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
   w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
-  w.bmax0 = take(rows / prep_rows(C) * 4); w.bmax1 = take(cols / prep_rows(C) * 4);
+  w.bmax0 = take(rows / 32 * 4); w.bmax1 = take(cols / prep_rows(C) * 4);
   w.rowA = take(rows * w.splits * 4); w.colA = take(cols * w.panels * 8 * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * 8 * 4);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
@@ -128,14 +128,8 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   hipStream_t st = (hipStream_t)stream;
   const float inv_ct = 1.0f / ((float)C * temperature);
 
-  hipError_t e = hipMemsetAsync(base + w.zero_begin, 0, w.zero_end - w.zero_begin, st);
-  if (e != hipSuccess) return (int)e;
-  unsigned* flags = (unsigned*)(base + w.scalars);
-  e = launch_prep(feat0, N, L, w.Lp, C, w.C, (_Float16*)(base + w.hi0), (_Float16*)(base + w.lo0),
-                  (float*)(base + w.norm0), (float*)(base + w.bmax0), flags, st);
-  if (e != hipSuccess) return (int)e;
-  e = launch_prep(feat1, N, S, w.Sp, C, w.C, (_Float16*)(base + w.hi1), (_Float16*)(base + w.lo1),
-                  (float*)(base + w.norm1), (float*)(base + w.bmax1), flags, st);
+  // one dispatch: clear the per-call counters, split both images into float16 planes
+  hipError_t e = launch_prep(feat0, feat1, C, w, base, st);
   if (e != hipSuccess) return (int)e;
   e = launch_corr(0, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;

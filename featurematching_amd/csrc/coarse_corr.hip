@@ -121,15 +121,17 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #endif
 
   // ---- this wave's 32 rows as A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7) ----
+  // (lane = h*32 + r is exactly the lane order of the fragment-major block)
   const int wrow0 = panel * kPanelRows + wv * 32;
   half8 ahi[KSTEPS], alo[MODE ? KSTEPS : 1];
   {
-    const long off = ((long)b * a.Lp + wrow0 + r) * C + h * (C / 2);
+    // fragment-major planes (k_prep_split): one contiguous 1 KiB block per (32-row block, k-step)
+    const long off = (((long)b * a.Lp + wrow0) / 32 * KSTEPS * 64 + lane) * 8;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) ahi[ks] = *reinterpret_cast<const half8*>(a.hi0 + off + ks * 8);
+    for (int ks = 0; ks < KSTEPS; ++ks) ahi[ks] = *reinterpret_cast<const half8*>(a.hi0 + off + ks * 512);
     if (MODE) {
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) alo[ks] = *reinterpret_cast<const half8*>(a.lo0 + off + ks * 8);
+      for (int ks = 0; ks < KSTEPS; ++ks) alo[ks] = *reinterpret_cast<const half8*>(a.lo0 + off + ks * 512);
     }
   }
 

@@ -15,62 +15,144 @@ namespace fm {
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-// C = padded channel count of the planes (64/128/256); c_in <= C = channels of the source rows,
-// the planes are zero beyond c_in (a dot product does not change under zero padding).
-template <int C>
-__global__ __launch_bounds__(256) void k_prep_split(const float* __restrict__ src, int rows, int rows_pad, int c_in,
-                                                    _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                    float* __restrict__ norms, float* __restrict__ blockmax,
-                                                    unsigned* __restrict__ flags) {
-  constexpr int LPR = C / 4;        // lanes per row (one float4 each)
-  constexpr int RPP = 256 / LPR;    // rows per pass of the workgroup
-  constexpr int kPrepRows = C >= 128 ? 8 : 16;   // == prep_rows(C)
-  const int tid = threadIdx.x;
-  const int sub = tid / LPR;
-  const int lir = tid % LPR;
-  const long row0 = (long)blockIdx.x * kPrepRows;
-  float bmax = 0.f;
-  bool bad = false;
-#pragma unroll
-  for (int p = 0; p < kPrepRows / RPP; ++p) {
-    const long prow = row0 + p * RPP + sub;
-    const int b = (int)(prow / rows_pad);
-    const int local = (int)(prow - (long)b * rows_pad);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (local < rows && lir * 4 < c_in)
-      v = *reinterpret_cast<const float4*>(src + ((long)b * rows + local) * c_in + lir * 4);
-    // NaN fails the comparison too
-    bad = bad || !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 32768.f) ||
-          v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
-    half4 h, l;
-    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-    l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-    l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-    *reinterpret_cast<half4*>(hi + prow * C + lir * 4) = h;
-    *reinterpret_cast<half4*>(lo + prow * C + lir * 4) = l;
-    float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-#pragma unroll
-    for (int m = LPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-    const float nrm = sqrtf(ss);
-    if (lir == 0) norms[prow] = nrm;
-    bmax = fmaxf(bmax, nrm);
-  }
-  __shared__ float sm[4];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, m));
-  if ((tid & 63) == 0) sm[tid >> 6] = bmax;
-  __syncthreads();
-  if (tid == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-  if (__any(bad) && (tid & 63) == 0) atomicOr(flags, (unsigned)FM_DEV_RANGE);
+struct PrepArgs {
+  const float* src0; const float* src1;
+  _Float16* hi0; _Float16* lo0; _Float16* hi1; _Float16* lo1;
+  float* norm0; float* norm1; float* bmax0; float* bmax1;
+  uint4* zero; int zero_vec;          // per-call counters to clear (uint4 units)
+  int L, S, Lp, Sp, c_in, blocks0;    // blocks0 = workgroups that convert image 0
+};
+
+__device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the comparison too
+  return !(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) < 32768.f) ||
+         v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
 }
 
-hipError_t launch_prep(const float* feat, int N, int rows, int rows_pad, int c_in, int C, _Float16* hi, _Float16* lo,
-                       float* norms, float* blockmax, unsigned* flags, hipStream_t st) {
-  const int blocks = (int)((long)N * rows_pad / prep_rows(C));
-  switch (C) {
-    case 64: hipLaunchKernelGGL(k_prep_split<64>, dim3(blocks), dim3(256), 0, st, feat, rows, rows_pad, c_in, hi, lo, norms, blockmax, flags); break;
-    case 128: hipLaunchKernelGGL(k_prep_split<128>, dim3(blocks), dim3(256), 0, st, feat, rows, rows_pad, c_in, hi, lo, norms, blockmax, flags); break;
-    case 256: hipLaunchKernelGGL(k_prep_split<256>, dim3(blocks), dim3(256), 0, st, feat, rows, rows_pad, c_in, hi, lo, norms, blockmax, flags); break;
+// One dispatch prepares both images and clears the per-call counters.
+// C = padded channel count of the planes (64/128/256); c_in <= C = channels of the source rows,
+// the planes are zero beyond c_in (a dot product does not change under zero padding).
+//   image 1 (streamed through LDS by the sweeps): planes row-major [N*Sp][C], 8/16 rows per workgroup.
+//   image 0 (register-resident A operand of the sweeps): planes FRAGMENT-major, one workgroup per
+//     32-row block: element (row, k) lives at (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8
+//     with chunk q = k/8 = h*KSTEPS + ks, so the 64 lanes (h, row%32) of a wave read one contiguous
+//     1 KiB block per k-step instead of 64 separate 16-byte pieces 512 B apart.
+// A workgroup that sees a non-finite / out-of-range value reports +inf as its block norm; k_reduce<0>
+// turns that into FM_DEV_RANGE (the flag word itself is cleared by this kernel, so it cannot be set here).
+template <int C>
+__global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
+  constexpr int KSTEPS = C / 16;
+  const int tid = threadIdx.x;
+  // ---- clear this workgroup's slice of the per-call counters ----
+  {
+    const int per = (a.zero_vec + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo_ = blockIdx.x * per, hi_ = min(lo_ + per, a.zero_vec);
+    for (int k = lo_ + tid; k < hi_; k += 256) a.zero[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __shared__ float sm[8][33];
+  float bmax = 0.f;
+  bool bad = false;
+  if ((int)blockIdx.x < a.blocks0) {
+    // ---------------- image 0: one 32-row block, fragment-major ----------------
+    const long rb = blockIdx.x;                       // global row block over N*Lp/32
+    const int b = (int)(rb * 32 / a.Lp);
+    const int r = tid & 31;
+    const int local = (int)(rb * 32 - (long)b * a.Lp) + r;
+    const float* row = a.src0 + ((long)b * a.L + local) * a.c_in;
+    float ss = 0.f;
+#pragma unroll
+    for (int n = 0; n < C / 8 / 8; ++n) {             // C/8 chunks of 8 channels, 8 per pass
+      const int q = n * 8 + (tid >> 5);
+      const int h = q / KSTEPS, ks = q - h * KSTEPS;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (local < a.L) {
+        if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
+        if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
+      }
+      bad = bad || bad_value(v0) || bad_value(v1);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+      half8 hh, ll;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        hh[e] = (_Float16)x[e];
+        ll[e] = (_Float16)(x[e] - (float)hh[e]);
+        ss += x[e] * x[e];
+      }
+      const long off = (((rb * KSTEPS + ks) * 2 + h) * 32 + r) * 8;
+      *reinterpret_cast<half8*>(a.hi0 + off) = hh;
+      *reinterpret_cast<half8*>(a.lo0 + off) = ll;
+    }
+    sm[tid >> 5][r] = ss;
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += sm[g][tid];
+      const float nrm = sqrtf(t);
+      a.norm0[rb * 32 + tid] = nrm;
+      bmax = nrm;
+    }
+  } else {
+    // ---------------- image 1: 8 or 16 rows, row-major ----------------
+    constexpr int LPR = C / 4;        // lanes per row (one float4 each)
+    constexpr int RPP = 256 / LPR;    // rows per pass of the workgroup
+    constexpr int kPrepRows = C >= 128 ? 8 : 16;   // == prep_rows(C)
+    const int sub = tid / LPR;
+    const int lir = tid % LPR;
+    const long row0 = (long)((int)blockIdx.x - a.blocks0) * kPrepRows;
+#pragma unroll
+    for (int p = 0; p < kPrepRows / RPP; ++p) {
+      const long prow = row0 + p * RPP + sub;
+      const int b = (int)(prow / a.Sp);
+      const int local = (int)(prow - (long)b * a.Sp);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (local < a.S && lir * 4 < a.c_in)
+        v = *reinterpret_cast<const float4*>(a.src1 + ((long)b * a.S + local) * a.c_in + lir * 4);
+      bad = bad || bad_value(v);
+      half4 h, l;
+      h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+      l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+      l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+      *reinterpret_cast<half4*>(a.hi1 + prow * C + lir * 4) = h;
+      *reinterpret_cast<half4*>(a.lo1 + prow * C + lir * 4) = l;
+      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+      for (int m = LPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+      const float nrm = sqrtf(ss);
+      if (lir == 0) a.norm1[prow] = nrm;
+      bmax = fmaxf(bmax, nrm);
+    }
+    __syncthreads();     // keep the barrier count equal on both paths (sm is reused below)
+  }
+  if (__any(bad)) bmax = INFINITY;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, m));
+  __shared__ float wmax[4];
+  if ((tid & 63) == 0) wmax[tid >> 6] = bmax;
+  __syncthreads();
+  if (tid == 0) {
+    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if ((int)blockIdx.x < a.blocks0) a.bmax0[blockIdx.x] = m;
+    else a.bmax1[(int)blockIdx.x - a.blocks0] = m;
+  }
+}
+
+hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
+                       hipStream_t st) {
+  PrepArgs a;
+  a.src0 = feat0; a.src1 = feat1;
+  a.hi0 = (_Float16*)(base + w.hi0); a.lo0 = (_Float16*)(base + w.lo0);
+  a.hi1 = (_Float16*)(base + w.hi1); a.lo1 = (_Float16*)(base + w.lo1);
+  a.norm0 = (float*)(base + w.norm0); a.norm1 = (float*)(base + w.norm1);
+  a.bmax0 = (float*)(base + w.bmax0); a.bmax1 = (float*)(base + w.bmax1);
+  a.zero = (uint4*)(base + w.zero_begin); a.zero_vec = (int)((w.zero_end - w.zero_begin) / 16);
+  a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.c_in = c_in;
+  a.blocks0 = (int)((long)w.N * w.Lp / 32);
+  const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / prep_rows(w.C));
+  switch (w.C) {
+    case 64: hipLaunchKernelGGL(k_prep_split<64>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 128: hipLaunchKernelGGL(k_prep_split<128>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 256: hipLaunchKernelGGL(k_prep_split<256>, dim3(blocks), dim3(256), 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -92,10 +174,10 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
                                                 const float* __restrict__ norm0, const float* __restrict__ norm1,
                                                 const float* __restrict__ bmax0, const float* __restrict__ bmax1,
                                                 float* __restrict__ rout, float* __restrict__ cout_, int Lp, int Sp,
-                                                int rparts, int cparts, float inv_ct, float sqrt_c, int prows,
+                                                int rparts, int cparts, float inv_ct, float sqrt_c, int prows0, int prows1,
                                                 const float* __restrict__ nm_r, const float* __restrict__ nm_c,
                                                 float* __restrict__ nm2_r, float* __restrict__ nm2_c,
-                                                int* __restrict__ cand_count, const unsigned* __restrict__ flags) {
+                                                int* __restrict__ cand_count, unsigned* __restrict__ flags) {
   const int side = blockIdx.z;
   const int b = blockIdx.y;
   const int len = side ? Sp : Lp;
@@ -119,6 +201,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
   float om = 0.f;
   if (MODE == 0) {   // largest descriptor norm of the OTHER image (for the screening margin)
     const int other_len = side ? Lp : Sp;
+    const int prows = side ? prows0 : prows1;      // granularity of the OTHER image's block norms
     const float* obm = (side ? bmax0 : bmax1) + (long)b * (other_len / prows);
     for (int k = threadIdx.x; k < other_len / prows; k += 256) om = fmaxf(om, obm[k]);
 #pragma unroll
@@ -140,6 +223,8 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
     return;
   }
   om = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  // a prep workgroup that met NaN/Inf/|x| >= 32768 reported +inf (either image is seen by one side)
+  if (!(om < INFINITY) && blockIdx.x == 0 && cx == 0) atomicOr(flags, (unsigned)FM_DEV_RANGE);
   float raw = v;
   if (!(raw > -INFINITY)) raw = 0.f;   // padded row/column: never used
   const float nrm = ((side ? norm1 : norm0) + (long)b * len)[idx];
@@ -156,14 +241,14 @@ hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, 
   if (mode == 0)
     hipLaunchKernelGGL(k_reduce<0>, grid, dim3(256), 0, st, (const float*)(base + w.rowA),
                        (const float*)(base + w.colA), n0, n1, b0, b1, (float*)(base + w.nmr), (float*)(base + w.nmc),
-                       w.Lp, w.Sp, w.splits, w.panels * 8, inv_ct, sqrtf((float)w.C), prep_rows(w.C), nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr);
+                       w.Lp, w.Sp, w.splits, w.panels * 8, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C), nullptr, nullptr,
+                       nullptr, nullptr, nullptr, (unsigned*)(base + w.scalars));
   else
     hipLaunchKernelGGL(k_reduce<1>, grid, dim3(256), 0, st, (const float*)(base + w.rowB),
                        (const float*)(base + w.colB), n0, n1, b0, b1, (float*)(base + w.rsum), (float*)(base + w.csum),
-                       w.Lp, w.Sp, w.splits, w.panels * 8, inv_ct, sqrtf((float)w.C), prep_rows(w.C),
+                       w.Lp, w.Sp, w.splits, w.panels * 8, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C),
                        (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
-                       (float*)(base + w.nmc2), (int*)(base + w.cand_count), (const unsigned*)(base + w.scalars));
+                       (float*)(base + w.nmc2), (int*)(base + w.cand_count), (unsigned*)(base + w.scalars));
   return hipGetLastError();
 }
 

@@ -51,8 +51,7 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 };
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
-hipError_t launch_prep(const float* feat, int N, int rows, int rows_pad, int c_in, int C,
-                       _Float16* hi, _Float16* lo, float* norms, float* blockmax, unsigned* flags,
+hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
                        hipStream_t st);
 hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st);
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);

@@ -58,8 +58,15 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
 
     inv_ct = 1.0 / (c * temp)
     # planes
-    hi0 = view(ws, base, lay["hi0"], n * Lp * c, torch.float16).reshape(n, Lp, c)
-    lo0 = view(ws, base, lay["lo0"], n * Lp * c, torch.float16).reshape(n, Lp, c)
+    cp = lay["C"]                       # padded channel count of the planes
+
+    def unfrag(a):                      # image-0 planes are fragment-major: [rowblock][ks][h][r][8]
+        ksteps = cp // 16
+        a = a.reshape(n * Lp // 32, ksteps, 2, 32, 8).transpose(0, 3, 2, 1, 4)      # rb, r, h, ks, e
+        return a.reshape(n, Lp, cp)[:, :, :c]
+
+    hi0 = unfrag(view(ws, base, lay["hi0"], n * Lp * cp, torch.float16))
+    lo0 = unfrag(view(ws, base, lay["lo0"], n * Lp * cp, torch.float16))
     hi1 = view(ws, base, lay["hi1"], n * Sp * c, torch.float16).reshape(n, Sp, c)
     lo1 = view(ws, base, lay["lo1"], n * Sp * c, torch.float16).reshape(n, Sp, c)
     e_hi = np.abs(hi0[:, :l].astype(np.float32) - f0.astype(np.float16).astype(np.float32)).max()
