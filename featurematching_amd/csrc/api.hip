@@ -42,8 +42,8 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
   w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
   w.bmax0 = take(rows / 32 * 4); w.bmax1 = take(cols / prep_rows(C) * 4);
-  w.rowA = take(rows * w.splits * 4); w.colA = take(cols * w.panels * 8 * 4);
-  w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * 8 * 4);
+  w.rowA = take(rows * w.splits * 4); w.colA = take(cols * w.panels * kColParts * 4);
+  w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * kColParts * 4);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
   w.rsum = take(rows * 4); w.csum = take(cols * 4);
   w.nmr2 = take(rows * 4); w.nmc2 = take(cols * 4);
@@ -121,7 +121,6 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
-  if (conf_matrix) return FM_E_UNSUPPORTED;   // dense conf_matrix (training surface) not built yet
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return FM_E_WORKSPACE;
   char* base = (char*)workspace;
@@ -141,6 +140,10 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   if (e != hipSuccess) return (int)e;
   e = launch_corr(2, w, base, inv_ct, thr, st);   // exits immediately unless pass B's screening overflowed
   if (e != hipSuccess) return (int)e;
+  if (conf_matrix) {                              // dense data['conf_matrix'] on request (a fourth sweep)
+    e = launch_corr(3, w, base, inv_ct, thr, st, conf_matrix);
+    if (e != hipSuccess) return (int)e;
+  }
   e = launch_select(w, base, feat0, feat1, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
                     b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, st);
   return (int)e;

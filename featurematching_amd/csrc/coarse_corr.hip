@@ -15,6 +15,8 @@
 //                    with the now-known softmax denominators, log2 P_row > log2 thr and
 //                    log2 P_col > log2 thr, which at most 1/thr entries of a row can pass.
 //                    The kernel is always enqueued and exits at once when it is not needed.
+//   pass D (MODE 3): on request only: the dense conf_matrix [N,L,S] (coarse_matching_new.py:70), written
+//                    from the same product and the log-softmax offsets; the training loss consumes it.
 //
 // Structure (one workgroup = 8 waves = 256 rows of image 0; cf. SURVEY.md 7, hard part 2):
 //   * each wave keeps its 32 rows x C of image-0 descriptors as MFMA A-fragments in
@@ -47,6 +49,7 @@ struct CorrArgs {
   const float* nmr; const float* nmc;
   float* rowpart; float* colpart;
   int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
+  float* conf;   // MODE 3: dense [N,L,S] output
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, slots;
   float k;    // log2(e) / (C*T): raw dot product -> log2-domain similarity
   float lt;   // log2(thr)
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 
   const int lanebase0 = r * ROWB + (((h * (CHUNKS / 2)) ^ swz<C>(r)) << 4);              // columns 0..31 of a tile
   const int lanebase1 = (32 + r) * ROWB + (((h * (CHUNKS / 2)) ^ swz<C>(32 + r)) << 4);  // columns 32..63
-  float* colout = a.colpart + (((long)b * a.panels + panel) * 8 + wv) * a.Sp;
+  float* colout = a.colpart + (((long)b * a.panels + panel) * kColParts + wv) * a.Sp;
 
   f32x16 acc;
 #if defined(FM_ABL_NOMFMA)
@@ -174,6 +177,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       asm volatile("ds_read_b128 %0, %1" : "=v"(bh[ks % RING]) : "v"(la));
       if (MODE) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[ks % RING]) : "v"(la), "i"(PLANE_BYTES));
     };
+#ifdef FM_SETPRIO
+    __builtin_amdgcn_s_setprio(FM_SETPRIO);   // MFMA phase wins issue arbitration over the SIMD partner's epilogue
+#endif
 #pragma unroll
     for (int ks = 0; ks < PF && ks < KSTEPS; ++ks) issue(ks);
 #pragma unroll
@@ -221,6 +227,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl[ks % RING], acc, 0, 0, 0);
       }
     }
+#ifdef FM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // epilogue of unit u: fold the accumulator into the row / column statistics
@@ -237,6 +246,24 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         cstat = fmaxf(cstat, x);
       }
       cstat = fmaxf(cstat, __shfl_xor(cstat, 32));
+    } else if (MODE == 3) {
+      // dense conf_matrix (coarse_matching_new.py:68,70): softmax(sim,1) * softmax(sim,2) from the
+      // log-softmax offsets nmr2 = nmr - log2(row sum), nmc2 = nmc - log2(column sum)
+      cstat = 0.f;
+      const float nmc = a.nmc[(long)b * a.Sp + col];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(nmr_lds + 8 * q + 4 * h);
+        const float nm[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = wrow0 + 8 * q + 4 * h + e;
+          const float x = acc[4 * q + e];
+          const float cf = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, nm[e])) *
+                           __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, nmc));
+          if (row < a.L && cvalid) a.conf[((long)b * a.L + row) * a.S + col] = cf;
+        }
+      }
     } else {
       const float nmc = a.nmc[(long)b * a.Sp + col];
       float best = -INFINITY;
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         }
       }
     }
-    if (MODE != 2 && h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
+    if (MODE <= 1 && h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
   };
 
   __syncthreads();
@@ -309,7 +336,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   }
   if (late && t1 > t0) epilogue(2 * t1 - 1);
 
-  if (MODE == 2) return;
+  if (MODE >= 2) return;
   // ---- row statistics of this workgroup's column range: reduce over the 32 lanes of each half ----
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -339,12 +366,13 @@ static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st) {
+hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st, float* conf) {
   CorrArgs a;
   a.hi0 = (const _Float16*)(base + w.hi0); a.lo0 = (const _Float16*)(base + w.lo0);
   a.hi1 = (const _Float16*)(base + w.hi1); a.lo1 = (const _Float16*)(base + w.lo1);
-  a.nmr = (const float*)(base + (mode == 2 ? w.nmr2 : w.nmr));
-  a.nmc = (const float*)(base + (mode == 2 ? w.nmc2 : w.nmc));
+  a.nmr = (const float*)(base + (mode >= 2 ? w.nmr2 : w.nmr));
+  a.nmc = (const float*)(base + (mode >= 2 ? w.nmc2 : w.nmc));
+  a.conf = conf;
   a.rowpart = (float*)(base + (mode ? w.rowB : w.rowA));
   a.colpart = (float*)(base + (mode ? w.colB : w.colA));
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
@@ -356,7 +384,8 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.lt = log2f(thr) - (mode == 2 ? 2e-4f : 0.f);   // pass C compares rounded log-softmax values: small guard
   const int blocks = w.N * w.splits * w.panels;
 #define FM_CORR_CASE(CC)                                                     \
-  case CC: return mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)            \
+  case CC: return mode == 3 ? launch_corr_t<CC, 3>(a, blocks, st)            \
+                 : mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)          \
                  : (mode ? launch_corr_t<CC, 1>(a, blocks, st) : launch_corr_t<CC, 0>(a, blocks, st));
   switch (w.C) {
     FM_CORR_CASE(64)

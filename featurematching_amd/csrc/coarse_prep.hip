@@ -241,12 +241,12 @@ hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, 
   if (mode == 0)
     hipLaunchKernelGGL(k_reduce<0>, grid, dim3(256), 0, st, (const float*)(base + w.rowA),
                        (const float*)(base + w.colA), n0, n1, b0, b1, (float*)(base + w.nmr), (float*)(base + w.nmc),
-                       w.Lp, w.Sp, w.splits, w.panels * 8, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C), nullptr, nullptr,
+                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C), nullptr, nullptr,
                        nullptr, nullptr, nullptr, (unsigned*)(base + w.scalars));
   else
     hipLaunchKernelGGL(k_reduce<1>, grid, dim3(256), 0, st, (const float*)(base + w.rowB),
                        (const float*)(base + w.colB), n0, n1, b0, b1, (float*)(base + w.rsum), (float*)(base + w.csum),
-                       w.Lp, w.Sp, w.splits, w.panels * 8, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C),
+                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C),
                        (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
                        (float*)(base + w.nmc2), (int*)(base + w.cand_count), (unsigned*)(base + w.scalars));
   return hipGetLastError();

@@ -9,6 +9,12 @@
 namespace fm {
 
 constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup owns
+// column partials each panel writes (one per wave): 8 waves x 32 rows, or 4 waves x 64 rows in the v2 sweep
+#ifdef FM_CORR_V2
+constexpr int kColParts = 4;
+#else
+constexpr int kColParts = 8;
+#endif
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
 // rows one prep workgroup converts (C = padded channel count)
 inline int prep_rows(int C) { return C >= 128 ? 8 : 16; }
@@ -53,7 +59,8 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
 hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
                        hipStream_t st);
-hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st);
+hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st,
+                       float* conf = nullptr);
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);
 hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, const float* feat1,
                          int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,

@@ -49,6 +49,7 @@ class SmallFPN(nn.Module):
         y1 = x1 + F.interpolate(self.up1(y2), scale_factor=2.0, mode='bilinear', align_corners=True)
         # zero-mean / unit-variance descriptors per cell (what the LayerNorm of the reference's coarse
         # transformer provides); post-ReLU features are otherwise all-positive and nearly collinear
+        x3 = x3 - x3.mean(dim=(2, 3), keepdim=True)      # drop the component common to every cell
         x3 = F.layer_norm(x3.permute(0, 2, 3, 1), (x3.shape[1],)).permute(0, 3, 1, 2).contiguous()
         return x3, self.out_f(y1)
 

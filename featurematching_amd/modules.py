@@ -25,7 +25,11 @@ logger = logging.getLogger("featurematching_amd")
 
 
 class CoarseMatching(nn.Module):
-    def __init__(self, config):
+    """`conf_matrix=True` also materialises the dense data['conf_matrix'] [N,L,S] the reference
+    always writes (coarse_matching_new.py:70; only its training loss reads it) - one more sweep and
+    N*L*S*4 bytes, so it is opt-in; it is required in training mode."""
+
+    def __init__(self, config, conf_matrix: bool = False):
         super().__init__()
         self.config = config
         self.thr = config['thr']
@@ -33,23 +37,36 @@ class CoarseMatching(nn.Module):
         self.train_coarse_percent = config.get('train_coarse_percent', 1.0)
         self.train_pad_num_gt_min = config.get('train_pad_num_gt_min', 200)
         self.temperature = config['dsmax_temperature']
+        self.conf_matrix = conf_matrix
 
     @torch.no_grad()
     def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
-        """Writes b_ids, i_ids, j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf into ``data``
-        (coarse_matching_new.py:118-141).  mask_c0/mask_c1 are accepted and ignored, as in the
-        reference.  The dense ``conf_matrix`` (:70) is not materialised: it is consumed only by
-        the training loss, which is outside this path."""
-        if self.training:
-            raise NotImplementedError("training-mode coarse matching (GT id substitution + dense "
-                                      "conf_matrix for the loss) is not part of the inference hot path")
+        """Writes b_ids, i_ids, j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf (and conf_matrix on
+        request) into ``data`` (coarse_matching_new.py:70,118-141).  mask_c0/mask_c1 are accepted and
+        ignored, as in the reference.  In training mode the ids that select the fine windows are the
+        supervision ids data['spv_*_ids'] (:113-116); the kernels are forward-only, so no gradient
+        flows through conf_matrix."""
+        if self.training and not self.conf_matrix:
+            raise RuntimeError("training-mode CoarseMatching needs conf_matrix=True (the loss reads data['conf_matrix'])")
         scale = data['hw0_i'][0] / data['hw0_c'][0]
         out = ops.coarse_match(feat_c0, feat_c1, data['hw0_c'], data['hw1_c'], scale, self.thr, self.border_rm,
-                               self.temperature, data.get('scale0'), data.get('scale1'))
+                               self.temperature, data.get('scale0'), data.get('scale1'),
+                               conf_matrix=self.conf_matrix)
+        if self.conf_matrix:
+            data.update({'conf_matrix': out['conf_matrix']})
         mconf = out['mconf']
-        data.update({'b_ids': out['b_ids'], 'i_ids': out['i_ids'], 'j_ids': out['j_ids'],
-                     'gt_mask': mconf == 0, 'm_bids': out['b_ids'],
-                     'mkpts0_c': out['mkpts0_c'], 'mkpts1_c': out['mkpts1_c'], 'mconf': mconf})
+        b_ids, i_ids, j_ids = out['b_ids'], out['i_ids'], out['j_ids']
+        mkpts0_c, mkpts1_c = out['mkpts0_c'], out['mkpts1_c']
+        if self.training:                                                    # :113-116, :126-134
+            b_ids, i_ids, j_ids = data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids']
+            scale0 = scale * data['scale0'][b_ids] if 'scale0' in data else scale
+            scale1 = scale * data['scale1'][b_ids] if 'scale1' in data else scale
+            w0c, w1c = data['hw0_c'][1], data['hw1_c'][1]
+            mkpts0_c = torch.stack([i_ids % w0c, torch.div(i_ids, w0c, rounding_mode='floor')], dim=1) * scale0
+            mkpts1_c = torch.stack([j_ids % w1c, torch.div(j_ids, w1c, rounding_mode='floor')], dim=1) * scale1
+        data.update({'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids,
+                     'gt_mask': mconf == 0, 'm_bids': b_ids,
+                     'mkpts0_c': mkpts0_c, 'mkpts1_c': mkpts1_c, 'mconf': mconf})
 
 
 class FinePreprocess(nn.Module):

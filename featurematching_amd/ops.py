@@ -43,6 +43,7 @@ class CoarseBuffers:
     count: torch.Tensor       # int32[2] on device: {M, status bits}
     cap: int
     workspace: torch.Tensor   # kept alive until the stream has consumed it
+    conf_matrix: Optional[torch.Tensor] = None   # dense [N,L,S] when requested
 
     def read_count(self) -> int:
         """The single host sync of the path: returns M (raises on a device-side status)."""
@@ -63,7 +64,8 @@ class CoarseBuffers:
 def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_c, scale_px: float,
                        thr: float = 0.2, border_rm: int = 2, temperature: float = 0.1,
                        scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
-                       cap: Optional[int] = None, cand_slots: Optional[int] = None) -> CoarseBuffers:
+                       cap: Optional[int] = None, cand_slots: Optional[int] = None,
+                       conf_matrix: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising."""
     lib = _lib.load()
@@ -88,26 +90,29 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     out = CoarseBuffers(torch.empty(cap, **i64), torch.empty(cap, **i64), torch.empty(cap, **i64),
                         torch.empty(cap, 2, **f32), torch.empty(cap, 2, **f32), torch.empty(cap, **f32),
                         torch.empty(2, dtype=torch.int32, device=dev), cap, ws)
+    if conf_matrix:      # data['conf_matrix'] (coarse_matching_new.py:70): one more sweep + N*L*S*4 bytes
+        out.conf_matrix = torch.empty(n, l, s, dtype=torch.float32, device=dev)
     sc0 = None if scale0 is None else _f32c(scale0.to(dev), "scale0")
     sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
     st = lib.fm_coarse_match(_ptr(f0), _ptr(f1), n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
                              int(hw1_c[1]), float(temperature), float(thr), int(border_rm), float(scale_px),
                              _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots,
                              _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids), _ptr(out.mkpts0_c),
-                             _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), None, _stream(dev))
+                             _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), _ptr(out.conf_matrix),
+                             _stream(dev))
     _lib.check(st, "fm_coarse_match")
     out._keep = (f0, f1, sc0, sc1)   # inputs must outlive the enqueued kernels
     return out
 
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
-                 scale0=None, scale1=None) -> dict:
+                 scale0=None, scale1=None, conf_matrix: bool = False) -> dict:
     """Synchronous form: sliced outputs.  Retries once with a larger capacity (exact ties can
     exceed N*min(L,S)) or more candidate slots when the device reports either overflow."""
     kw = dict(cap=None, cand_slots=None)
     for _ in range(4):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
-                                 scale0, scale1, **kw)
+                                 scale0, scale1, conf_matrix=conf_matrix, **kw)
         try:
             m = buf.read_count()
         except _lib.FMatchError as e:
@@ -119,7 +124,10 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
                 kw['cand_slots'] = min(64, base * 2)
                 continue
             raise
-        return buf.sliced(m)
+        out = buf.sliced(m)
+        if conf_matrix:
+            out['conf_matrix'] = buf.conf_matrix
+        return out
     raise RuntimeError("coarse_match: overflow persisted after retries")
 
 

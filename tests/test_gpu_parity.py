@@ -274,8 +274,39 @@ def test_matcher_end_to_end_on_warped_images():
     k0, k1, conf = m.match(img0, img1)
     assert k0.shape == k1.shape and k0.shape[1] == 2 and conf.shape[0] == k0.shape[0]
     assert k0.shape[0] > 100
-    d = (k0 - k1).cpu().numpy()
-    good = (np.abs(d[:, 0] - 16) < 4) & (np.abs(d[:, 1] - 8) < 4)
-    assert good.mean() > 0.8
+    # coarse level: image1 = image0 shifted by exactly (2, 1) cells -> every coarse match has that shift
+    dc = (m.last['mkpts0_c'] - m.last['mkpts1_c']).cpu().numpy()
+    assert ((dc[:, 0] == 16) & (dc[:, 1] == 8)).mean() > 0.98
+    # fine level (random weights): offsets stay inside the window, i.e. W//2 +- (W//2)*scale = 3 +- 6 px
+    off0 = (k0 - m.last['mkpts0_c']).cpu().numpy()
+    assert off0.min() >= -3.001 and off0.max() <= 9.001
     for key in ('mkpts0_f', 'mkpts1_f', 'mconf', 'm_bids', 'feat_c0', 'feat_f1', 'hw0_c', 'W'):
         assert key in m.last
+
+
+# ------------------------------------------------------------------ dense conf_matrix + training ids
+def test_dense_conf_matrix_and_training_ids():
+    f0, f1 = synth.coarse_descriptors(91, 2, 23 * 31, 256, "borderline")       # ragged L = S = 713
+    hw_c, hw_i = (23, 31), (184, 248)
+    ref = orc.coarse_match(f0, f1, hw_i, hw_c, hw_c, 0.2, 2, 0.1, return_conf=True)
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    out = ops.coarse_match(t0, t1, hw_c, hw_c, 8.0, conf_matrix=True)
+    _assert_coarse(out, ref)
+    got = out['conf_matrix'].cpu()
+    assert got.shape == ref['conf_matrix'].shape
+    err = (got - ref['conf_matrix']).abs().max().item()
+    assert err <= 1e-5, err
+    # the emitted mconf are entries of the dense matrix
+    pick = got[out['b_ids'].cpu(), out['i_ids'].cpu(), out['j_ids'].cpu()]
+    assert (pick - out['mconf'].cpu()).abs().max().item() <= 2e-6
+    # training mode: supervision ids select the windows (coarse_matching_new.py:113-116)
+    cm = modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1}, conf_matrix=True).train()
+    spv = dict(spv_b_ids=torch.tensor([0, 1, 1], device=DEV), spv_i_ids=torch.tensor([40, 7, 300], device=DEV),
+               spv_j_ids=torch.tensor([41, 8, 5], device=DEV))
+    data = dict(hw0_i=hw_i, hw1_i=hw_i, hw0_c=hw_c, hw1_c=hw_c, **spv)
+    cm(t0, t1, data)
+    assert torch.equal(data['i_ids'], spv['spv_i_ids']) and data['conf_matrix'].shape == (2, 713, 713)
+    assert data['mkpts0_c'].cpu().tolist() == [[(40 % 31) * 8.0, (40 // 31) * 8.0], [56.0, 0.0], [(300 % 31) * 8.0, 72.0]]
+    assert data['mconf'].shape[0] == ref['mconf'].shape[0]
+    with pytest.raises(RuntimeError):
+        modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1}).train()(t0, t1, dict(data))
