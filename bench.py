@@ -94,6 +94,22 @@ def time_corr_kernel(pair, mode, iters=30):
     return total / iters
 
 
+def pmc_traffic_bytes(a):
+    """HBM/fabric bytes per launch of the sum pass from the committed rocprofv3 PMC passes of this
+    very command (profiles/r01_pmc_fetch_write_cfg2.json: separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs of `bench.py --no-graph`), with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE
+    counts half of the bytes of wide reads, both counters are in KiB.  None for other workloads."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_cfg2.json")
+    if a.workload != "cfg2" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    for name, c in d.items():
+        if "k_corr<256, 1>" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    return None
+
+
 def cpu_baseline(wl, window, seed, budget_s=12.0):
     """The CPU oracle (a port of the reference's torch ops, pinned to the reference by the golden
     fixtures) on this host's cores, on a bounded sample of the same workload."""
@@ -103,7 +119,10 @@ def cpu_baseline(wl, window, seed, budget_s=12.0):
     f0, f1 = synth.coarse_descriptors(seed, n, sh["l"], wl["c"], "peaky")
     ff0, ff1 = synth.fine_maps(seed, n, wl["cf"], sh["hf"], sh["wf"])
     mix = synth.mix_weights(seed, window * window)
-    threads = torch.get_num_threads()
+    # torch's default (all 256 hardware threads of the host) is 4x slower than a few cores for these
+    # memory-bound dense passes; 8 threads was the fastest of {8,16,32,64,128} on the MI355X host
+    threads = min(8, os.cpu_count() or 8)
+    torch.set_num_threads(threads)
     orc.match_features(f0, f1, ff0, ff1, (wl["h"], wl["w"]), mix, w=window)     # warm-up
     t0 = time.perf_counter()
     done = 0
@@ -223,7 +242,7 @@ def main():
                    "matches_per_pair": round(float(np.mean(ms)) / wl["n"], 1)},
         "roofline": {"bound": "mfma", "kernel": "k_corr<256,1> (sum pass: correlation + dual-softmax sums + candidates)",
                      "achieved": round(ach_b, 2), "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach_b / PEAK_F16_DENSE_TFLOPS, 4), "traffic": None,
+                     "frac": round(ach_b / PEAK_F16_DENSE_TFLOPS, 4), "traffic": pmc_traffic_bytes(a),
                      "avg_ms": round(t_b, 5), "algorithmic_flop": flops,
                      "mfma_issued_frac": round(3 * ach_b / PEAK_F16_DENSE_TFLOPS, 4),
                      "max_pass_avg_ms": round(t_a, 5),

@@ -41,12 +41,13 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
   w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
-  w.bmax0 = take(rows / 32 * 4); w.bmax1 = take(cols / prep_rows(C) * 4);
+  w.bmax0 = take(rows / 32 * 4); w.bmax1 = take(cols / 32 * 4);
   w.rowA = take(rows * w.splits * 4); w.colA = take(cols * w.panels * kColParts * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * kColParts * 4);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
   w.rsum = take(rows * 4); w.csum = take(cols * 4);
   w.nmr2 = take(rows * 4); w.nmc2 = take(cols * 4);
+  w.umax = take(rows / 32 * (cols / N / 32) * 4); w.emarg = take((size_t)N * 4);
   w.cand_j = take(rows * slots * 4); w.cand_conf = take(rows * slots * 4); w.rowbest = take(rows * 4);
   w.keep_j = take(rows * slots * 4); w.keep_conf = take(rows * slots * 4); w.rowcnt = take(rows * 4);
   w.total = o;

@@ -1,15 +1,23 @@
-// Coarse stage, the two correlation sweeps (the hot kernels).
+// Coarse stage, the correlation sweeps (the hot kernels).
 //
 // Reproduces network/utils/coarse_matching_new.py:64-68 (all-pairs correlation + dual
 // softmax statistics) without ever writing the L x S matrix:
 //
 //   pass A (MODE 0): raw = hi0 . hi1^T on the f16 matrix cores; per-row and per-column
-//                    maxima (partial over column splits / row panels).
+//                    maxima (partial over column splits / row panels) and the maximum of
+//                    every 32 x 32 unit (block map for pass B).
 //   pass B (MODE 1): raw = hi0.hi1 + lo0.hi1 + hi0.lo1 (float32-accurate product);
 //                    row sums  sum_j exp(s_ij - m^_i), column sums sum_i exp(s_ij - c^_j)
-//                    with the stabilisers of k_reduce_max, and the sparse candidate list
+//                    with the stabilisers of k_reduce<0>, and the sparse candidate list
 //                    {(i,j): s_ij - m^_i > ln thr  and  s_ij - c^_j > ln thr}, a superset
 //                    of every entry with conf > thr (coarse_matching_new.py:99).
+//                    BLOCK-SPARSE: a unit whose largest entry (from pass A, plus the f16 error
+//                    margin) lies more than 2^32 below every row stabiliser of its 32 rows AND every
+//                    column stabiliser of its 32 columns is skipped: each of its entries adds
+//                    < 2^-32 to a sum that is >= e^-2E ~ 1 (at most S * 2^-32 ~ 1e-6 relative in total,
+//                    inside the 1e-5 parity bar) and none can be a candidate.  With dual-softmax-
+//                    trained (peaked) descriptors ~85 % of the units qualify; with flat similarity
+//                    nothing is skipped and the sweep is dense.
 //   pass C (MODE 2): only when pass B's screening overflowed a row's candidate slots (flat
 //                    similarity rows, e.g. an untrained network): the same product again, screened
 //                    with the now-known softmax denominators, log2 P_row > log2 thr and
@@ -21,9 +29,9 @@
 // Structure (one workgroup = 8 waves = 256 rows of image 0; cf. SURVEY.md 7, hard part 2):
 //   * each wave keeps its 32 rows x C of image-0 descriptors as MFMA A-fragments in
 //     registers for the whole sweep (no K loop, no re-read);
-//   * image-1 descriptors stream through LDS in 64-column tiles, double buffered,
-//     filled by LDS-DMA (global_load_lds_dwordx4) with an XOR swizzle applied on the
-//     SOURCE address so that the ds_read_b128 fragment reads are bank-conflict free;
+//   * image-1 descriptors stream through LDS in 64-column tiles, double buffered, filled by LDS-DMA
+//     (global_load_lds_dwordx4) one 1 KiB fragment block at a time; planes are fragment-major
+//     (k_prep_split), so the LDS image is lane-linear and every ds_read_b128 is bank-conflict free;
 //   * the f32 accumulator tile (32 rows x 32 cols per wave and unit) never leaves registers:
 //     the epilogue turns it into exp2 terms, accumulates row sums in registers across
 //     the whole sweep and reduces column sums lane-locally (rows live in registers,
@@ -43,13 +51,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef FM_PF_MAX
 #define FM_PF_MAX 4
 #endif
+constexpr float kSkipLog2 = 32.f;     // block-sparse threshold: entries below 2^-32 of every stabiliser
 
 struct CorrArgs {
   const _Float16* hi0; const _Float16* lo0; const _Float16* hi1; const _Float16* lo1;
   const float* nmr; const float* nmc;
   float* rowpart; float* colpart;
+  float* umax;            // [N][Lp/32][Sp/32] unit maxima of the raw f16 product (written by MODE 0)
+  const float* emarg;     // [N] log2-domain bound of |f16 product - exact product| * k
   int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
-  float* conf;   // MODE 3: dense [N,L,S] output
+  float* conf;            // MODE 3: dense [N,L,S] output
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, slots;
   float k;    // log2(e) / (C*T): raw dot product -> log2-domain similarity
   float lt;   // log2(thr)
@@ -62,36 +73,43 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
   return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + y;
 }
 
-template <int C>
-__device__ __forceinline__ int swz(int col) {
-  constexpr int CHUNKS = C / 8;
-  return CHUNKS >= 16 ? (col & 15) : ((col >> 1) & (CHUNKS - 1));
-}
-
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-#ifndef FM_NO_GLDS
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-#else
-  const uint4 v = *reinterpret_cast<const uint4*>(gsrc);
-  *reinterpret_cast<uint4*>(lds_wave_base + (threadIdx.x & 63) * 16) = v;
-#endif
+}
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, 0xf, BANK, false));
+}
+// max over the 64 lanes, in every lane; DPP + permlane swaps (no LDS).  See fine.hip for the lane maps.
+__device__ __forceinline__ float wave_max64(float v) {
+  v = fmaxf(v, dpp_mov<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x4E, 0xf>(v, v));
+  { float t = dpp_mov<0x104, 0x5>(v, v); t = dpp_mov<0x114, 0xA>(t, v); v = fmaxf(v, t); }
+  v = fmaxf(v, dpp_mov<0x128, 0xf>(v, v));
+  { float p = v, q = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q)); v = fmaxf(p, q); }
+  { float p = v, q = v; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q)); v = fmaxf(p, q); }
+  return v;
 }
 
 template <int C, int MODE>
 __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   constexpr int KSTEPS = C / 16;
   constexpr int ROWB = C * 2;
-  constexpr int CHUNKS = C / 8;
   constexpr int PLANES = MODE ? 2 : 1;
   constexpr int PLANE_BYTES = kTileCols * ROWB;
   constexpr int BUF_BYTES = PLANES * PLANE_BYTES;
   constexpr int INSTR_PER_WAVE = PLANE_BYTES / 1024 / 8;
+  constexpr bool SPARSE = (MODE == 1 || MODE == 2);
+  constexpr int META = 80;          // per tile: 64 column stabilisers + 16 unit maxima (8 waves x 2 units)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   if (MODE == 2 && !(*a.flags & FM_INT_SCREEN_OVERFLOW)) return;   // uniform: fast screening sufficed
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
   int kk = xcd_remap(blockIdx.x, gridDim.x);
@@ -101,34 +119,45 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const int t0 = split * a.tiles_per_split;
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
-  const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};
+  const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};   // fragment-major
+  float* nmr_lds = reinterpret_cast<float*>(smem + 2 * BUF_BYTES) + wv * 32;
+  float* meta = reinterpret_cast<float*>(smem + 2 * BUF_BYTES + 1024);       // [2][META]
 
+  // One LDS-DMA instruction copies one 1 KiB fragment block (32 columns x one k-step x one lane half
+  // pair) of the fragment-major planes: contiguous in global memory and in LDS.  Tile image in LDS:
+  // [plane][column block 0/1][k-step][64 lanes x 16 B].
   auto stage = [&](int t, int buf) {
 #pragma unroll
     for (int p = 0; p < PLANES; ++p) {
 #pragma unroll
       for (int n = 0; n < INSTR_PER_WAVE; ++n) {
-        const int instr = wv * INSTR_PER_WAVE + n;
-        const int byte = instr * 1024 + lane * 16;
-        const int col = byte / ROWB;
-        const int q = ((byte % ROWB) >> 4) ^ swz<C>(col);
-        const _Float16* src = planes1[p] + (long)(t * kTileCols + col) * C + q * 8;
-        glds16(src, smem + buf * BUF_BYTES + p * PLANE_BYTES + instr * 1024);
+        const int blk = wv * INSTR_PER_WAVE + n;                       // 0 .. 2*KSTEPS-1 = (cb, ks)
+        const _Float16* src = planes1[p] + ((long)(2 * t) * KSTEPS + blk) * 512 + lane * 8;
+        glds16(src, smem + buf * BUF_BYTES + p * PLANE_BYTES + blk * 1024);
       }
     }
   };
+  // per-tile metadata travels with the tile: threads 0..63 fetch the column stabilisers, threads
+  // 64..79 the unit maxima of (wave, unit) = ((tid-64)/2, (tid-64)%2); written to LDS before the barrier
+  auto meta_load = [&](int t) -> float {
+    if (MODE && tid < 64) return a.nmc[(long)b * a.Sp + t * kTileCols + tid];
+    if (SPARSE && tid >= 64 && tid < META) {
+      const int w = (tid - 64) >> 1, s = (tid - 64) & 1;
+      return a.umax[((long)b * (a.Lp / 32) + panel * 8 + w) * (a.Sp / 32) + 2 * t + s];
+    }
+    return 0.f;
+  };
+  auto meta_store = [&](int buf, float v) { if (MODE && tid < META) meta[buf * META + tid] = v; };
 
-  if (t0 < t1) stage(t0, 0);
-#ifdef FM_ABL_NOSTAGE
-  if (t0 + 1 < t1) stage(t0 + 1, 1);
-#endif
+  float mv = 0.f;
+  if (t0 < t1) { stage(t0, 0); mv = meta_load(t0); }
 
   // ---- this wave's 32 rows as A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7) ----
-  // (lane = h*32 + r is exactly the lane order of the fragment-major block)
+  // fragment-major planes (k_prep_split): one contiguous 1 KiB block per (32-row block, k-step);
+  // lane = h*32 + r is exactly the lane order of that block.
   const int wrow0 = panel * kPanelRows + wv * 32;
   half8 ahi[KSTEPS], alo[MODE ? KSTEPS : 1];
   {
-    // fragment-major planes (k_prep_split): one contiguous 1 KiB block per (32-row block, k-step)
     const long off = (((long)b * a.Lp + wrow0) / 32 * KSTEPS * 64 + lane) * 8;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) ahi[ks] = *reinterpret_cast<const half8*>(a.hi0 + off + ks * 512);
@@ -143,19 +172,19 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #pragma unroll
   for (int g = 0; g < 16; ++g) rstat[g] = MODE ? 0.f : -INFINITY;
   // row stabilisers of this wave's 32 rows, parked in LDS (read back 4 at a time in the epilogue)
-  float* nmr_lds = reinterpret_cast<float*>(smem + 2 * BUF_BYTES) + wv * 32;
-  if (MODE && lane < 32) nmr_lds[lane] = a.nmr[(long)b * a.Lp + wrow0 + lane];
+  float wmax_nmr = 0.f;     // largest (= least negative) row stabiliser of this wave's rows, uniform
+  float emarg = 0.f;
+  if (MODE) {
+    const float nv = lane < 32 ? a.nmr[(long)b * a.Lp + wrow0 + lane] : -INFINITY;
+    if (lane < 32) nmr_lds[lane] = nv;
+    // padded rows (>= L) never contribute: keep them out of the wave's largest stabiliser
+    if (SPARSE) { wmax_nmr = wave_max64(wrow0 + lane < a.L ? nv : -INFINITY); emarg = a.emarg[b]; }
+  }
   const bool row_edge = (wrow0 + 32 > a.L);     // wave-uniform: some of this wave's rows are padding
 
-  const int lanebase0 = r * ROWB + (((h * (CHUNKS / 2)) ^ swz<C>(r)) << 4);              // columns 0..31 of a tile
-  const int lanebase1 = (32 + r) * ROWB + (((h * (CHUNKS / 2)) ^ swz<C>(32 + r)) << 4);  // columns 32..63
   float* colout = a.colpart + (((long)b * a.panels + panel) * kColParts + wv) * a.Sp;
 
   f32x16 acc;
-#if defined(FM_ABL_NOMFMA)
-#pragma unroll
-  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-#endif
 
   // one unit = 32 rows x 32 columns x C: the accumulator tile of this wave.
   // B fragments are read PF k-steps ahead into a small register ring so that the LDS latency
@@ -167,19 +196,17 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   // more conservative if the compiler has LDS/SMEM operations of its own in flight.
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto mfma_unit = [&](int u) {
-    const unsigned base = lds0 + (((u >> 1) - t0) & 1) * BUF_BYTES + ((u & 1) ? lanebase1 : lanebase0);
+    const unsigned base = lds0 + (((u >> 1) - t0) & 1) * BUF_BYTES + (u & 1) * (KSTEPS * 1024) + lane * 16;
     constexpr int PF = MODE ? FM_PF_SUM : FM_PF_MAX;
     constexpr int RING = PF + 1;
     constexpr int RPK = MODE ? 2 : 1;       // LDS reads per k-step
     half8 bh[RING], bl[MODE ? RING : 1];
     auto issue = [&](int ks) {
-      const unsigned la = base ^ (unsigned)(ks << 4);
+      const unsigned la = base + (unsigned)(ks * 1024);
       asm volatile("ds_read_b128 %0, %1" : "=v"(bh[ks % RING]) : "v"(la));
       if (MODE) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[ks % RING]) : "v"(la), "i"(PLANE_BYTES));
     };
-#ifdef FM_SETPRIO
-    __builtin_amdgcn_s_setprio(FM_SETPRIO);   // MFMA phase wins issue arbitration over the SIMD partner's epilogue
-#endif
+    __builtin_amdgcn_s_setprio(1);   // the MFMA phase wins issue arbitration over the SIMD partner's epilogue
 #pragma unroll
     for (int ks = 0; ks < PF && ks < KSTEPS; ++ks) issue(ks);
 #pragma unroll
@@ -227,13 +254,11 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl[ks % RING], acc, 0, 0, 0);
       }
     }
-#ifdef FM_SETPRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
   };
 
   // epilogue of unit u: fold the accumulator into the row / column statistics
-  auto epilogue = [&](int u) {
+  auto epilogue = [&](int u, float nmc) {
     const int col = (u >> 1) * kTileCols + (u & 1) * 32 + r;     // this lane's column
     const bool cvalid = col < a.S;
     float cstat;
@@ -246,11 +271,12 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         cstat = fmaxf(cstat, x);
       }
       cstat = fmaxf(cstat, __shfl_xor(cstat, 32));
+      const float um = wave_max64(cstat);                         // block map for the sum pass
+      if (lane == 0) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * (a.Sp / 32) + u] = um;
     } else if (MODE == 3) {
       // dense conf_matrix (coarse_matching_new.py:68,70): softmax(sim,1) * softmax(sim,2) from the
       // log-softmax offsets nmr2 = nmr - log2(row sum), nmc2 = nmc - log2(column sum)
       cstat = 0.f;
-      const float nmc = a.nmc[(long)b * a.Sp + col];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(nmr_lds + 8 * q + 4 * h);
@@ -265,7 +291,6 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         }
       }
     } else {
-      const float nmc = a.nmc[(long)b * a.Sp + col];
       float best = -INFINITY;
       cstat = 0.f;
       float nmr[16];
@@ -307,34 +332,40 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     if (MODE <= 1 && h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
   };
 
-  __syncthreads();
+  meta_store(0, mv);
+  __syncthreads();          // first tile and its metadata landed
 
   // Waves w and w+4 share a SIMD.  The second half of the workgroup runs one epilogue behind the
   // first, so that on every SIMD one wave's exp/add epilogue overlaps the other's MFMA chain.
-#ifdef FM_ABL_NOSTAGGER
-  const bool late = false;
-#else
   const bool late = wv >= 4;
-#endif
+  int pend = -1;            // late waves: unit whose epilogue is still owed (its accumulator is live)
+  float nmc_pend = 0.f;
   for (int u = 2 * t0; u < 2 * t1; ++u) {
-#ifndef FM_ABL_NOSTAGE
-    if ((u & 1) == 0 && (u >> 1) + 1 < t1) stage((u >> 1) + 1, (((u >> 1) - t0) & 1) ^ 1);
-#endif
-#ifdef FM_ABL_NOEPI
-    mfma_unit(u);
-    asm volatile("" :: "v"(acc));
-#elif defined(FM_ABL_NOMFMA)
-    if (late && u > 2 * t0) epilogue(u - 1);
-    asm volatile("" : "+v"(acc));
-    if (!late) epilogue(u);
-#else
-    if (late && u > 2 * t0) epilogue(u - 1);
-    mfma_unit(u);
-    if (!late) epilogue(u);
-#endif
-    if (u & 1) __syncthreads();   // tile consumed by every wave; next tile landed (LDS-DMA drained)
+    const int t = u >> 1, par = (t - t0) & 1;
+    if ((u & 1) == 0 && t + 1 < t1) { stage(t + 1, par ^ 1); mv = meta_load(t + 1); }
+
+    const float nmc_u = MODE ? meta[par * META + (u & 1) * 32 + r] : 0.f;
+    bool skip = false;
+    if (SPARSE) {
+      const float um = meta[par * META + 64 + wv * 2 + (u & 1)];    // largest raw f16 product of this unit
+      const float top = __builtin_fmaf(um, a.k, emarg);             // >= k * (exact product), log2 domain
+      const float cmax = wave_max64(t * kTileCols + (u & 1) * 32 + r < a.S ? nmc_u : -INFINITY);
+      skip = __builtin_amdgcn_readfirstlane((int)((top + wmax_nmr < -kSkipLog2) && (top + cmax < -kSkipLog2)));
+    }
+    if (late && pend >= 0) { epilogue(pend, nmc_pend); pend = -1; }
+    if (!skip) {
+      mfma_unit(u);
+      if (late) { pend = u; nmc_pend = nmc_u; }
+      else epilogue(u, nmc_u);
+    } else if (MODE == 1 && h == 0) {
+      colout[t * kTileCols + (u & 1) * 32 + r] = 0.f;               // skipped unit: contributes nothing
+    }
+    if (u & 1) {
+      if (t + 1 < t1) meta_store(par ^ 1, mv);
+      __syncthreads();      // tile consumed by every wave; next tile landed (LDS-DMA drained)
+    }
   }
-  if (late && t1 > t0) epilogue(2 * t1 - 1);
+  if (late && pend >= 0) epilogue(pend, nmc_pend);
 
   if (MODE >= 2) return;
   // ---- row statistics of this workgroup's column range: reduce over the 32 lanes of each half ----
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 template <int C, int MODE>
 static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
   constexpr int BUF_BYTES = (MODE ? 2 : 1) * kTileCols * C * 2;
-  constexpr int SMEM = 2 * BUF_BYTES + 8 * 32 * 4;
+  constexpr int SMEM = 2 * BUF_BYTES + 8 * 32 * 4 + 2 * 80 * 4;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr<C, MODE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   if (e != hipSuccess) return e;
@@ -375,6 +406,7 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.conf = conf;
   a.rowpart = (float*)(base + (mode ? w.rowB : w.rowA));
   a.colpart = (float*)(base + (mode ? w.colB : w.colA));
+  a.umax = (float*)(base + w.umax); a.emarg = (const float*)(base + w.emarg);
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
   a.cand_x = (float*)(base + w.cand_conf);   // raw dot product now, replaced by conf in k_cand_conf
   a.flags = (unsigned*)(base + w.scalars);

@@ -31,11 +31,13 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 // One dispatch prepares both images and clears the per-call counters.
 // C = padded channel count of the planes (64/128/256); c_in <= C = channels of the source rows,
 // the planes are zero beyond c_in (a dot product does not change under zero padding).
-//   image 1 (streamed through LDS by the sweeps): planes row-major [N*Sp][C], 8/16 rows per workgroup.
-//   image 0 (register-resident A operand of the sweeps): planes FRAGMENT-major, one workgroup per
-//     32-row block: element (row, k) lives at (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8
-//     with chunk q = k/8 = h*KSTEPS + ks, so the 64 lanes (h, row%32) of a wave read one contiguous
-//     1 KiB block per k-step instead of 64 separate 16-byte pieces 512 B apart.
+//   Both images' planes are FRAGMENT-major, one workgroup per 32-row block: element (row, k) lives at
+//     (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8   with chunk q = k/8 = h*KSTEPS + ks,
+//   i.e. the 64 lanes (h, row%32) of an MFMA operand fragment are one contiguous 1 KiB block per
+//   (32-row block, k-step).  Image 0 (the register-resident A operand of the sweeps) is read that way
+//   straight into registers; image 1 blocks are copied 1 KiB at a time into LDS by LDS-DMA (lane-linear
+//   image: the ds_read_b128 of lane l at l*16 is bank-conflict free with no swizzle), or fetched directly
+//   by the block-sparse path.
 // A workgroup that sees a non-finite / out-of-range value reports +inf as its block norm; k_reduce<0>
 // turns that into FM_DEV_RANGE (the flag word itself is cleared by this kernel, so it cannot be set here).
 template <int C>
@@ -51,20 +53,24 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   __shared__ float sm[8][33];
   float bmax = 0.f;
   bool bad = false;
-  if ((int)blockIdx.x < a.blocks0) {
-    // ---------------- image 0: one 32-row block, fragment-major ----------------
-    const long rb = blockIdx.x;                       // global row block over N*Lp/32
-    const int b = (int)(rb * 32 / a.Lp);
+  {
+    // ---------------- one 32-row block of image 0 or image 1, fragment-major ----------------
+    const bool img1 = (int)blockIdx.x >= a.blocks0;
+    const long rb = img1 ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;   // row block over N*Lp/32 (N*Sp/32)
+    const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
+    _Float16* const hi = img1 ? a.hi1 : a.hi0;
+    _Float16* const lo = img1 ? a.lo1 : a.lo0;
+    const int b = (int)(rb * 32 / rows_pad);
     const int r = tid & 31;
-    const int local = (int)(rb * 32 - (long)b * a.Lp) + r;
-    const float* row = a.src0 + ((long)b * a.L + local) * a.c_in;
+    const int local = (int)(rb * 32 - (long)b * rows_pad) + r;
+    const float* row = (img1 ? a.src1 : a.src0) + ((long)b * rows + local) * a.c_in;
     float ss = 0.f;
 #pragma unroll
     for (int n = 0; n < C / 8 / 8; ++n) {             // C/8 chunks of 8 channels, 8 per pass
       const int q = n * 8 + (tid >> 5);
       const int h = q / KSTEPS, ks = q - h * KSTEPS;
       float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-      if (local < a.L) {
+      if (local < rows) {
         if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
         if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
       }
@@ -79,8 +85,8 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
         ss += x[e] * x[e];
       }
       const long off = (((rb * KSTEPS + ks) * 2 + h) * 32 + r) * 8;
-      *reinterpret_cast<half8*>(a.hi0 + off) = hh;
-      *reinterpret_cast<half8*>(a.lo0 + off) = ll;
+      *reinterpret_cast<half8*>(hi + off) = hh;
+      *reinterpret_cast<half8*>(lo + off) = ll;
     }
     sm[tid >> 5][r] = ss;
     __syncthreads();
@@ -89,40 +95,9 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) t += sm[g][tid];
       const float nrm = sqrtf(t);
-      a.norm0[rb * 32 + tid] = nrm;
+      (img1 ? a.norm1 : a.norm0)[rb * 32 + tid] = nrm;
       bmax = nrm;
     }
-  } else {
-    // ---------------- image 1: 8 or 16 rows, row-major ----------------
-    constexpr int LPR = C / 4;        // lanes per row (one float4 each)
-    constexpr int RPP = 256 / LPR;    // rows per pass of the workgroup
-    constexpr int kPrepRows = C >= 128 ? 8 : 16;   // == prep_rows(C)
-    const int sub = tid / LPR;
-    const int lir = tid % LPR;
-    const long row0 = (long)((int)blockIdx.x - a.blocks0) * kPrepRows;
-#pragma unroll
-    for (int p = 0; p < kPrepRows / RPP; ++p) {
-      const long prow = row0 + p * RPP + sub;
-      const int b = (int)(prow / a.Sp);
-      const int local = (int)(prow - (long)b * a.Sp);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (local < a.S && lir * 4 < a.c_in)
-        v = *reinterpret_cast<const float4*>(a.src1 + ((long)b * a.S + local) * a.c_in + lir * 4);
-      bad = bad || bad_value(v);
-      half4 h, l;
-      h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-      l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-      l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-      *reinterpret_cast<half4*>(a.hi1 + prow * C + lir * 4) = h;
-      *reinterpret_cast<half4*>(a.lo1 + prow * C + lir * 4) = l;
-      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-#pragma unroll
-      for (int m = LPR / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
-      const float nrm = sqrtf(ss);
-      if (lir == 0) a.norm1[prow] = nrm;
-      bmax = fmaxf(bmax, nrm);
-    }
-    __syncthreads();     // keep the barrier count equal on both paths (sm is reused below)
   }
   if (__any(bad)) bmax = INFINITY;
 #pragma unroll
@@ -133,7 +108,7 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   if (tid == 0) {
     const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     if ((int)blockIdx.x < a.blocks0) a.bmax0[blockIdx.x] = m;
-    else a.bmax1[(int)blockIdx.x - a.blocks0] = m;
+    else a.bmax1[(int)blockIdx.x - a.blocks0] = m;     // one entry per 32-row block for both images
   }
 }
 
@@ -148,7 +123,7 @@ hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const C
   a.zero = (uint4*)(base + w.zero_begin); a.zero_vec = (int)((w.zero_end - w.zero_begin) / 16);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.c_in = c_in;
   a.blocks0 = (int)((long)w.N * w.Lp / 32);
-  const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / prep_rows(w.C));
+  const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / 32);
   switch (w.C) {
     case 64: hipLaunchKernelGGL(k_prep_split<64>, dim3(blocks), dim3(256), 0, st, a); break;
     case 128: hipLaunchKernelGGL(k_prep_split<128>, dim3(blocks), dim3(256), 0, st, a); break;
@@ -177,7 +152,8 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
                                                 int rparts, int cparts, float inv_ct, float sqrt_c, int prows0, int prows1,
                                                 const float* __restrict__ nm_r, const float* __restrict__ nm_c,
                                                 float* __restrict__ nm2_r, float* __restrict__ nm2_c,
-                                                int* __restrict__ cand_count, unsigned* __restrict__ flags) {
+                                                int* __restrict__ cand_count, unsigned* __restrict__ flags,
+                                                float* __restrict__ emarg) {
   const int side = blockIdx.z;
   const int b = blockIdx.y;
   const int len = side ? Sp : Lp;
@@ -225,6 +201,13 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
   om = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
   // a prep workgroup that met NaN/Inf/|x| >= 32768 reported +inf (either image is seen by one side)
   if (!(om < INFINITY) && blockIdx.x == 0 && cx == 0) atomicOr(flags, (unsigned)FM_DEV_RANGE);
+  if (side == 0 && blockIdx.x == 0 && cx == 0) {
+    // log2-domain bound of k * |f16 product - exact product| over the whole pair: lets pass B turn the
+    // unit maxima of pass A into upper bounds of the exact similarity (block-sparse skipping)
+    float own = 0.f;
+    for (int k = 0; k < Lp / prows0; ++k) own = fmaxf(own, bmax0[(long)b * (Lp / prows0) + k]);
+    emarg[b] = ((9.8633e-4f * own * om + 5.9605e-8f * sqrt_c * (own + om)) * inv_ct + 1e-6f) * kLog2e + 1e-3f;
+  }
   float raw = v;
   if (!(raw > -INFINITY)) raw = 0.f;   // padded row/column: never used
   const float nrm = ((side ? norm1 : norm0) + (long)b * len)[idx];
@@ -241,14 +224,14 @@ hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, 
   if (mode == 0)
     hipLaunchKernelGGL(k_reduce<0>, grid, dim3(256), 0, st, (const float*)(base + w.rowA),
                        (const float*)(base + w.colA), n0, n1, b0, b1, (float*)(base + w.nmr), (float*)(base + w.nmc),
-                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C), nullptr, nullptr,
-                       nullptr, nullptr, nullptr, (unsigned*)(base + w.scalars));
+                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, 32, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, (unsigned*)(base + w.scalars), (float*)(base + w.emarg));
   else
     hipLaunchKernelGGL(k_reduce<1>, grid, dim3(256), 0, st, (const float*)(base + w.rowB),
                        (const float*)(base + w.colB), n0, n1, b0, b1, (float*)(base + w.rsum), (float*)(base + w.csum),
-                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, prep_rows(w.C),
+                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, 32,
                        (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
-                       (float*)(base + w.nmc2), (int*)(base + w.cand_count), (unsigned*)(base + w.scalars));
+                       (float*)(base + w.nmc2), (int*)(base + w.cand_count), (unsigned*)(base + w.scalars), nullptr);
   return hipGetLastError();
 }
 

@@ -9,15 +9,9 @@
 namespace fm {
 
 constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup owns
-// column partials each panel writes (one per wave): 8 waves x 32 rows, or 4 waves x 64 rows in the v2 sweep
-#ifdef FM_CORR_V2
-constexpr int kColParts = 4;
-#else
+// column partials each panel writes (one per wave: 8 waves x 32 rows)
 constexpr int kColParts = 8;
-#endif
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
-// rows one prep workgroup converts (C = padded channel count)
-inline int prep_rows(int C) { return C >= 128 ? 8 : 16; }
 constexpr float kLog2e = 1.4426950408889634f;
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
 constexpr unsigned FM_INT_SCREEN_OVERFLOW = 8u;
@@ -42,6 +36,7 @@ struct CoarseWs {
   size_t nmr, nmc;                            // -stabiliser*log2e per row / column
   size_t rsum, csum;                          // softmax denominators per row / column
   size_t nmr2, nmc2;                          // nmr - log2(rsum), nmc - log2(csum): log-softmax offsets
+  size_t umax, emarg;                         // unit maxima [N][Lp/32][Sp/32] of pass A; f16 error margin [N]
   size_t cand_j, cand_conf, rowbest;          // candidate columns, exact conf, best conf per row
   size_t keep_j, keep_conf, rowcnt;           // selected matches per row (sorted by j)
   size_t total;

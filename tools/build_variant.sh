@@ -1,13 +1,11 @@
 #!/bin/bash
 # Build an experimental variant of the library:  tools/build_variant.sh NAME "-DFM_PF_SUM=3 ..."
 # -> build/variants/libfmatch_NAME.so   (load it with FMATCH_LIB=build/variants/libfmatch_NAME.so)
-# -DFM_CORR_V2 among the flags selects coarse_corr2.hip (4-wave sweep) instead of coarse_corr.hip.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 OUT=$ROOT/build/variants; mkdir -p $OUT/obj_$NAME; rm -f $OUT/obj_$NAME/*.o
 CORR=coarse_corr
-case "$*" in *FM_CORR_V2*) CORR=coarse_corr2;; esac
 for f in api coarse_prep $CORR coarse_select fine; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$ROOT/featurematching_amd/csrc "$@" \
     -c $ROOT/featurematching_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &

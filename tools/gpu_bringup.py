@@ -60,15 +60,15 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     # planes
     cp = lay["C"]                       # padded channel count of the planes
 
-    def unfrag(a):                      # image-0 planes are fragment-major: [rowblock][ks][h][r][8]
+    def unfrag(a, rows_pad):            # planes are fragment-major: [rowblock][ks][h][r][8]
         ksteps = cp // 16
-        a = a.reshape(n * Lp // 32, ksteps, 2, 32, 8).transpose(0, 3, 2, 1, 4)      # rb, r, h, ks, e
-        return a.reshape(n, Lp, cp)[:, :, :c]
+        a = a.reshape(n * rows_pad // 32, ksteps, 2, 32, 8).transpose(0, 3, 2, 1, 4)      # rb, r, h, ks, e
+        return a.reshape(n, rows_pad, cp)[:, :, :c]
 
-    hi0 = unfrag(view(ws, base, lay["hi0"], n * Lp * cp, torch.float16))
-    lo0 = unfrag(view(ws, base, lay["lo0"], n * Lp * cp, torch.float16))
-    hi1 = view(ws, base, lay["hi1"], n * Sp * c, torch.float16).reshape(n, Sp, c)
-    lo1 = view(ws, base, lay["lo1"], n * Sp * c, torch.float16).reshape(n, Sp, c)
+    hi0 = unfrag(view(ws, base, lay["hi0"], n * Lp * cp, torch.float16), Lp)
+    lo0 = unfrag(view(ws, base, lay["lo0"], n * Lp * cp, torch.float16), Lp)
+    hi1 = unfrag(view(ws, base, lay["hi1"], n * Sp * cp, torch.float16), Sp)
+    lo1 = unfrag(view(ws, base, lay["lo1"], n * Sp * cp, torch.float16), Sp)
     e_hi = np.abs(hi0[:, :l].astype(np.float32) - f0.astype(np.float16).astype(np.float32)).max()
     rec = np.abs(hi0[:, :l].astype(np.float64) + lo0[:, :l].astype(np.float64) - f0).max()
     rec1 = np.abs(hi1[:, :s].astype(np.float64) + lo1[:, :s].astype(np.float64) - f1).max()
