@@ -101,6 +101,10 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   constexpr int PLANES = MODE ? 2 : 1;
   constexpr int PLANE_BYTES = kTileCols * ROWB;
   constexpr int BUF_BYTES = PLANES * PLANE_BYTES;
+  // LDS tile ring: the max pass needs only the hi plane (32 KiB per tile at C = 256), so it keeps 3 tiles
+  // in flight; the other passes (hi + lo) double-buffer.
+  constexpr int NBUF = MODE ? 2 : 4;
+  constexpr int GLDS_PER_TILE = PLANES * (PLANE_BYTES / 1024 / 8);     // LDS-DMA instructions per wave and tile
   constexpr int INSTR_PER_WAVE = PLANE_BYTES / 1024 / 8;
   constexpr bool SPARSE = (MODE == 1 || MODE == 2);
   constexpr int META = 80;          // per tile: 64 column stabilisers + 16 unit maxima (8 waves x 2 units)
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
   const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};   // fragment-major
-  float* nmr_lds = reinterpret_cast<float*>(smem + 2 * BUF_BYTES) + wv * 32;
-  float* meta = reinterpret_cast<float*>(smem + 2 * BUF_BYTES + 1024);       // [2][META]
+  float* nmr_lds = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES) + wv * 32;
+  float* meta = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES + 1024);    // [2][META]
 
   // One LDS-DMA instruction copies one 1 KiB fragment block (32 columns x one k-step x one lane half
   // pair) of the fragment-major planes: contiguous in global memory and in LDS.  Tile image in LDS:
@@ -150,7 +154,10 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   auto meta_store = [&](int buf, float v) { if (MODE && tid < META) meta[buf * META + tid] = v; };
 
   float mv = 0.f;
-  if (t0 < t1) { stage(t0, 0); mv = meta_load(t0); }
+  if (t0 < t1) mv = meta_load(t0);
+#pragma unroll
+  for (int d = 0; d < NBUF - 1; ++d)
+    if (t0 + d < t1) stage(t0 + d, d);
 
   // ---- this wave's 32 rows as A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7) ----
   // fragment-major planes (k_prep_split): one contiguous 1 KiB block per (32-row block, k-step);
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   // more conservative if the compiler has LDS/SMEM operations of its own in flight.
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto mfma_unit = [&](int u) {
-    const unsigned base = lds0 + (((u >> 1) - t0) & 1) * BUF_BYTES + (u & 1) * (KSTEPS * 1024) + lane * 16;
+    const unsigned base = lds0 + (((u >> 1) - t0) % NBUF) * BUF_BYTES + (u & 1) * (KSTEPS * 1024) + lane * 16;
     constexpr int PF = MODE ? FM_PF_SUM : FM_PF_MAX;
     constexpr int RING = PF + 1;
     constexpr int RPK = MODE ? 2 : 1;       // LDS reads per k-step
@@ -333,7 +340,19 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   };
 
   meta_store(0, mv);
-  __syncthreads();          // first tile and its metadata landed
+  // Tile hand-over: LDS-DMA writes are ordered for other waves' reads only by the issuing wave's vmcnt
+  // followed by a barrier.  A counted vmcnt leaves the younger tiles of the ring in flight across the
+  // barrier (`__syncthreads()` would drain them: hipcc emits vmcnt(0) in front of it); VMEM returns in
+  // order, so 'at most K outstanding' with K = instructions issued for the tiles after the wanted one
+  // means the wanted tile has landed (stores in flight only make the wait more conservative).
+  auto tile_barrier = [&](int tiles_after) {
+    if (tiles_after <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (tiles_after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(GLDS_PER_TILE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * GLDS_PER_TILE) : "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  static_assert(NBUF <= 4 && 2 * GLDS_PER_TILE <= 63, "tile_barrier covers at most two tiles in flight");
+  tile_barrier(min(NBUF - 2, t1 - t0 - 1));     // first tile and its metadata landed
 
   // Waves w and w+4 share a SIMD.  The second half of the workgroup runs one epilogue behind the
   // first, so that on every SIMD one wave's exp/add epilogue overlaps the other's MFMA chain.
@@ -342,7 +361,13 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   float nmc_pend = 0.f;
   for (int u = 2 * t0; u < 2 * t1; ++u) {
     const int t = u >> 1, par = (t - t0) & 1;
-    if ((u & 1) == 0 && t + 1 < t1) { stage(t + 1, par ^ 1); mv = meta_load(t + 1); }
+    if ((u & 1) == 0) {
+      // refill the ring slot of tile t-1 (all waves left it at the previous barrier)
+#ifndef FM_ABL_NOSTAGE   // timing-only ablations (results are wrong): never defined in the shipped build
+      if (t + NBUF - 1 < t1) stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF);
+#endif
+      if (t + 1 < t1) mv = meta_load(t + 1);
+    }
 
     const float nmc_u = MODE ? meta[par * META + (u & 1) * 32 + r] : 0.f;
     bool skip = false;
@@ -355,14 +380,21 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     if (late && pend >= 0) { epilogue(pend, nmc_pend); pend = -1; }
     if (!skip) {
       mfma_unit(u);
+#ifdef FM_ABL_NOEPI
+      asm volatile("" :: "v"(acc));
+#else
       if (late) { pend = u; nmc_pend = nmc_u; }
       else epilogue(u, nmc_u);
+#endif
     } else if (MODE == 1 && h == 0) {
       colout[t * kTileCols + (u & 1) * 32 + r] = 0.f;               // skipped unit: contributes nothing
     }
     if (u & 1) {
       if (t + 1 < t1) meta_store(par ^ 1, mv);
-      __syncthreads();      // tile consumed by every wave; next tile landed (LDS-DMA drained)
+      // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
+#ifndef FM_ABL_NOBAR
+      tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1));
+#endif
     }
   }
   if (late && pend >= 0) epilogue(pend, nmc_pend);
@@ -389,7 +421,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 template <int C, int MODE>
 static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
   constexpr int BUF_BYTES = (MODE ? 2 : 1) * kTileCols * C * 2;
-  constexpr int SMEM = 2 * BUF_BYTES + 8 * 32 * 4 + 2 * 80 * 4;
+  constexpr int SMEM = (MODE ? 2 : 4) * BUF_BYTES + 8 * 32 * 4 + 2 * 80 * 4;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr<C, MODE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   if (e != hipSuccess) return e;
