@@ -59,14 +59,18 @@ class Pair:
         self.win0 = torch.empty(self.cap, window * window, wl["cf"], device=dev)
         self.win1 = torch.empty_like(self.win0)
         self.last = None
+        self.tiled = os.environ.get("FM_TILED_GATHER", "0") == "1"
 
     def step(self):
         """Enqueue the whole path; nothing synchronises the host (the match count stays on the
         device and the window/fine kernels read it there)."""
         w = self.window
         buf = ops.coarse_match_async(self.f0, self.f1, self.hw_c, self.hw_c, self.hw_i[0] / self.hw_c[0], cap=self.cap)
-        ops.gather_windows(self.ff0, buf.b_ids, buf.i_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win0)
-        ops.gather_windows(self.ff1, buf.b_ids, buf.j_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win1)
+        cells0, cells1 = buf.cell_maps() if self.tiled else (None, None)
+        ops.gather_windows(self.ff0, buf.b_ids, buf.i_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win0,
+                           cells=cells0, h_c=self.hw_c[0])
+        ops.gather_windows(self.ff1, buf.b_ids, buf.j_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win1,
+                           cells=cells1, h_c=self.hw_c[0])
         k0, k1 = ops.fine_match(self.win0, self.win1, self.mix0, self.mix1, buf.mkpts0_c, buf.mkpts1_c,
                                 self.hw_i[0] / self.hw_f[0], count=buf.count)
         self.last = (buf, k0, k1)

@@ -422,8 +422,8 @@ template <int C, int MODE>
 static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
   constexpr int BUF_BYTES = (MODE ? 2 : 1) * kTileCols * C * 2;
   constexpr int SMEM = (MODE ? 2 : 4) * BUF_BYTES + 8 * 32 * 4 + 2 * 80 * 4;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr<C, MODE>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  static unsigned long long lds_set = 0;      // one flag word per template instance
+  hipError_t e = ensure_dynamic_lds(&k_corr<C, MODE>, SMEM, &lds_set);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_corr<C, MODE>), dim3(blocks), dim3(512), SMEM, st, a);
   return hipGetLastError();

@@ -23,6 +23,7 @@ struct SelArgs {
   const float* scale0; const float* scale1;
   int64_t* b_ids; int64_t* i_ids; int64_t* j_ids; float* k0; float* k1; float* mconf;
   int cap; int32_t* d_count;
+  int* cell0; int* cell1;     // cell -> match index + 1 (for the cell-tiled window gather)
 };
 
 // one thread per (row, slot); a row's `slots` threads are adjacent lanes of one wave
@@ -138,6 +139,8 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
   const int i = (int)(grow - (long)b * a.Lp);
   const int j = a.keep_j[grow * a.slots + slot];
   a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = j;
+  a.cell0[grow] = (int)o + 1;                         // exact ties: any of the tied matches may win the cell;
+  a.cell1[(long)b * a.Sp + j] = (int)o + 1;           // the gather picks the others up as left-overs
   a.mconf[o] = a.keep_conf[grow * a.slots + slot];
   // coarse_matching_new.py:126-134: (x, y) = (id % w, id // w) * scale [* scale{0,1}[b]]
   float s0x = a.scale_px, s0y = a.scale_px, s1x = a.scale_px, s1y = a.scale_px;
@@ -167,6 +170,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, cons
   a.k = inv_ct * kLog2e; a.thr = thr; a.scale_px = scale_px; a.scale0 = scale0; a.scale1 = scale1;
   a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.k0 = k0; a.k1 = k1; a.mconf = mconf;
   a.cap = cap; a.d_count = d_count;
+  a.cell0 = (int*)(base + w.cell0); a.cell1 = (int*)(base + w.cell1);
   const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
   hipLaunchKernelGGL(k_cand_conf, dim3(blocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_cand_keep, dim3(blocks), dim3(256), 0, st, a);

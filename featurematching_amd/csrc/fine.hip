@@ -64,6 +64,133 @@ __global__ __launch_bounds__(256) void k_gather_nchw64(const float* __restrict__
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// k_gather_cells64<W>: cell-tiled crop.  One workgroup = 8 adjacent coarse cells of one coarse row.
+// The strip of the fine map under those 8 windows (W rows x 28+W columns x 64 channels) is read ONCE
+// in runs of ~34 floats (two cache lines per (channel,row) instead of one line per 20-byte run and
+// window: 3x less fabric traffic than the per-window kernel), transposed through LDS, and the windows
+// of the cells that are matched (cell -> match map from the coarse stage, 0 = unmatched) are written
+// as contiguous records.  Matches that lost their cell to an exactly tied match are picked up at the
+// end from this workgroup's slice of the match list with the per-window path.
+// ----------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_gather_cells64(const float* __restrict__ feat, int N, int Hf, int Wf, int h_c,
+                                                        int w_c, const int32_t* __restrict__ cell_to_match,
+                                                        int cell_pitch, const int64_t* __restrict__ b_ids,
+                                                        const int64_t* __restrict__ ids,
+                                                        const int32_t* __restrict__ d_count, int m_max,
+                                                        float* __restrict__ out) {
+  constexpr int CF = 64, G = 8, STRIDE = 4, PAD = 2, WW = W * W, TOTAL = CF * WW;
+  constexpr int SPAN = (G - 1) * STRIDE + W;        // fine columns under the 8 windows
+  constexpr int NX2 = (SPAN + 1) / 2;               // loaded as float2 (the strip starts at an even column)
+  constexpr int SPANP = 2 * NX2;
+  constexpr int PITCH = CF + 1;
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [W][SPANP][PITCH]
+  __shared__ int mids[G];
+  __shared__ int left[32];
+  __shared__ int nleft;
+  const int tid = threadIdx.x;
+  const int M = d_count ? min(d_count[0], m_max) : m_max;
+  const int groups = (w_c + G - 1) / G;
+  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int gx = bid % groups;
+  const int cy = (bid / groups) % h_c;
+  const int b = bid / (groups * h_c);
+  if (tid < G) {
+    const int x = gx * G + tid;
+    int m = -1;
+    if (x < w_c) m = cell_to_match[(long)b * cell_pitch + cy * w_c + x] - 1;
+    mids[tid] = (m < M) ? m : -1;
+  }
+  if (tid == 0) nleft = 0;
+  __syncthreads();
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < G; ++k) any = any || (mids[k] >= 0);
+  if (any) {
+    const int oy = cy * STRIDE - PAD, ox = gx * G * STRIDE - PAD;
+    const float* src = feat + (long)b * CF * Hf * Wf;
+    const bool even = (Wf & 1) == 0;
+    // all loads of a thread are issued before the first LDS write (compile-time trip count, fully
+    // unrolled): one round trip to L2/HBM per workgroup instead of one per loop iteration
+    constexpr int NLOAD = (CF * W * NX2 + 255) / 256;
+    float2 v[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = it * 256 + tid;
+      const int xq = idx % NX2;
+      const int cw = idx / NX2;
+      const int wy = cw % W, c = cw / W;
+      const int y = oy + wy, x = ox + 2 * xq;
+      v[it] = make_float2(0.f, 0.f);
+      if (idx < CF * W * NX2 && y >= 0 && y < Hf) {
+        const float* row = src + ((long)c * Hf + y) * Wf;
+        if (even && x >= 0 && x + 1 < Wf) v[it] = *reinterpret_cast<const float2*>(row + x);
+        else {
+          if (x >= 0 && x < Wf) v[it].x = row[x];
+          if (x + 1 >= 0 && x + 1 < Wf) v[it].y = row[x + 1];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = it * 256 + tid;
+      if (idx < CF * W * NX2) {
+        const int xq = idx % NX2;
+        const int cw = idx / NX2;
+        const int wy = cw % W, c = cw / W;
+        tile[(wy * SPANP + 2 * xq) * PITCH + c] = v[it].x;
+        tile[(wy * SPANP + 2 * xq + 1) * PITCH + c] = v[it].y;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < G; ++k) {
+      const int m = mids[k];
+      if (m < 0) continue;
+      float* dst = out + (long)m * TOTAL;
+#pragma unroll
+      for (int it = 0; it < (TOTAL + 255) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < TOTAL) {
+          const int rpos = idx >> 6, c = idx & 63;
+          const int wy = rpos / W, wx = rpos - wy * W;
+          dst[idx] = tile[(wy * SPANP + k * STRIDE + wx) * PITCH + c];
+        }
+      }
+    }
+  }
+  // ---- left-overs of this workgroup's slice of the match list (exact ties only) ----
+  const int chunk = (M + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int m0 = blockIdx.x * chunk;
+  if (tid < chunk && tid < 32 && m0 + tid < M) {
+    const int m = m0 + tid;
+    const int mb = (int)b_ids[m], id = (int)ids[m];
+    if (cell_to_match[(long)mb * cell_pitch + id] != m + 1) left[atomicAdd(&nleft, 1)] = m;
+  }
+  __syncthreads();
+  const int nl = nleft;
+  for (int q = 0; q < nl; ++q) {          // rare
+    __syncthreads();
+    const int m = left[q];
+    const int mb = (int)b_ids[m], id = (int)ids[m];
+    const int ccy = id / w_c;
+    const int oy = ccy * STRIDE - PAD, ox = (id - ccy * w_c) * STRIDE - PAD;
+    const float* src = feat + (long)mb * CF * Hf * Wf;
+    for (int idx = tid; idx < TOTAL; idx += 256) {
+      const int c = idx / WW, rem = idx - c * WW;
+      const int wy = rem / W, wx = rem - wy * W;
+      const int y = oy + wy, x = ox + wx;
+      float v = 0.f;
+      if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)c * Hf + y) * Wf + x];
+      tile[rem * PITCH + c] = v;
+    }
+    __syncthreads();
+    float* dst = out + (long)m * TOTAL;
+    for (int idx = tid; idx < TOTAL; idx += 256) dst[idx] = tile[(idx >> 6) * PITCH + (idx & 63)];
+  }
+}
+
 // generic fallback (any Cf / W): one workgroup per window, transposed through LDS
 __global__ __launch_bounds__(256) void k_gather_nchw(const float* __restrict__ feat, int Cf, int Hf, int Wf, int W,
                                                      int stride, int pad, int w_c, const int64_t* __restrict__ b_ids,
@@ -302,6 +429,37 @@ extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int
   } else {
     hipLaunchKernelGGL(k_gather_nhwc, dim3(m_max), dim3(256), 0, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c, b_ids,
                        ids, d_count, m_max, out);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int Hf, int Wf, int W, int stride, int pad,
+                                       int h_c, int w_c, const int32_t* cell_to_match, int cell_pitch,
+                                       const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max,
+                                       float* out, void* stream) {
+  if (m_max == 0) return FM_OK;
+  if (!feat_f || !cell_to_match || !b_ids || !ids || !out) return FM_E_NULL;
+  if (N <= 0 || Hf <= 0 || Wf <= 0 || h_c <= 0 || w_c <= 0 || m_max < 0 || cell_pitch < h_c * w_c) return FM_E_SHAPE;
+  if (Cf != 64 || (W != 5 && W != 7) || stride != 4 || pad != 2) return FM_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = (w_c + 7) / 8;
+  const int blocks = N * h_c * groups;
+  if (m_max > 32L * blocks) return FM_E_UNSUPPORTED;      // left-over slices hold at most 32 matches each
+  const int span = 7 * 4 + W;
+  const size_t smem = (size_t)W * (2 * ((span + 1) / 2)) * 65 * sizeof(float);
+  hipError_t e;
+  if (W == 5) {
+    static unsigned long long lds_set5 = 0;
+    e = ensure_dynamic_lds(&k_gather_cells64<5>, (int)smem, &lds_set5);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_gather_cells64<5>, dim3(blocks), dim3(256), smem, st, feat_f, N, Hf, Wf, h_c, w_c, cell_to_match,
+                       cell_pitch, b_ids, ids, d_count, m_max, out);
+  } else {
+    static unsigned long long lds_set7 = 0;
+    e = ensure_dynamic_lds(&k_gather_cells64<7>, (int)smem, &lds_set7);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_gather_cells64<7>, dim3(blocks), dim3(256), smem, st, feat_f, N, Hf, Wf, h_c, w_c, cell_to_match,
+                       cell_pitch, b_ids, ids, d_count, m_max, out);
   }
   return (int)hipGetLastError();
 }

@@ -27,6 +27,7 @@ struct CoarseWs {
   int N, L, S, C, Lp, Sp, panels, tiles, splits, slots;
   // zeroed on every call (contiguous, starts at the base)
   size_t zero_begin, cand_count, colbest, blocktot, scalars, zero_end;
+  size_t cell0, cell1;                        // (zeroed) match index + 1 of every image-0 / image-1 cell
   // float16 planes
   size_t hi0, lo0, hi1, lo1;
   // per-row / per-column statistics
@@ -63,5 +64,19 @@ hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, cons
                          int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* k0, float* k1,
                          float* mconf, int cap, int32_t* d_count, hipStream_t st);
 hipError_t launch_conf_dense(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
+
+// Raises a kernel's dynamic-LDS limit once per (kernel, device) instead of on every launch: the
+// attribute call costs tens of host microseconds, which an eager (non-graph) caller would pay per step.
+template <typename K>
+inline hipError_t ensure_dynamic_lds(K kernel, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+  return e;
+}
 
 }  // namespace fm

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -64,6 +65,8 @@ class CoarseMatching(nn.Module):
             w0c, w1c = data['hw0_c'][1], data['hw1_c'][1]
             mkpts0_c = torch.stack([i_ids % w0c, torch.div(i_ids, w0c, rounding_mode='floor')], dim=1) * scale0
             mkpts1_c = torch.stack([j_ids % w1c, torch.div(j_ids, w1c, rounding_mode='floor')], dim=1) * scale1
+        if not self.training:     # cell -> match maps for the (opt-in) cell-tiled window crop of FinePreprocess
+            data['_fm_coarse'] = out['_coarse_buffers']
         data.update({'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids,
                      'gt_mask': mconf == 0, 'm_bids': b_ids,
                      'mkpts0_c': mkpts0_c, 'mkpts1_c': mkpts1_c, 'mconf': mconf})
@@ -98,9 +101,17 @@ class FinePreprocess(nn.Module):
             feat1 = torch.empty(0, W ** 2, self.d_model_f, device=feat_f0.device)
             return feat0, feat1
         # windows of the matched cells only (the reference unfolds all L cells, then selects)
+        # The per-window kernel is the default: at 640x480 the fine map stays in L2/MALL and it measured
+        # faster (profiles/README.md); FM_TILED_GATHER=1 selects the cell-tiled kernel instead.
+        cells0 = cells1 = None
+        buf = data.get('_fm_coarse') if os.environ.get("FM_TILED_GATHER", "0") == "1" else None
+        if buf is not None and buf.b_ids.data_ptr() == b_ids.data_ptr():     # ids are this coarse call's
+            cells0, cells1 = buf.cell_maps()
         with torch.no_grad():
-            win0 = ops.gather_windows(feat_f0, b_ids, i_ids, W, stride, data['hw0_c'][1])
-            win1 = ops.gather_windows(feat_f1, b_ids, j_ids, W, stride, data['hw1_c'][1])
+            win0 = ops.gather_windows(feat_f0, b_ids, i_ids, W, stride, data['hw0_c'][1], cells=cells0,
+                                      h_c=data['hw0_c'][0])
+            win1 = ops.gather_windows(feat_f1, b_ids, j_ids, W, stride, data['hw1_c'][1], cells=cells1,
+                                      h_c=data['hw1_c'][0])
         if self.cat_c_feat:
             feat_c_win = self.down_proj(torch.cat([feat_c0[b_ids, i_ids], feat_c1[b_ids, j_ids]], 0))
             feat_cf_win = self.merge_feat(torch.cat([

@@ -56,6 +56,19 @@ class CoarseBuffers:
             raise err
         return int(m.value)
 
+    def cell_maps(self):
+        """((ptr0, pitch0), (ptr1, pitch1)): device addresses of the cell -> match-index+1 maps of image 0
+        and image 1 inside the workspace (valid while this object is alive); feed them to
+        gather_windows(cells=...) for the cell-tiled crop."""
+        lib = _lib.load()
+        n, l, s, c, slots = self._shape
+        p0, p1 = C.c_void_p(), C.c_void_p()
+        q0, q1 = C.c_int(), C.c_int()
+        base = self.workspace.data_ptr() + ((-self.workspace.data_ptr()) % 256)
+        _lib.check(lib.fm_coarse_cell_maps(C.c_void_p(base), n, l, s, c, slots, C.byref(p0), C.byref(q0),
+                                           C.byref(p1), C.byref(q1)), "fm_coarse_cell_maps")
+        return (p0.value, q0.value), (p1.value, q1.value)
+
     def sliced(self, m: int) -> dict:
         return dict(b_ids=self.b_ids[:m], i_ids=self.i_ids[:m], j_ids=self.j_ids[:m],
                     mkpts0_c=self.mkpts0_c[:m], mkpts1_c=self.mkpts1_c[:m], mconf=self.mconf[:m])
@@ -102,6 +115,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                              _stream(dev))
     _lib.check(st, "fm_coarse_match")
     out._keep = (f0, f1, sc0, sc1)   # inputs must outlive the enqueued kernels
+    out._shape = (n, l, s, c, cand_slots)
     return out
 
 
@@ -127,15 +141,18 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
         out = buf.sliced(m)
         if conf_matrix:
             out['conf_matrix'] = buf.conf_matrix
+        out['_coarse_buffers'] = buf          # keeps the workspace (and its cell maps) alive
         return out
     raise RuntimeError("coarse_match: overflow persisted after retries")
 
 
 def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor, w: int, stride: int,
                    w_c: int, pad: int = 2, count: Optional[torch.Tensor] = None,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, cells=None, h_c: Optional[int] = None) -> torch.Tensor:
     """Window crop (fine_preprocess.py:43-50) of the selected coarse cells only.
-    feat_f is the logical [N,Cf,Hf,Wf] tensor, stored NCHW-contiguous or channels_last."""
+    feat_f is the logical [N,Cf,Hf,Wf] tensor, stored NCHW-contiguous or channels_last.
+    cells = (device address, pitch) of this image's cell -> match map (CoarseBuffers.cell_maps())
+    selects the cell-tiled kernel when the shape allows it (NCHW, Cf 64, W 5/7, stride 4)."""
     lib = _lib.load()
     if not feat_f.is_cuda:
         raise RuntimeError("feat_f must live on the GPU: the HIP path has no CPU fallback")
@@ -153,6 +170,13 @@ def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor,
         out = torch.empty(m_max, w * w, cf, dtype=torch.float32, device=feat_f.device)
     if m_max == 0:
         return out
+    if cells is not None and layout == 0 and cf == 64 and w in (5, 7) and stride == 4 and pad == 2 and h_c:
+        st = lib.fm_gather_windows_cells(_ptr(feat_f), n, cf, hf, wf, w, stride, pad, int(h_c), int(w_c),
+                                         C.c_void_p(cells[0]), int(cells[1]), _ptr(b_ids), _ptr(ids), _ptr(count),
+                                         m_max, _ptr(out), _stream(feat_f.device))
+        if st != -3:                       # FM_E_UNSUPPORTED: fall through to the per-window kernel
+            _lib.check(st, "fm_gather_windows_cells")
+            return out
     st = lib.fm_gather_windows(_ptr(feat_f), n, cf, hf, wf, layout, w, stride, pad, w_c, _ptr(b_ids), _ptr(ids),
                                _ptr(count), m_max, _ptr(out), _stream(feat_f.device))
     _lib.check(st, "fm_gather_windows")

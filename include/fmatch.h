@@ -115,6 +115,21 @@ int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int la
                       const int32_t* d_count, int m_max, float* out, void* stream);
 
 /*
+ * Faster variant of the window crop for NCHW maps with Cf = 64, W in {5,7}, stride 4, pad 2: workgroups
+ * walk the coarse grid (h_c x w_c cells per sample) in strips of 8 cells, read the fine-map strip once
+ * and emit the windows of the matched cells.  cell_to_match [N, cell_pitch] int32 holds match index + 1
+ * per cell of THIS image (0 = unmatched): fm_coarse_cell_maps returns the two maps the coarse stage keeps
+ * in its workspace (valid until the workspace is reused).  Same outputs as fm_gather_windows.
+ * FM_E_UNSUPPORTED when the shape is outside the fast path: call fm_gather_windows instead.
+ */
+int fm_coarse_cell_maps(void* workspace, int N, int L, int S, int C, int cand_slots,
+                        int32_t** cell0, int* pitch0, int32_t** cell1, int* pitch1);
+int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int Hf, int Wf, int W, int stride, int pad,
+                            int h_c, int w_c, const int32_t* cell_to_match, int cell_pitch,
+                            const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max,
+                            float* out, void* stream);
+
+/*
  * Fine stage (fine_matching_new.py:50-79): dual-direction window correlation,
  * softmax heat-map, spatial expectation, std.  win0/win1 [m_max, WW, Cf];
  * mix0/mix1 [dev] float32 [WW+1] = Linear(WW,1) weight then bias;

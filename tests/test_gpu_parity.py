@@ -25,7 +25,7 @@ DEV = "cuda:0"
 
 
 def _np(d):
-    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.items()}
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.items() if not k.startswith('_')}
 
 
 def _assert_coarse(got, ref, thr=0.2):
@@ -310,3 +310,26 @@ def test_dense_conf_matrix_and_training_ids():
     assert data['mconf'].shape[0] == ref['mconf'].shape[0]
     with pytest.raises(RuntimeError):
         modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1}).train()(t0, t1, dict(data))
+
+
+# ------------------------------------------------------------------ cell-tiled window crop
+@pytest.mark.parametrize("w", [5, 7])
+def test_cell_tiled_gather_equals_per_window_gather(w):
+    """Same windows from the cell-tiled kernel (incl. map borders, unmatched cells, a row that is not
+    a multiple of 8 cells wide, and an exact tie whose second match is a left-over)."""
+    hc, wc = 11, 13
+    f0, f1 = synth.coarse_descriptors(71, 2, hc * wc, 64, "peaky")
+    f1[0, 40] = f1[0, 41] = f0[0, 30] + 0.4 * synth.normal(71, 9, (64,))      # tie: cell 30 -> cells 40 and 41
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    buf = ops.coarse_match_async(t0, t1, (hc, wc), (hc, wc), 8.0, border_rm=0)
+    m = buf.read_count()
+    o = buf.sliced(m)
+    assert m > 150 and len(set(o['i_ids'].tolist())) < m                      # the tie is there
+    ff0, ff1 = synth.fine_maps(71, 2, 64, hc * 4, wc * 4)
+    c0, c1 = buf.cell_maps()
+    for ff, ids, cells in ((ff0, o['i_ids'], c0), (ff1, o['j_ids'], c1)):
+        t = torch.as_tensor(ff, device=DEV)
+        ref = ops.gather_windows(t, o['b_ids'], ids, w, 4, wc)
+        got = ops.gather_windows(t, o['b_ids'], ids, w, 4, wc, cells=cells, h_c=hc)
+        assert torch.equal(got, ref)
+        assert torch.equal(ref.cpu(), orc.crop_windows(ff, o['b_ids'].cpu(), ids.cpu(), w, 4, wc))
