@@ -60,12 +60,20 @@ class Pair:
         self.win1 = torch.empty_like(self.win0)
         self.last = None
         self.tiled = os.environ.get("FM_TILED_GATHER", "0") == "1"
+        self.stages = "all"      # diagnostic only (--stages): "coarse" or "fine" time a part of the step
 
     def step(self):
         """Enqueue the whole path; nothing synchronises the host (the match count stays on the
         device and the window/fine kernels read it there)."""
         w = self.window
-        buf = ops.coarse_match_async(self.f0, self.f1, self.hw_c, self.hw_c, self.hw_i[0] / self.hw_c[0], cap=self.cap)
+        if self.stages == "fine" and self.last is not None:
+            buf = self.last[0]
+        else:
+            buf = ops.coarse_match_async(self.f0, self.f1, self.hw_c, self.hw_c, self.hw_i[0] / self.hw_c[0],
+                                         cap=self.cap)
+        if self.stages == "coarse" and self.last is not None:
+            self.last = (buf,) + self.last[1:]
+            return self.last
         cells0, cells1 = buf.cell_maps() if self.tiled else (None, None)
         ops.gather_windows(self.ff0, buf.b_ids, buf.i_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win0,
                            cells=cells0, h_c=self.hw_c[0])
@@ -151,6 +159,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are spread over")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--stages", default="all", choices=["all", "coarse", "fine"],
+                    help="diagnostic: time only a part of the step (the JSON line is then not the metric)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +194,8 @@ def main():
         with torch.cuda.stream(streams[i % nstreams]):
             p.step()
     torch.cuda.synchronize()
+    for p in pairs:
+        p.stages = a.stages
     if not a.no_graph:
         for i, p in enumerate(pairs):
             g = torch.cuda.CUDAGraph()
@@ -222,6 +234,7 @@ def main():
 
         t_a = t_b = None
         if rank == 0:
+            pairs[0].stages = "all"
             pairs[0].step()
             torch.cuda.synchronize()
             t_a = time_corr_kernel(pairs[0], 0)
@@ -241,8 +254,9 @@ def main():
     flops = 2.0 * wl["n"] * pairs[0].l * pairs[0].l * wl["c"]          # one GEMM per pair
     ach_b = flops / (t_b * 1e-3) / 1e12
     out = {
-        "metric": "image-pairs/sec at 640x480 (coarse corr + dual-softmax mutual-NN + fine window refinement)"
-                  if a.workload == "cfg2" else f"image-pairs/sec ({a.workload})",
+        "metric": ("image-pairs/sec at 640x480 (coarse corr + dual-softmax mutual-NN + fine window refinement)"
+                   if a.workload == "cfg2" else f"image-pairs/sec ({a.workload})")
+                  + ("" if a.stages == "all" else f" [DIAGNOSTIC: {a.stages} stage only]"),
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16 hi+lo split operands, f32 accumulate (f32-equivalent product)",

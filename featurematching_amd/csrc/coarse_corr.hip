@@ -359,7 +359,12 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const bool late = wv >= 4;
   int pend = -1;            // late waves: unit whose epilogue is still owed (its accumulator is live)
   float nmc_pend = 0.f;
+#ifdef FM_ABL_NOTILES     // timing-only: prologue + final reduction, no sweep
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int u = 2 * t0; u < 2 * t0; ++u) {
+#else
   for (int u = 2 * t0; u < 2 * t1; ++u) {
+#endif
     const int t = u >> 1, par = (t - t0) & 1;
     if ((u & 1) == 0) {
       // refill the ring slot of tile t-1 (all waves left it at the previous barrier)
@@ -377,6 +382,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       const float cmax = wave_max64(t * kTileCols + (u & 1) * 32 + r < a.S ? nmc_u : -INFINITY);
       skip = __builtin_amdgcn_readfirstlane((int)((top + wmax_nmr < -kSkipLog2) && (top + cmax < -kSkipLog2)));
     }
+#ifdef FM_ABL_ALLSKIP     // timing-only: tile streaming and barriers, no unit work
+    skip = true;
+#endif
     if (late && pend >= 0) { epilogue(pend, nmc_pend); pend = -1; }
     if (!skip) {
       mfma_unit(u);
