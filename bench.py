@@ -59,7 +59,7 @@ class Pair:
         self.win0 = torch.empty(self.cap, window * window, wl["cf"], device=dev)
         self.win1 = torch.empty_like(self.win0)
         self.last = None
-        self.tiled = os.environ.get("FM_TILED_GATHER", "0") == "1"
+        self.gather = os.environ.get("FM_GATHER", "cells")      # cells | list (see ops.gather_windows)
         self.stages = "all"      # diagnostic only (--stages): "coarse" or "fine" time a part of the step
 
     def step(self):
@@ -74,7 +74,7 @@ class Pair:
         if self.stages == "coarse" and self.last is not None:
             self.last = (buf,) + self.last[1:]
             return self.last
-        cells0, cells1 = buf.cell_maps() if self.tiled else (None, None)
+        cells0, cells1 = buf.cell_maps() if self.gather != "list" else (None, None)
         ops.gather_windows(self.ff0, buf.b_ids, buf.i_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win0,
                            cells=cells0, h_c=self.hw_c[0])
         ops.gather_windows(self.ff1, buf.b_ids, buf.j_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win1,

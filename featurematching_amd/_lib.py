@@ -37,8 +37,9 @@ SIGNATURES = {
     "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "fm_read_count": (_i, [_p, _i, C.POINTER(C.c_int32), _p]),
     "fm_gather_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
-    "fm_coarse_cell_maps": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_p), C.POINTER(_i)]),
-    "fm_gather_windows_cells": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p]),
+    "fm_coarse_cell_maps": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_p),
+                                 C.POINTER(_p), C.POINTER(_i), C.POINTER(_p)]),
+    "fm_gather_windows_cells": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p]),
     "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
 }
 

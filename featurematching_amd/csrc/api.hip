@@ -37,6 +37,8 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.colbest = take(cols * 4);
   w.cell0 = take(rows * 4);
   w.cell1 = take(cols * 4);
+  w.ties0 = take((kTieCap + 1) * 4);
+  w.ties1 = take((kTieCap + 1) * 4);
   w.scalars = take(sizeof(Scalars));
   w.zero_end = o;
   w.blocktot = take(nblk * 4);
@@ -155,13 +157,13 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
 // Device pointers of the cell -> (match index + 1) maps the coarse stage leaves in its workspace
 // (0 = cell unmatched; pitch = padded cells per sample).  fm_gather_windows_cells consumes them.
 extern "C" int fm_coarse_cell_maps(void* workspace, int N, int L, int S, int C, int cand_slots, int32_t** cell0,
-                                   int* pitch0, int32_t** cell1, int* pitch1) {
-  if (!workspace || !cell0 || !cell1 || !pitch0 || !pitch1) return FM_E_NULL;
+                                   int* pitch0, int32_t** ties0, int32_t** cell1, int* pitch1, int32_t** ties1) {
+  if (!workspace || !cell0 || !cell1 || !pitch0 || !pitch1 || !ties0 || !ties1) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  *cell0 = (int32_t*)((char*)workspace + w.cell0); *pitch0 = w.Lp;
-  *cell1 = (int32_t*)((char*)workspace + w.cell1); *pitch1 = w.Sp;
+  *cell0 = (int32_t*)((char*)workspace + w.cell0); *pitch0 = w.Lp; *ties0 = (int32_t*)((char*)workspace + w.ties0);
+  *cell1 = (int32_t*)((char*)workspace + w.cell1); *pitch1 = w.Sp; *ties1 = (int32_t*)((char*)workspace + w.ties1);
   return FM_OK;
 }
 

@@ -52,6 +52,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FM_PF_MAX 4
 #endif
 constexpr float kSkipLog2 = 32.f;     // block-sparse threshold: entries below 2^-32 of every stabiliser
+constexpr int kCandQueue = 64;        // candidates a wave parks in LDS per sweep (one per lane at the hand-over)
 
 struct CorrArgs {
   const _Float16* hi0; const _Float16* lo0; const _Float16* hi1; const _Float16* lo1;
@@ -126,6 +127,14 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};   // fragment-major
   float* nmr_lds = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES) + wv * 32;
   float* meta = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES + 1024);    // [2][META]
+  // wave-private candidate queue (sum / screening passes): candidates found during the sweep are parked
+  // here and handed to the global per-row slot lists once, after the sweep.  (A global atomicAdd with
+  // return per find stalls the wave for a memory round trip in the middle of the MFMA pipeline: 10 us of
+  // a 43 us sweep at 640x480, where nearly every computed unit holds a match.)
+  int* qkey = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES + 1024 + 640) + wv * kCandQueue;   // (col << 5) | local row
+  float* qx = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES + 1024 + 640 + 8 * kCandQueue * 4) + wv * kCandQueue;
+  int* qcnt = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES + 1024 + 640 + 16 * kCandQueue * 4) + wv;
+  if (SPARSE && lane == 0) *qcnt = 0;
 
   // One LDS-DMA instruction copies one 1 KiB fragment block (32 columns x one k-step x one lane half
   // pair) of the fragment-major planes: contiguous in global memory and in LDS.  Tile image in LDS:
@@ -264,6 +273,12 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+  auto record_candidate = [&](long grow, int col, float x) {
+    const int pos = atomicAdd(&a.cand_count[grow], 1);
+    if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = col; a.cand_x[grow * a.slots + pos] = x; }
+    else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
+  };
+
   // epilogue of unit u: fold the accumulator into the row / column statistics
   auto epilogue = [&](int u, float nmc) {
     const int col = (u >> 1) * kTileCols + (u & 1) * 32 + r;     // this lane's column
@@ -318,20 +333,23 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         best = fmaxf(best, fminf(rr, cc));
       }
       if (MODE == 1) cstat += __shfl_xor(cstat, 32);
-      if (__any(best > a.lt)) {      // rare: some lane holds a candidate in this unit
-        int rbase = wrow0 + 4 * h;
-        asm volatile("" : "+v"(rbase));   // keep the 16 per-row addresses from being hoisted (and spilled)
+#ifdef FM_ABL_NOCAND            // timing-only: no candidate recording
+      if (false) {
+#else
+      if (__any(best > a.lt)) {      // some lane holds a candidate in this unit
+#endif
+        int rbase = 4 * h;
+        asm volatile("" : "+v"(rbase));   // keep the 16 per-row values from being hoisted (and spilled)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const float x = acc[g];
           const float rr = __builtin_fmaf(x, a.k, nmr[g]);
           const float cc = __builtin_fmaf(x, a.k, nmc);
-          const int row = rbase + (g & 3) + 8 * (g >> 2);
-          if (rr > a.lt && cc > a.lt && row < a.L && cvalid) {
-            const long grow = (long)b * a.Lp + row;
-            const int pos = atomicAdd(&a.cand_count[grow], 1);
-            if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = col; a.cand_x[grow * a.slots + pos] = x; }
-            else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
+          const int rl = rbase + (g & 3) + 8 * (g >> 2);          // row inside this wave's 32
+          if (rr > a.lt && cc > a.lt && wrow0 + rl < a.L && cvalid) {
+            const int q = atomicAdd(qcnt, 1);                     // LDS, wave-private
+            if (q < kCandQueue) { qkey[q] = (col << 5) | rl; qx[q] = x; }
+            else record_candidate((long)b * a.Lp + wrow0 + rl, col, x);     // queue full: straight to the lists
           }
         }
       }
@@ -407,6 +425,15 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   }
   if (late && pend >= 0) epilogue(pend, nmc_pend);
 
+  if (SPARSE) {      // hand the parked candidates to the per-row slot lists: one entry per lane, one round trip
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int nq = min(*qcnt, kCandQueue);
+    if (lane < nq) {
+      const int key = qkey[lane];
+      record_candidate((long)b * a.Lp + wrow0 + (key & 31), key >> 5, qx[lane]);
+    }
+  }
   if (MODE >= 2) return;
   // ---- row statistics of this workgroup's column range: reduce over the 32 lanes of each half ----
 #pragma unroll
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 template <int C, int MODE>
 static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
   constexpr int BUF_BYTES = (MODE ? 2 : 1) * kTileCols * C * 2;
-  constexpr int SMEM = (MODE ? 2 : 4) * BUF_BYTES + 8 * 32 * 4 + 2 * 80 * 4;
+  constexpr int SMEM = (MODE ? 2 : 4) * BUF_BYTES + 8 * 32 * 4 + 2 * 80 * 4 + 16 * kCandQueue * 4 + 64;
   static unsigned long long lds_set = 0;      // one flag word per template instance
   hipError_t e = ensure_dynamic_lds(&k_corr<C, MODE>, SMEM, &lds_set);
   if (e != hipSuccess) return e;

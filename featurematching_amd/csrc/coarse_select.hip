@@ -23,7 +23,8 @@ struct SelArgs {
   const float* scale0; const float* scale1;
   int64_t* b_ids; int64_t* i_ids; int64_t* j_ids; float* k0; float* k1; float* mconf;
   int cap; int32_t* d_count;
-  int* cell0; int* cell1;     // cell -> match index + 1 (for the cell-tiled window gather)
+  int* cell0; int* cell1;     // cell -> match index + 1 (for the cell-ordered window gathers)
+  int* ties0; int* ties1;     // [0] = count, then the matches that lost their cell to an exactly tied match
 };
 
 // one thread per (row, slot); a row's `slots` threads are adjacent lanes of one wave
@@ -139,8 +140,17 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
   const int i = (int)(grow - (long)b * a.Lp);
   const int j = a.keep_j[grow * a.slots + slot];
   a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = j;
-  a.cell0[grow] = (int)o + 1;                         // exact ties: any of the tied matches may win the cell;
-  a.cell1[(long)b * a.Sp + j] = (int)o + 1;           // the gather picks the others up as left-overs
+  // cell -> match maps: with exact ties the largest match index keeps the cell, every other tied match
+  // is listed once (whoever loses the atomicMax, now or when it is displaced later, is the one listed)
+  {
+    const int me = (int)o + 1;
+    int old = atomicMax(&a.cell0[grow], me);
+    int loser = old > me ? me : old;
+    if (loser > 0) { const int p = atomicAdd(&a.ties0[0], 1); if (p < kTieCap) a.ties0[1 + p] = loser - 1; }
+    old = atomicMax(&a.cell1[(long)b * a.Sp + j], me);
+    loser = old > me ? me : old;
+    if (loser > 0) { const int p = atomicAdd(&a.ties1[0], 1); if (p < kTieCap) a.ties1[1 + p] = loser - 1; }
+  }
   a.mconf[o] = a.keep_conf[grow * a.slots + slot];
   // coarse_matching_new.py:126-134: (x, y) = (id % w, id // w) * scale [* scale{0,1}[b]]
   float s0x = a.scale_px, s0y = a.scale_px, s1x = a.scale_px, s1y = a.scale_px;
@@ -171,6 +181,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, cons
   a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.k0 = k0; a.k1 = k1; a.mconf = mconf;
   a.cap = cap; a.d_count = d_count;
   a.cell0 = (int*)(base + w.cell0); a.cell1 = (int*)(base + w.cell1);
+  a.ties0 = (int*)(base + w.ties0); a.ties1 = (int*)(base + w.ties1);
   const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
   hipLaunchKernelGGL(k_cand_conf, dim3(blocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_cand_keep, dim3(blocks), dim3(256), 0, st, a);

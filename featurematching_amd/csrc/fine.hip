@@ -13,181 +13,156 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
 }
 
 // ----------------------------------------------------------------------------------------
-// k_gather_nchw64<W>: one workgroup per window (Cf = 64, W compile-time).
+// Window crop for NCHW maps with Cf = 64 (W compile-time): ONE WAVE PER WINDOW, four windows per
+// workgroup, no workgroup barrier.
 // The reference unfolds EVERY coarse cell's window (60 MB per image at 640x480) and then selects M
 // of them; here only the M selected windows are read, straight from the NCHW map.  Lanes run along
 // (channel, window row, x) with x fastest, so one wave-load touches ~64/W short runs in 2-3 channel
 // planes.  (Lane = channel would put the 64 lanes of a load one plane stride apart - 307200 B at
-// 240x320 - which lands on a handful of L2/HBM channels; measured 2x slower.)  The [c][r] -> [r][c]
-// transpose goes through LDS (pitch 65: conflict-free both ways) and the window leaves as one
-// contiguous record.  Window origin = stride*cell - pad with the reference's literal pad = 2, zero
-// outside the map.
+// 240x320 - which lands on a handful of L2/HBM channels; measured 2x slower.)  All loads of the window
+// are issued before the first use (25 / 49 in flight per lane).  The [c][r] -> [r][c] transpose goes
+// through a wave-private LDS tile (pitch 68 floats: 16-byte aligned rows) and the window leaves as one
+// contiguous record in 16-byte stores.  Window origin = stride*cell - pad with the reference's literal
+// pad = 2, zero outside the map.
+// (One workgroup per window, 3776 four-wave workgroups at 640x480, was bound by workgroup launch
+// rate: its time followed the number of workgroups, not the bytes.)
 // ----------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int Wf, int oy, int ox,
+                                                   float* __restrict__ dst, float* tile, int lane) {
+  constexpr int CF = 64, WW = W * W, TOTAL = CF * WW, PITCH = CF + 4;
+  // lane -> (channel within the instruction, window position) is the same for every load: W = 5 puts two
+  // channels x 32 position slots (25 used) in one wave-load, W = 7 one channel x 64 slots (49 used).  Only
+  // the channel advances from load to load, by a SCALAR offset, so the address math is done once.
+  constexpr int SLOTS = W == 5 ? 32 : 64, CPI = 64 / SLOTS, NLOAD = CF / CPI;
+  static_assert(W == 5 || W == 7, "position decode below is for W in {5,7}");
+  const int rem = lane & (SLOTS - 1), hi = lane / SLOTS;
+  const int wy = W == 5 ? (rem * 13) >> 6 : (rem * 37) >> 8;       // rem / W for rem < W*W
+  const int wx = rem - wy * W;
+  const int y = oy + wy, x = ox + wx;
+  const bool ok = rem < WW && y >= 0 && y < Hf && x >= 0 && x < Wf;
+  // Buffer loads through a descriptor of this sample's map (src is wave-uniform): positions outside the
+  // map (the zero padding of the unfold) get an out-of-range offset, which the hardware range check
+  // answers with 0 - no branch, no 64-bit address per load.
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, CF * Hf * Wf * 4, 0x00020000);
+  const unsigned voff = ok ? (unsigned)((hi * Hf + y) * Wf + x) * 4u : 0x80000000u;
+  const int step = Hf * Wf * 4 * CPI;                               // bytes from one load to the next
+  float v[NLOAD];
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it) {
+#ifndef FM_ABL_G_NOLOAD      // timing-only ablations (wrong results): never defined in the shipped build
+    v[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, it * step, 0));
+#else
+    v[it] = 0.f;
+#endif
+  }
+  float* slot = tile + rem * PITCH + hi;
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it)
+    if (rem < WW) slot[it * CPI] = v[it];
+  __builtin_amdgcn_wave_barrier();       // same-wave LDS accesses are processed in order: no s_barrier needed
+  float4* dst4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int it = 0; it < (TOTAL / 4 + 63) / 64; ++it) {
+    const int idx = it * 64 + lane;          // float4 index: position idx / 16, channels 4*(idx % 16) ..
+    if (idx < TOTAL / 4) {
+      const float4 q = *reinterpret_cast<const float4*>(tile + (idx >> 4) * PITCH + (idx & 15) * 4);
+#ifdef FM_ABL_G_NOSTORE
+      if (q.x == 1.2345e-30f) dst4[idx] = q;
+#else
+      dst4[idx] = q;
+#endif
+    }
+  }
+  __builtin_amdgcn_wave_barrier();       // the tile may be refilled by this wave right away
+}
+
+constexpr int kGatherTileFloats(int W) { return W * W * 68; }
+
+// list order: window m of the match list (any ids; the generic entry point)
 template <int W>
 __global__ __launch_bounds__(256) void k_gather_nchw64(const float* __restrict__ feat, int Hf, int Wf, int stride,
                                                        int pad, int w_c, const int64_t* __restrict__ b_ids,
                                                        const int64_t* __restrict__ ids,
                                                        const int32_t* __restrict__ d_count, int m_max,
                                                        float* __restrict__ out) {
-  constexpr int CF = 64, WW = W * W, TOTAL = CF * WW;
-  __shared__ float tile[WW * (CF + 1)];
+  constexpr int CF = 64, TOTAL = CF * W * W;
+  __shared__ __attribute__((aligned(16))) float tile[4 * kGatherTileFloats(W)];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = d_count ? min(d_count[0], m_max) : m_max;
   // spread the M live windows (not the m_max launched ones) contiguously over the XCDs
   const int per = (M + 7) >> 3;
-  const int m = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || m >= M) return;
-  const int b = (int)b_ids[m];
-  const int id = (int)ids[m];
+  const int slot = (int)(blockIdx.x >> 3) * 4 + wv;
+  const int m = (blockIdx.x & 7) * per + slot;
+  if (slot >= per || m >= M) return;
+  const int b = __builtin_amdgcn_readfirstlane((int)b_ids[m]);       // wave-uniform values into scalars
+  const int id = __builtin_amdgcn_readfirstlane((int)ids[m]);
   const int cy = id / w_c;
-  const int oy = cy * stride - pad;
-  const int ox = (id - cy * w_c) * stride - pad;
-  const float* src = feat + (long)b * CF * Hf * Wf;
-#pragma unroll
-  for (int it = 0; it < (TOTAL + 255) / 256; ++it) {
-    const int idx = it * 256 + threadIdx.x;
-    if (idx < TOTAL) {
-      const int c = idx / WW;
-      const int rem = idx - c * WW;
-      const int wy = rem / W, wx = rem - wy * W;
-      const int y = oy + wy, x = ox + wx;
-      float v = 0.f;
-      if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)c * Hf + y) * Wf + x];
-      tile[rem * (CF + 1) + c] = v;
-    }
-  }
-  __syncthreads();
-  float* dst = out + (long)m * TOTAL;
-#pragma unroll
-  for (int it = 0; it < (TOTAL + 255) / 256; ++it) {
-    const int idx = it * 256 + threadIdx.x;
-    if (idx < TOTAL) dst[idx] = tile[(idx >> 6) * (CF + 1) + (idx & 63)];
-  }
+  wave_copy_window64<W>(feat + (long)b * CF * Hf * Wf, Hf, Wf, cy * stride - pad, (id - cy * w_c) * stride - pad,
+                        out + (long)m * TOTAL, tile + wv * kGatherTileFloats(W), lane);
 }
 
 // ----------------------------------------------------------------------------------------
-// k_gather_cells64<W>: cell-tiled crop.  One workgroup = 8 adjacent coarse cells of one coarse row.
-// The strip of the fine map under those 8 windows (W rows x 28+W columns x 64 channels) is read ONCE
-// in runs of ~34 floats (two cache lines per (channel,row) instead of one line per 20-byte run and
-// window: 3x less fabric traffic than the per-window kernel), transposed through LDS, and the windows
-// of the cells that are matched (cell -> match map from the coarse stage, 0 = unmatched) are written
-// as contiguous records.  Matches that lost their cell to an exactly tied match are picked up at the
-// end from this workgroup's slice of the match list with the per-window path.
+// k_gather_cellorder64<W>: the same per-window copy, but the waves run over the CELLS of this image
+// in raster order (cell -> match map from the coarse stage, 0 = unmatched) and each XCD takes a
+// contiguous band of cells.  For image 1 the match list is sorted by the image-0 cell, so in list
+// order the windows of one XCD are scattered over the whole map (20 MB at 640x480 against a 4 MB L2:
+// every 20-byte run misses to the fabric); in cell order one XCD touches only its band (2.5 MB).
+// Matches that lost their cell to an exactly tied match (listed by k_emit) are copied by the first
+// waves of the grid, one each; if that list overflowed (> kTieCap) every wave scans its slice of the
+// match list instead.
 // ----------------------------------------------------------------------------------------
 template <int W>
-__global__ __launch_bounds__(256) void k_gather_cells64(const float* __restrict__ feat, int N, int Hf, int Wf, int h_c,
-                                                        int w_c, const int32_t* __restrict__ cell_to_match,
-                                                        int cell_pitch, const int64_t* __restrict__ b_ids,
-                                                        const int64_t* __restrict__ ids,
-                                                        const int32_t* __restrict__ d_count, int m_max,
-                                                        float* __restrict__ out) {
-  constexpr int CF = 64, G = 8, STRIDE = 4, PAD = 2, WW = W * W, TOTAL = CF * WW;
-  constexpr int SPAN = (G - 1) * STRIDE + W;        // fine columns under the 8 windows
-  constexpr int NX2 = (SPAN + 1) / 2;               // loaded as float2 (the strip starts at an even column)
-  constexpr int SPANP = 2 * NX2;
-  constexpr int PITCH = CF + 1;
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [W][SPANP][PITCH]
-  __shared__ int mids[G];
-  __shared__ int left[32];
-  __shared__ int nleft;
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_gather_cellorder64(const float* __restrict__ feat, int Hf, int Wf, int stride,
+                                                            int pad, int w_c, int cells, int total_cells,
+                                                            const int32_t* __restrict__ cell_to_match, int cell_pitch,
+                                                            const int32_t* __restrict__ ties,
+                                                            const int64_t* __restrict__ b_ids,
+                                                            const int64_t* __restrict__ ids,
+                                                            const int32_t* __restrict__ d_count, int m_max,
+                                                            float* __restrict__ out) {
+  constexpr int CF = 64, TOTAL = CF * W * W;
+  __shared__ __attribute__((aligned(16))) float tile_all[4 * kGatherTileFloats(W)];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* tile = tile_all + wv * kGatherTileFloats(W);
   const int M = d_count ? min(d_count[0], m_max) : m_max;
-  const int groups = (w_c + G - 1) / G;
-  const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int gx = bid % groups;
-  const int cy = (bid / groups) % h_c;
-  const int b = bid / (groups * h_c);
-  if (tid < G) {
-    const int x = gx * G + tid;
-    int m = -1;
-    if (x < w_c) m = cell_to_match[(long)b * cell_pitch + cy * w_c + x] - 1;
-    mids[tid] = (m < M) ? m : -1;
+  const int nties = ties[0];
+  const int lid = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;      // grid is a multiple of 8
+  // job = (match, sample, cell) this wave copies next; first its own cell, then tie losers (rare)
+  int jm = -1, jb = 0, jcell = 0;
+  if (lid < total_cells) {
+    const int b = lid / cells, cell = lid - b * cells;
+    const int m = cell_to_match[(long)b * cell_pitch + cell] - 1;
+    if (m >= 0 && m < M) { jm = m; jb = b; jcell = cell; }
   }
-  if (tid == 0) nleft = 0;
-  __syncthreads();
-  bool any = false;
-#pragma unroll
-  for (int k = 0; k < G; ++k) any = any || (mids[k] >= 0);
-  if (any) {
-    const int oy = cy * STRIDE - PAD, ox = gx * G * STRIDE - PAD;
-    const float* src = feat + (long)b * CF * Hf * Wf;
-    const bool even = (Wf & 1) == 0;
-    // all loads of a thread are issued before the first LDS write (compile-time trip count, fully
-    // unrolled): one round trip to L2/HBM per workgroup instead of one per loop iteration
-    constexpr int NLOAD = (CF * W * NX2 + 255) / 256;
-    float2 v[NLOAD];
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      const int idx = it * 256 + tid;
-      const int xq = idx % NX2;
-      const int cw = idx / NX2;
-      const int wy = cw % W, c = cw / W;
-      const int y = oy + wy, x = ox + 2 * xq;
-      v[it] = make_float2(0.f, 0.f);
-      if (idx < CF * W * NX2 && y >= 0 && y < Hf) {
-        const float* row = src + ((long)c * Hf + y) * Wf;
-        if (even && x >= 0 && x + 1 < Wf) v[it] = *reinterpret_cast<const float2*>(row + x);
-        else {
-          if (x >= 0 && x < Wf) v[it].x = row[x];
-          if (x + 1 >= 0 && x + 1 < Wf) v[it].y = row[x + 1];
-        }
-      }
+  const int gwave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+  const int mode = nties == 0 ? 0 : (nties <= kTieCap ? 1 : 2);          // 2: list overflowed, scan the matches
+  int q = gwave;
+  const int chunk = (M + nwaves - 1) / nwaves;
+  int scan = gwave * chunk;
+  const int scan_end = min(M, scan + chunk);
+  for (;;) {
+    if (jm >= 0) {
+      jm = __builtin_amdgcn_readfirstlane(jm); jb = __builtin_amdgcn_readfirstlane(jb);
+      jcell = __builtin_amdgcn_readfirstlane(jcell);
+      const int cy = jcell / w_c;
+      wave_copy_window64<W>(feat + (long)jb * CF * Hf * Wf, Hf, Wf, cy * stride - pad, (jcell - cy * w_c) * stride - pad,
+                            out + (long)jm * TOTAL, tile, lane);
     }
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      const int idx = it * 256 + tid;
-      if (idx < CF * W * NX2) {
-        const int xq = idx % NX2;
-        const int cw = idx / NX2;
-        const int wy = cw % W, c = cw / W;
-        tile[(wy * SPANP + 2 * xq) * PITCH + c] = v[it].x;
-        tile[(wy * SPANP + 2 * xq + 1) * PITCH + c] = v[it].y;
-      }
+    jm = -1;
+    if (mode == 0) break;                                                // the common case: no exact ties
+    if (mode == 1) {
+      if (q >= nties) break;
+      const int m = ties[1 + q];
+      q += nwaves;
+      if (m >= 0 && m < M) { jm = m; jb = (int)b_ids[m]; jcell = (int)ids[m]; }
+    } else {
+      if (scan >= scan_end) break;
+      const int m = scan++;
+      const int mb = (int)b_ids[m], id = (int)ids[m];
+      if (cell_to_match[(long)mb * cell_pitch + id] != m + 1) { jm = m; jb = mb; jcell = id; }
     }
-    __syncthreads();
-#pragma unroll 1
-    for (int k = 0; k < G; ++k) {
-      const int m = mids[k];
-      if (m < 0) continue;
-      float* dst = out + (long)m * TOTAL;
-#pragma unroll
-      for (int it = 0; it < (TOTAL + 255) / 256; ++it) {
-        const int idx = it * 256 + tid;
-        if (idx < TOTAL) {
-          const int rpos = idx >> 6, c = idx & 63;
-          const int wy = rpos / W, wx = rpos - wy * W;
-          dst[idx] = tile[(wy * SPANP + k * STRIDE + wx) * PITCH + c];
-        }
-      }
-    }
-  }
-  // ---- left-overs of this workgroup's slice of the match list (exact ties only) ----
-  const int chunk = (M + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int m0 = blockIdx.x * chunk;
-  if (tid < chunk && tid < 32 && m0 + tid < M) {
-    const int m = m0 + tid;
-    const int mb = (int)b_ids[m], id = (int)ids[m];
-    if (cell_to_match[(long)mb * cell_pitch + id] != m + 1) left[atomicAdd(&nleft, 1)] = m;
-  }
-  __syncthreads();
-  const int nl = nleft;
-  for (int q = 0; q < nl; ++q) {          // rare
-    __syncthreads();
-    const int m = left[q];
-    const int mb = (int)b_ids[m], id = (int)ids[m];
-    const int ccy = id / w_c;
-    const int oy = ccy * STRIDE - PAD, ox = (id - ccy * w_c) * STRIDE - PAD;
-    const float* src = feat + (long)mb * CF * Hf * Wf;
-    for (int idx = tid; idx < TOTAL; idx += 256) {
-      const int c = idx / WW, rem = idx - c * WW;
-      const int wy = rem / W, wx = rem - wy * W;
-      const int y = oy + wy, x = ox + wx;
-      float v = 0.f;
-      if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)c * Hf + y) * Wf + x];
-      tile[rem * PITCH + c] = v;
-    }
-    __syncthreads();
-    float* dst = out + (long)m * TOTAL;
-    for (int idx = tid; idx < TOTAL; idx += 256) dst[idx] = tile[(idx >> 6) * PITCH + (idx & 63)];
   }
 }
 
@@ -414,12 +389,15 @@ extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int
   if (N <= 0 || Cf <= 0 || Hf <= 0 || Wf <= 0 || W <= 0 || stride <= 0 || w_c <= 0 || m_max < 0) return FM_E_SHAPE;
   if (W > 15 || Cf > 512 || (layout == 1 && Cf % 4) || (layout != 0 && layout != 1)) return FM_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (layout == 0 && Cf == 64 && (W == 5 || W == 7)) {
+  // the fast NCHW kernels address one sample's map with 31-bit byte offsets (buffer descriptor)
+  if (layout == 0 && Cf == 64 && (W == 5 || W == 7) && (long)Hf * Wf * 64 * 4 < (1L << 31)) {
+    // 8 XCD ranges of ceil(M/8) windows, four windows (waves) per workgroup
+    const int blocks = 8 * (((m_max + 7) / 8 + 3) / 4);
     if (W == 5)
-      hipLaunchKernelGGL(k_gather_nchw64<5>, dim3((m_max + 7) / 8 * 8), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
+      hipLaunchKernelGGL(k_gather_nchw64<5>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
                          ids, d_count, m_max, out);
     else
-      hipLaunchKernelGGL(k_gather_nchw64<7>, dim3((m_max + 7) / 8 * 8), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
+      hipLaunchKernelGGL(k_gather_nchw64<7>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
                          ids, d_count, m_max, out);
   } else if (layout == 0) {
     const size_t smem = (size_t)W * W * (Cf + 1) * sizeof(float);
@@ -435,32 +413,22 @@ extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int
 
 extern "C" int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int Hf, int Wf, int W, int stride, int pad,
                                        int h_c, int w_c, const int32_t* cell_to_match, int cell_pitch,
-                                       const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max,
-                                       float* out, void* stream) {
+                                       const int32_t* ties, const int64_t* b_ids, const int64_t* ids,
+                                       const int32_t* d_count, int m_max, float* out, void* stream) {
   if (m_max == 0) return FM_OK;
-  if (!feat_f || !cell_to_match || !b_ids || !ids || !out) return FM_E_NULL;
-  if (N <= 0 || Hf <= 0 || Wf <= 0 || h_c <= 0 || w_c <= 0 || m_max < 0 || cell_pitch < h_c * w_c) return FM_E_SHAPE;
-  if (Cf != 64 || (W != 5 && W != 7) || stride != 4 || pad != 2) return FM_E_UNSUPPORTED;
+  if (!feat_f || !cell_to_match || !ties || !b_ids || !ids || !out) return FM_E_NULL;
+  if (N <= 0 || Hf <= 0 || Wf <= 0 || h_c <= 0 || w_c <= 0 || stride <= 0 || m_max < 0 || cell_pitch < h_c * w_c)
+    return FM_E_SHAPE;
+  if (Cf != 64 || (W != 5 && W != 7) || (long)Hf * Wf * 64 * 4 >= (1L << 31)) return FM_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int groups = (w_c + 7) / 8;
-  const int blocks = N * h_c * groups;
-  if (m_max > 32L * blocks) return FM_E_UNSUPPORTED;      // left-over slices hold at most 32 matches each
-  const int span = 7 * 4 + W;
-  const size_t smem = (size_t)W * (2 * ((span + 1) / 2)) * 65 * sizeof(float);
-  hipError_t e;
-  if (W == 5) {
-    static unsigned long long lds_set5 = 0;
-    e = ensure_dynamic_lds(&k_gather_cells64<5>, (int)smem, &lds_set5);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_gather_cells64<5>, dim3(blocks), dim3(256), smem, st, feat_f, N, Hf, Wf, h_c, w_c, cell_to_match,
-                       cell_pitch, b_ids, ids, d_count, m_max, out);
-  } else {
-    static unsigned long long lds_set7 = 0;
-    e = ensure_dynamic_lds(&k_gather_cells64<7>, (int)smem, &lds_set7);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_gather_cells64<7>, dim3(blocks), dim3(256), smem, st, feat_f, N, Hf, Wf, h_c, w_c, cell_to_match,
-                       cell_pitch, b_ids, ids, d_count, m_max, out);
-  }
+  const long total = (long)N * h_c * w_c;                 // one wave per cell, four per workgroup
+  const int blocks = (int)(((total + 3) / 4 + 7) / 8 * 8);
+  if (W == 5)
+    hipLaunchKernelGGL(k_gather_cellorder64<5>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
+                       h_c * w_c, (int)total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out);
+  else
+    hipLaunchKernelGGL(k_gather_cellorder64<7>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
+                       h_c * w_c, (int)total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out);
   return (int)hipGetLastError();
 }
 

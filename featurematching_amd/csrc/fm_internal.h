@@ -11,6 +11,7 @@ namespace fm {
 constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup owns
 // column partials each panel writes (one per wave: 8 waves x 32 rows)
 constexpr int kColParts = 8;
+constexpr int kTieCap = 1023;        // listed tie losers per image; beyond it the gathers scan the match list
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
 constexpr float kLog2e = 1.4426950408889634f;
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
@@ -28,6 +29,8 @@ struct CoarseWs {
   // zeroed on every call (contiguous, starts at the base)
   size_t zero_begin, cand_count, colbest, blocktot, scalars, zero_end;
   size_t cell0, cell1;                        // (zeroed) match index + 1 of every image-0 / image-1 cell
+  size_t ties0, ties1;                        // (zeroed) [0] = count, [1..kTieCap] = matches that lost their cell to an
+                                              // exactly tied match (the cell-ordered gathers pick them up)
   // float16 planes
   size_t hi0, lo0, hi1, lo1;
   // per-row / per-column statistics

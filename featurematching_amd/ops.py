@@ -57,17 +57,17 @@ class CoarseBuffers:
         return int(m.value)
 
     def cell_maps(self):
-        """((ptr0, pitch0), (ptr1, pitch1)): device addresses of the cell -> match-index+1 maps of image 0
-        and image 1 inside the workspace (valid while this object is alive); feed them to
-        gather_windows(cells=...) for the cell-tiled crop."""
+        """((map0, pitch0, ties0), (map1, pitch1, ties1)): device addresses of the cell -> match-index+1
+        maps and tie lists of image 0 and image 1 inside the workspace (valid while this object is alive);
+        feed them to gather_windows(cells=...) for the cell-ordered crops."""
         lib = _lib.load()
         n, l, s, c, slots = self._shape
-        p0, p1 = C.c_void_p(), C.c_void_p()
+        p0, p1, t0, t1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         q0, q1 = C.c_int(), C.c_int()
         base = self.workspace.data_ptr() + ((-self.workspace.data_ptr()) % 256)
-        _lib.check(lib.fm_coarse_cell_maps(C.c_void_p(base), n, l, s, c, slots, C.byref(p0), C.byref(q0),
-                                           C.byref(p1), C.byref(q1)), "fm_coarse_cell_maps")
-        return (p0.value, q0.value), (p1.value, q1.value)
+        _lib.check(lib.fm_coarse_cell_maps(C.c_void_p(base), n, l, s, c, slots, C.byref(p0), C.byref(q0), C.byref(t0),
+                                           C.byref(p1), C.byref(q1), C.byref(t1)), "fm_coarse_cell_maps")
+        return (p0.value, q0.value, t0.value), (p1.value, q1.value, t1.value)
 
     def sliced(self, m: int) -> dict:
         return dict(b_ids=self.b_ids[:m], i_ids=self.i_ids[:m], j_ids=self.j_ids[:m],
@@ -151,8 +151,9 @@ def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor,
                    out: Optional[torch.Tensor] = None, cells=None, h_c: Optional[int] = None) -> torch.Tensor:
     """Window crop (fine_preprocess.py:43-50) of the selected coarse cells only.
     feat_f is the logical [N,Cf,Hf,Wf] tensor, stored NCHW-contiguous or channels_last.
-    cells = (device address, pitch) of this image's cell -> match map (CoarseBuffers.cell_maps())
-    selects the cell-tiled kernel when the shape allows it (NCHW, Cf 64, W 5/7, stride 4)."""
+    cells = (map address, pitch, tie-list address) of this image (CoarseBuffers.cell_maps())
+    selects the cell-ordered kernel when the shape allows it (NCHW, Cf 64, W 5/7): the windows are
+    visited in raster order of THIS image's cells, which keeps each XCD's reads inside a band of the map."""
     lib = _lib.load()
     if not feat_f.is_cuda:
         raise RuntimeError("feat_f must live on the GPU: the HIP path has no CPU fallback")
@@ -170,10 +171,10 @@ def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor,
         out = torch.empty(m_max, w * w, cf, dtype=torch.float32, device=feat_f.device)
     if m_max == 0:
         return out
-    if cells is not None and layout == 0 and cf == 64 and w in (5, 7) and stride == 4 and pad == 2 and h_c:
+    if cells is not None and layout == 0 and cf == 64 and w in (5, 7) and h_c:
         st = lib.fm_gather_windows_cells(_ptr(feat_f), n, cf, hf, wf, w, stride, pad, int(h_c), int(w_c),
-                                         C.c_void_p(cells[0]), int(cells[1]), _ptr(b_ids), _ptr(ids), _ptr(count),
-                                         m_max, _ptr(out), _stream(feat_f.device))
+                                         C.c_void_p(cells[0]), int(cells[1]), C.c_void_p(cells[2]), _ptr(b_ids), _ptr(ids),
+                                         _ptr(count), m_max, _ptr(out), _stream(feat_f.device))
         if st != -3:                       # FM_E_UNSUPPORTED: fall through to the per-window kernel
             _lib.check(st, "fm_gather_windows_cells")
             return out

@@ -115,17 +115,20 @@ int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int la
                       const int32_t* d_count, int m_max, float* out, void* stream);
 
 /*
- * Faster variant of the window crop for NCHW maps with Cf = 64, W in {5,7}, stride 4, pad 2: workgroups
- * walk the coarse grid (h_c x w_c cells per sample) in strips of 8 cells, read the fine-map strip once
- * and emit the windows of the matched cells.  cell_to_match [N, cell_pitch] int32 holds match index + 1
- * per cell of THIS image (0 = unmatched): fm_coarse_cell_maps returns the two maps the coarse stage keeps
- * in its workspace (valid until the workspace is reused).  Same outputs as fm_gather_windows.
- * FM_E_UNSUPPORTED when the shape is outside the fast path: call fm_gather_windows instead.
+ * Cell-ordered window crop for NCHW maps with Cf = 64 and W in {5,7}: one wave per coarse cell in raster
+ * order, every XCD a contiguous band of the map (keeps the windows of image 1, whose list order is
+ * scattered over the map, inside one L2).  cell_to_match [N, cell_pitch] int32 holds match index + 1 per
+ * cell of THIS image (0 = unmatched); ties[0] = number of matches that lost their cell to an exactly
+ * tied match, ties[1..] = their indices (at most 1023 listed; beyond that the kernel scans the match
+ * list).  fm_coarse_cell_maps returns the maps and tie lists the coarse stage keeps in its workspace
+ * (valid until the workspace is reused).  Same outputs as fm_gather_windows.
+ * FM_E_UNSUPPORTED when the shape is outside this path: call fm_gather_windows instead.
  */
 int fm_coarse_cell_maps(void* workspace, int N, int L, int S, int C, int cand_slots,
-                        int32_t** cell0, int* pitch0, int32_t** cell1, int* pitch1);
+                        int32_t** cell0, int* pitch0, int32_t** ties0,
+                        int32_t** cell1, int* pitch1, int32_t** ties1);
 int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int Hf, int Wf, int W, int stride, int pad,
-                            int h_c, int w_c, const int32_t* cell_to_match, int cell_pitch,
+                            int h_c, int w_c, const int32_t* cell_to_match, int cell_pitch, const int32_t* ties,
                             const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max,
                             float* out, void* stream);
 

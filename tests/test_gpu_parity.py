@@ -312,19 +312,29 @@ def test_dense_conf_matrix_and_training_ids():
         modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1}).train()(t0, t1, dict(data))
 
 
-# ------------------------------------------------------------------ cell-tiled window crop
+# ------------------------------------------------------------------ cell-ordered window crops
 @pytest.mark.parametrize("w", [5, 7])
-def test_cell_tiled_gather_equals_per_window_gather(w):
-    """Same windows from the cell-tiled kernel (incl. map borders, unmatched cells, a row that is not
-    a multiple of 8 cells wide, and an exact tie whose second match is a left-over)."""
+def test_cell_ordered_gather_equals_list_ordered_gather(w):
+    """Same windows from the cell-ordered kernel (one wave per cell of the image) as from the list-ordered
+    one, incl. map borders, unmatched cells, a cell count that is not a multiple of the grid granule, and
+    exact ties (two- and three-way, in either image) whose losers come from the tie list."""
     hc, wc = 11, 13
     f0, f1 = synth.coarse_descriptors(71, 2, hc * wc, 64, "peaky")
-    f1[0, 40] = f1[0, 41] = f0[0, 30] + 0.4 * synth.normal(71, 9, (64,))      # tie: cell 30 -> cells 40 and 41
+    # exact ties built from fresh descriptors (the cells' original partners simply stay unmatched)
+    va, vb, vc = (4.0 * synth.normal(71, k, (64,)) for k in (9, 10, 11))
+    f0[0, 30] = va
+    f1[0, 40] = f1[0, 41] = va + 0.4 * synth.normal(71, 12, (64,))            # cell 30 -> cells 40 and 41
+    f0[1, 33] = vb
+    f1[1, 50] = f1[1, 51] = f1[1, 52] = vb + 0.4 * synth.normal(71, 13, (64,))    # three-way tie in sample 1
+    f1[1, 70] = vc
+    f0[1, 60] = f0[1, 61] = vc + 0.4 * synth.normal(71, 14, (64,))            # two image-0 cells -> one image-1 cell
     t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
     buf = ops.coarse_match_async(t0, t1, (hc, wc), (hc, wc), 8.0, border_rm=0)
     m = buf.read_count()
     o = buf.sliced(m)
-    assert m > 150 and len(set(o['i_ids'].tolist())) < m                      # the tie is there
+    pairs0 = list(zip(o['b_ids'].tolist(), o['i_ids'].tolist()))
+    pairs1 = list(zip(o['b_ids'].tolist(), o['j_ids'].tolist()))
+    assert m > 150 and len(set(pairs0)) <= m - 3 and len(set(pairs1)) <= m - 1      # the ties are there
     ff0, ff1 = synth.fine_maps(71, 2, 64, hc * 4, wc * 4)
     c0, c1 = buf.cell_maps()
     for ff, ids, cells in ((ff0, o['i_ids'], c0), (ff1, o['j_ids'], c1)):

@@ -67,8 +67,9 @@ def main():
                  timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 0, st), a.iters)))
     rows.append(("  corr sum pass (k_corr<.,1>)",
                  timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 1, st), a.iters, reset)))
-    p.tiled = False
-    rows.append(("gather windows (both images, per-window)", timed(lambda: (
+    buf, k0, k1 = p.step()          # the sweep timings above reset this workspace (cell maps included)
+    torch.cuda.synchronize()
+    rows.append(("gather windows (both images, list order)", timed(lambda: (
         ops.gather_windows(p.ff0, buf.b_ids, buf.i_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win0),
         ops.gather_windows(p.ff1, buf.b_ids, buf.j_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win1)), a.iters)))
     rows.append(("  gather image 0 (sorted cells)", timed(lambda: ops.gather_windows(
@@ -76,13 +77,12 @@ def main():
     rows.append(("  gather image 1 (permuted cells)", timed(lambda: ops.gather_windows(
         p.ff1, buf.b_ids, buf.j_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win1), a.iters)))
     c0, c1 = buf.cell_maps()
-    rows.append(("  gather image 0, cell-tiled", timed(lambda: ops.gather_windows(
+    rows.append(("  gather image 0, cell order", timed(lambda: ops.gather_windows(
         p.ff0, buf.b_ids, buf.i_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win0, cells=c0, h_c=p.hw_c[0]), a.iters)))
-    rows.append(("  gather image 1, cell-tiled", timed(lambda: ops.gather_windows(
+    rows.append(("  gather image 1, cell order", timed(lambda: ops.gather_windows(
         p.ff1, buf.b_ids, buf.j_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win1, cells=c1, h_c=p.hw_c[0]), a.iters)))
     rows.append(("fine match", timed(lambda: ops.fine_match(p.win0, p.win1, p.mix0, p.mix1, buf.mkpts0_c, buf.mkpts1_c,
                                                               2.0, count=buf.count), a.iters)))
-    p.tiled = True
     rows.append(("whole step (eager)", timed(lambda: p.step(), a.iters)))
     flops = 2.0 * p.n * p.l * p.l * p.c
     for name, (med, mn) in rows:
