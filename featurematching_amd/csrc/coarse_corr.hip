@@ -37,6 +37,8 @@
 //     the whole sweep and reduces column sums lane-locally (rows live in registers,
 //     columns on lanes: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5));
 //     each wave writes the column partial of its own 32 rows (8 partials per panel).
+#include <stdlib.h>
+
 #include "fm_internal.h"
 
 namespace fm {
@@ -63,6 +65,7 @@ struct CorrArgs {
   int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
   float* conf;            // MODE 3: dense [N,L,S] output
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, slots;
+  int pgroup;             // panels per XCD-locality group of the workgroup order
   float k;    // log2(e) / (C*T): raw dot product -> log2-domain similarity
   float lt;   // log2(thr)
 };
@@ -95,6 +98,18 @@ __device__ __forceinline__ float wave_max64(float v) {
   return v;
 }
 
+// reduction over the 32 lanes that share lane>>5 (max or sum), result in every lane of the half; DPP only
+template <bool SUM>
+__device__ __forceinline__ float half_reduce32(float v) {
+  auto op = [](float x, float y) { return SUM ? x + y : fmaxf(x, y); };
+  v = op(v, dpp_mov<0xB1, 0xf>(v, v));                                                       // lane ^ 1
+  v = op(v, dpp_mov<0x4E, 0xf>(v, v));                                                       // lane ^ 2
+  { float t = dpp_mov<0x104, 0x5>(v, v); t = dpp_mov<0x114, 0xA>(t, v); v = op(v, t); }     // lane ^ 4
+  v = op(v, dpp_mov<0x128, 0xf>(v, v));                                                      // lane ^ 8
+  { float p = v, q = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q)); v = op(p, q); }   // ^ 16
+  return v;
+}
+
 template <int C, int MODE>
 __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   constexpr int KSTEPS = C / 16;
@@ -112,15 +127,35 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   if (MODE == 2 && !(*a.flags & FM_INT_SCREEN_OVERFLOW)) return;   // uniform: fast screening sufficed
+#ifdef FM_DIAG_CLOCK       // diagnostic build only: shader-clock stamps (s_memtime) per phase of every wave
+  const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long diag_mfma = 0, diag_epi = 0, diag_bar = 0, diag_pro = 0, diag_loop_end = 0;
+  int diag_units = 0, diag_cand = 0;
+#define DIAG_T0 const unsigned long long diag_t = __builtin_amdgcn_s_memtime();
+#define DIAG_ADD(x) x += __builtin_amdgcn_s_memtime() - diag_t;
+#else
+#define DIAG_T0
+#define DIAG_ADD(x)
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
+  // Logical workgroup order: sample, then GROUPS of a.pgroup panels, inside a group split-major.  An XCD's
+  // contiguous share of that order (xcd_remap) is then a compact block of a few panels x a few splits:
+  // its L2 has to pull only those panels' A fragments and those splits' column ranges over the fabric
+  // (panel-fastest order made every XCD fetch ALL of image 0 during the prologue: 14.5k cycles at 640x480).
   int kk = xcd_remap(blockIdx.x, gridDim.x);
-  const int panel = kk % a.panels; kk /= a.panels;
-  const int split = kk % a.splits;
-  const int b = kk / a.splits;
+  const int per_sample = a.panels * a.splits;
+  const int b = kk / per_sample;
+  kk -= b * per_sample;
+  const int gsz = a.pgroup * a.splits;
+  const int pg = kk / gsz;
+  kk -= pg * gsz;
+  const int pcount = min(a.pgroup, a.panels - pg * a.pgroup);
+  const int split = kk / pcount;
+  const int panel = pg * a.pgroup + (kk - split * pcount);
   const int t0 = split * a.tiles_per_split;
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
@@ -313,7 +348,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         }
       }
     } else {
-      float best = -INFINITY;
+      // largest min(row term, column term) per group of four accumulator registers (= rows 8q+4h .. +3):
+      // tells the candidate scan below which groups to look at without recomputing anything
+      float best4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       cstat = 0.f;
       float nmr[16];
 #pragma unroll
@@ -330,26 +367,35 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
           rstat[g] += __builtin_amdgcn_exp2f(rr);
           cstat += __builtin_amdgcn_exp2f(cc);
         }
-        best = fmaxf(best, fminf(rr, cc));
+        best4[g >> 2] = fmaxf(best4[g >> 2], fminf(rr, cc));
       }
       if (MODE == 1) cstat += __shfl_xor(cstat, 32);
+      const float best = fmaxf(fmaxf(best4[0], best4[1]), fmaxf(best4[2], best4[3]));
 #ifdef FM_ABL_NOCAND            // timing-only: no candidate recording
       if (false) {
 #else
       if (__any(best > a.lt)) {      // some lane holds a candidate in this unit
 #endif
-        int rbase = 4 * h;
-        asm volatile("" : "+v"(rbase));   // keep the 16 per-row values from being hoisted (and spilled)
+#ifdef FM_DIAG_CLOCK
+        ++diag_cand;
+#endif
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const float x = acc[g];
-          const float rr = __builtin_fmaf(x, a.k, nmr[g]);
-          const float cc = __builtin_fmaf(x, a.k, nmc);
-          const int rl = rbase + (g & 3) + 8 * (g >> 2);          // row inside this wave's 32
-          if (rr > a.lt && cc > a.lt && wrow0 + rl < a.L && cvalid) {
-            const int q = atomicAdd(qcnt, 1);                     // LDS, wave-private
-            if (q < kCandQueue) { qkey[q] = (col << 5) | rl; qx[q] = x; }
-            else record_candidate((long)b * a.Lp + wrow0 + rl, col, x);     // queue full: straight to the lists
+        for (int q = 0; q < 4; ++q) {
+          if (!__any(best4[q] > a.lt)) continue;                  // wave-uniform: usually 3 of the 4 groups
+          int rbase = 8 * q + 4 * h;
+          asm volatile("" : "+v"(rbase));   // keep the per-row values from being hoisted (and spilled)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int g = 4 * q + e;
+            const float x = acc[g];
+            const float rr = __builtin_fmaf(x, a.k, nmr[g]);
+            const float cc = __builtin_fmaf(x, a.k, nmc);
+            const int rl = rbase + e;                             // row inside this wave's 32
+            if (rr > a.lt && cc > a.lt && wrow0 + rl < a.L && cvalid) {
+              const int qi = atomicAdd(qcnt, 1);                  // LDS, wave-private
+              if (qi < kCandQueue) { qkey[qi] = (col << 5) | rl; qx[qi] = x; }
+              else record_candidate((long)b * a.Lp + wrow0 + rl, col, x);     // queue full: straight to the lists
+            }
           }
         }
       }
@@ -371,6 +417,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   };
   static_assert(NBUF <= 4 && 2 * GLDS_PER_TILE <= 63, "tile_barrier covers at most two tiles in flight");
   tile_barrier(min(NBUF - 2, t1 - t0 - 1));     // first tile and its metadata landed
+#ifdef FM_DIAG_CLOCK
+  diag_pro = __builtin_amdgcn_s_memtime() - diag_c0;
+#endif
 
   // Waves w and w+4 share a SIMD.  The second half of the workgroup runs one epilogue behind the
   // first, so that on every SIMD one wave's exp/add epilogue overlaps the other's MFMA chain.
@@ -403,14 +452,17 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #ifdef FM_ABL_ALLSKIP     // timing-only: tile streaming and barriers, no unit work
     skip = true;
 #endif
-    if (late && pend >= 0) { epilogue(pend, nmc_pend); pend = -1; }
+    if (late && pend >= 0) { DIAG_T0 epilogue(pend, nmc_pend); pend = -1; DIAG_ADD(diag_epi) }
     if (!skip) {
-      mfma_unit(u);
+#ifdef FM_DIAG_CLOCK
+      ++diag_units;
+#endif
+      { DIAG_T0 mfma_unit(u); asm volatile("" :: "v"(acc)); DIAG_ADD(diag_mfma) }
 #ifdef FM_ABL_NOEPI
       asm volatile("" :: "v"(acc));
 #else
       if (late) { pend = u; nmc_pend = nmc_u; }
-      else epilogue(u, nmc_u);
+      else { DIAG_T0 epilogue(u, nmc_u); DIAG_ADD(diag_epi) }
 #endif
     } else if (MODE == 1 && h == 0) {
       colout[t * kTileCols + (u & 1) * 32 + r] = 0.f;               // skipped unit: contributes nothing
@@ -419,11 +471,14 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       if (t + 1 < t1) meta_store(par ^ 1, mv);
       // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
 #ifndef FM_ABL_NOBAR
-      tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1));
+      { DIAG_T0 tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1)); DIAG_ADD(diag_bar) }
 #endif
     }
   }
-  if (late && pend >= 0) epilogue(pend, nmc_pend);
+  if (late && pend >= 0) { DIAG_T0 epilogue(pend, nmc_pend); DIAG_ADD(diag_epi) }
+#ifdef FM_DIAG_CLOCK
+  diag_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
   if (SPARSE) {      // hand the parked candidates to the per-row slot lists: one entry per lane, one round trip
     __builtin_amdgcn_wave_barrier();
@@ -436,21 +491,26 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   }
   if (MODE >= 2) return;
   // ---- row statistics of this workgroup's column range: reduce over the 32 lanes of each half ----
+  // (DPP butterflies: the former ds_bpermute shuffles cost ~3.7k cycles of LDS round trips per wave)
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    float v = rstat[g];
-#pragma unroll
-    for (int m = 1; m <= 16; m <<= 1) {
-      const float o = __shfl_xor(v, m);
-      v = MODE ? v + o : fmaxf(v, o);
-    }
-    rstat[g] = v;
-  }
+  for (int g = 0; g < 16; ++g) rstat[g] = half_reduce32<MODE != 0>(rstat[g]);
   if (r == 0) {
     float* out = a.rowpart + ((long)b * a.splits + split) * a.Lp + wrow0 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 16; ++g) out[(g & 3) + 8 * (g >> 2)] = rstat[g];
   }
+#ifdef FM_DIAG_CLOCK       // candidate slots of the padded rows (>= L, never used) carry the stamps of 64 waves
+  if (MODE <= 1 && t1 == a.tiles && panel < 8 && (a.Lp - a.L) * a.slots >= 512 && lane < 8) {
+    const float vals[8] = {(float)(__builtin_amdgcn_s_memtime() - diag_c0),
+                           (float)(__builtin_amdgcn_s_memrealtime() - diag_r0), (float)diag_units, (float)diag_mfma,
+                           (float)diag_epi, (float)diag_bar, (float)diag_pro,
+                           (float)(__builtin_amdgcn_s_memtime() - diag_loop_end)};
+    float vv = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vv = lane == q ? vals[q] : vv;
+    a.cand_x[((long)b * a.Lp + a.L) * a.slots + (panel * 8 + wv) * 8 + lane] = vv;
+  }
+#endif
 }
 
 template <int C, int MODE>
@@ -479,6 +539,18 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.flags = (unsigned*)(base + w.scalars);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
   a.splits = w.splits; a.tiles_per_split = (w.tiles + w.splits - 1) / w.splits; a.slots = w.slots;
+  {
+    // one XCD runs ~blocks/8 workgroups: make its block of (panels x splits) as square as the bytes are
+    // (a panel contributes 256 rows of A, a split tiles_per_split*64 columns of B)
+    const int blocks_all = w.N * w.splits * w.panels;
+    const float share = fmaxf(1.f, (float)blocks_all / 8.f);
+    int pgr = (int)lroundf(sqrtf(share * (float)(a.tiles_per_split * kTileCols) / (float)kPanelRows));
+    a.pgroup = pgr < 1 ? 1 : (pgr > w.panels ? w.panels : pgr);
+    if (w.splits == 1) a.pgroup = w.panels;
+#ifdef FM_TUNE_ENV
+    if (const char* e = getenv("FM_PGROUP")) a.pgroup = atoi(e) < 1 ? 1 : (atoi(e) > w.panels ? w.panels : atoi(e));
+#endif
+  }
   a.k = inv_ct * kLog2e;
   a.lt = log2f(thr) - (mode == 2 ? 2e-4f : 0.f);   // pass C compares rounded log-softmax values: small guard
   const int blocks = w.N * w.splits * w.panels;
