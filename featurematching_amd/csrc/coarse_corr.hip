@@ -480,16 +480,30 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   diag_loop_end = __builtin_amdgcn_s_memtime();
 #endif
 
-  if (SPARSE) {      // hand the parked candidates to the per-row slot lists: one entry per lane, one round trip
+  // Hand the parked candidates to the per-row slot lists: one entry per lane.  The slot reservation (a
+  // global atomic with return, one memory round trip) is issued here and consumed after the row
+  // reduction below, which hides most of its latency.
+  int q_pos = -1, q_key = 0;
+  float q_x = 0.f;
+  long q_row = 0;
+  if (SPARSE) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int nq = min(*qcnt, kCandQueue);
     if (lane < nq) {
-      const int key = qkey[lane];
-      record_candidate((long)b * a.Lp + wrow0 + (key & 31), key >> 5, qx[lane]);
+      q_key = qkey[lane];
+      q_x = qx[lane];
+      q_row = (long)b * a.Lp + wrow0 + (q_key & 31);
+      q_pos = atomicAdd(&a.cand_count[q_row], 1);
     }
   }
-  if (MODE >= 2) return;
+  auto commit_candidates = [&]() {
+    if (SPARSE && q_pos >= 0) {
+      if (q_pos < a.slots) { a.cand_j[q_row * a.slots + q_pos] = q_key >> 5; a.cand_x[q_row * a.slots + q_pos] = q_x; }
+      else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
+    }
+  };
+  if (MODE >= 2) { commit_candidates(); return; }
   // ---- row statistics of this workgroup's column range: reduce over the 32 lanes of each half ----
   // (DPP butterflies: the former ds_bpermute shuffles cost ~3.7k cycles of LDS round trips per wave)
 #pragma unroll
@@ -499,6 +513,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) out[(g & 3) + 8 * (g >> 2)] = rstat[g];
   }
+  commit_candidates();
 #ifdef FM_DIAG_CLOCK       // candidate slots of the padded rows (>= L, never used) carry the stamps of 64 waves
   if (MODE <= 1 && t1 == a.tiles && panel < 8 && (a.Lp - a.L) * a.slots >= 512 && lane < 8) {
     const float vals[8] = {(float)(__builtin_amdgcn_s_memtime() - diag_c0),
