@@ -92,23 +92,25 @@ class Pair:
 
 def time_corr_kernel(pair, mode, iters=30):
     """Average duration (ms) of ONE launch of the correlation sweep, bracketed by events on the
-    stream it is launched on (torch's current stream)."""
+    stream it is launched on (torch's current stream).  All iterations are enqueued before the host
+    waits, so each bracket holds the kernel and not the idle-queue launch latency of a lone dispatch
+    (that reads ~6 us longer than the kernel's duration in a rocprofv3 trace)."""
     lib = _lib.load()
     buf = pair.last[0]
     ws = buf.workspace
     ptr = C.c_void_p(ws.data_ptr() + ((-ws.data_ptr()) % 256))
     slots = lib.fm_default_cand_slots(0.2)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    total = 0.0
-    for _ in range(iters):
+    evs = []
+    for _ in range(iters + 3):
         _lib.check(lib.fm_debug_reset_counters(ptr, pair.n, pair.l, pair.l, pair.c, slots, st), "reset")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(lib.fm_debug_launch_corr(ptr, pair.n, pair.l, pair.l, pair.c, slots, 0.1, 0.2, mode, st), "corr")
         e1.record()
-        e1.synchronize()
-        total += e0.elapsed_time(e1)
-    return total / iters
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(e0.elapsed_time(e1) for e0, e1 in evs[3:]) / iters
 
 
 def pmc_traffic_bytes(a):

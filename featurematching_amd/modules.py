@@ -65,7 +65,7 @@ class CoarseMatching(nn.Module):
             w0c, w1c = data['hw0_c'][1], data['hw1_c'][1]
             mkpts0_c = torch.stack([i_ids % w0c, torch.div(i_ids, w0c, rounding_mode='floor')], dim=1) * scale0
             mkpts1_c = torch.stack([j_ids % w1c, torch.div(j_ids, w1c, rounding_mode='floor')], dim=1) * scale1
-        if not self.training:     # cell -> match maps for the (opt-in) cell-tiled window crop of FinePreprocess
+        if not self.training:     # cell -> match maps for the cell-ordered window crop of FinePreprocess
             data['_fm_coarse'] = out['_coarse_buffers']
         data.update({'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids,
                      'gt_mask': mconf == 0, 'm_bids': b_ids,
@@ -101,10 +101,10 @@ class FinePreprocess(nn.Module):
             feat1 = torch.empty(0, W ** 2, self.d_model_f, device=feat_f0.device)
             return feat0, feat1
         # windows of the matched cells only (the reference unfolds all L cells, then selects)
-        # The per-window kernel is the default: at 640x480 the fine map stays in L2/MALL and it measured
-        # faster (profiles/README.md); FM_TILED_GATHER=1 selects the cell-tiled kernel instead.
+        # Cell-ordered crop when the ids are this coarse call's own (its cell -> match maps are still in the
+        # workspace): every XCD then reads one band of the map; FM_GATHER=list forces the list-ordered kernel.
         cells0 = cells1 = None
-        buf = data.get('_fm_coarse') if os.environ.get("FM_TILED_GATHER", "0") == "1" else None
+        buf = data.get('_fm_coarse') if os.environ.get("FM_GATHER", "cells") != "list" else None
         if buf is not None and buf.b_ids.data_ptr() == b_ids.data_ptr():     # ids are this coarse call's
             cells0, cells1 = buf.cell_maps()
         with torch.no_grad():

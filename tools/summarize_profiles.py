@@ -24,8 +24,9 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
+    """newest match: gpurun merges results into gpurun_out/ without removing those of earlier calls"""
     f = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def short(name):

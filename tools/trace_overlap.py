@@ -12,7 +12,7 @@ def short(n):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+    skip = 0.3
     ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])) for r in rows)
     t0, t1 = ev[int(len(ev) * skip)][0], ev[-40][1]
     pts = []
