@@ -82,6 +82,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ void glds4(const float* gsrc, float* lds_wave_base) {      // lane l -> base + 4*l
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
 template <int CTRL, int BANK>
 __device__ __forceinline__ float dpp_mov(float old, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
@@ -98,6 +103,14 @@ __device__ __forceinline__ float wave_max64(float v) {
   return v;
 }
 
+// both halves of the wave combine their values (lane l with lane l^32); v_permlane32_swap, no LDS crossbar
+template <bool SUM>
+__device__ __forceinline__ float combine_halves(float v) {
+  float p = v, q = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  return SUM ? p + q : fmaxf(p, q);
+}
+
 // reduction over the 32 lanes that share lane>>5 (max or sum), result in every lane of the half; DPP only
 template <bool SUM>
 __device__ __forceinline__ float half_reduce32(float v) {
@@ -108,6 +121,22 @@ __device__ __forceinline__ float half_reduce32(float v) {
   v = op(v, dpp_mov<0x128, 0xf>(v, v));                                                      // lane ^ 8
   { float p = v, q = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q)); v = op(p, q); }   // ^ 16
   return v;
+}
+
+// LDS accesses of the small tables INSIDE the sweep are inline asm: hipcc orders every LDS access it can
+// see against the outstanding LDS-DMA writes of the tile ring (it cannot tell the objects apart) and put
+// `s_waitcnt vmcnt(0)` in front of each one - i.e. waited for the tile prefetch it had just issued, which
+// serialised the ring (~1 us per tile).  The waits below are ours; outputs are tied to them ("+v").
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ unsigned lds_addr(T* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) T*)p;
+}
+__device__ __forceinline__ void lds_store_b32(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_store_b32(unsigned addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 template <int C, int MODE>
@@ -160,16 +189,27 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
   const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};   // fragment-major
-  float* nmr_lds = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES) + wv * 32;
-  float* meta = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES + 1024);    // [2][META]
+  // Small per-workgroup tables live in their OWN static LDS objects, not in the dynamic tile ring: hipcc
+  // orders every LDS access it can see against outstanding LDS-DMA writes it cannot tell apart from it -
+  // with the tables inside `smem` it put `s_waitcnt vmcnt(0)` in front of each table read, i.e. waited for
+  // the tile prefetch it had just issued (the whole ring was serialised: ~1 us per tile).
+  __shared__ float s_nmr[8 * 32];                 // row stabilisers of the 8 waves' rows
+  __shared__ float s_meta[2 * META];              // per tile: 64 column stabilisers + 16 unit maxima
   // wave-private candidate queue (sum / screening passes): candidates found during the sweep are parked
   // here and handed to the global per-row slot lists once, after the sweep.  (A global atomicAdd with
   // return per find stalls the wave for a memory round trip in the middle of the MFMA pipeline: 10 us of
   // a 43 us sweep at 640x480, where nearly every computed unit holds a match.)
-  int* qkey = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES + 1024 + 640) + wv * kCandQueue;   // (col << 5) | local row
-  float* qx = reinterpret_cast<float*>(smem + NBUF * BUF_BYTES + 1024 + 640 + 8 * kCandQueue * 4) + wv * kCandQueue;
-  int* qcnt = reinterpret_cast<int*>(smem + NBUF * BUF_BYTES + 1024 + 640 + 16 * kCandQueue * 4) + wv;
+  __shared__ int s_qkey[8 * kCandQueue];          // (col << 5) | local row
+  __shared__ float s_qx[8 * kCandQueue];
+  __shared__ int s_qcnt[8];
+  float* nmr_lds = s_nmr + wv * 32;
+  float* meta = s_meta;
+  int* qkey = s_qkey + wv * kCandQueue;
+  float* qx = s_qx + wv * kCandQueue;
+  int* qcnt = s_qcnt + wv;
   if (SPARSE && lane == 0) *qcnt = 0;
+  const unsigned meta_a = lds_addr(meta), nmr_a = lds_addr(nmr_lds), qcnt_a = lds_addr(qcnt), qkey_a = lds_addr(qkey),
+                 qx_a = lds_addr(qx);
 
   // One LDS-DMA instruction copies one 1 KiB fragment block (32 columns x one k-step x one lane half
   // pair) of the fragment-major planes: contiguous in global memory and in LDS.  Tile image in LDS:
@@ -184,21 +224,14 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         glds16(src, smem + buf * BUF_BYTES + p * PLANE_BYTES + blk * 1024);
       }
     }
+    // The tile's metadata travels the same way (one 4-byte LDS-DMA each, so no register carries a global
+    // load across the sweep - hipcc would order every such load against the tile prefetch with vmcnt(0)):
+    // wave 0 brings the 64 column stabilisers, wave 1 the 16 unit maxima of (wave, unit) = (lane/2, lane%2).
+    if (MODE && wv == 0) glds4(a.nmc + (long)b * a.Sp + t * kTileCols + lane, meta + (buf & 1) * META);
+    if (SPARSE && wv == 1 && lane < 16)
+      glds4(a.umax + ((long)b * (a.Lp / 32) + panel * 8 + (lane >> 1)) * (a.Sp / 32) + 2 * t + (lane & 1),
+            meta + (buf & 1) * META + 64);
   };
-  // per-tile metadata travels with the tile: threads 0..63 fetch the column stabilisers, threads
-  // 64..79 the unit maxima of (wave, unit) = ((tid-64)/2, (tid-64)%2); written to LDS before the barrier
-  auto meta_load = [&](int t) -> float {
-    if (MODE && tid < 64) return a.nmc[(long)b * a.Sp + t * kTileCols + tid];
-    if (SPARSE && tid >= 64 && tid < META) {
-      const int w = (tid - 64) >> 1, s = (tid - 64) & 1;
-      return a.umax[((long)b * (a.Lp / 32) + panel * 8 + w) * (a.Sp / 32) + 2 * t + s];
-    }
-    return 0.f;
-  };
-  auto meta_store = [&](int buf, float v) { if (MODE && tid < META) meta[buf * META + tid] = v; };
-
-  float mv = 0.f;
-  if (t0 < t1) mv = meta_load(t0);
 #pragma unroll
   for (int d = 0; d < NBUF - 1; ++d)
     if (t0 + d < t1) stage(t0 + d, d);
@@ -314,6 +347,16 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
   };
 
+  // this lane's 16 row stabilisers (rows 8q + 4h + 0..3 of the wave's 32), four 16-byte LDS reads
+  auto load_nmr = [&](f32x4 (&v)[4]) {
+    const unsigned la = nmr_a + 16 * h;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v[0]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(v[1]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(v[2]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(v[3]) : "v"(la));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+  };
+
   // epilogue of unit u: fold the accumulator into the row / column statistics
   auto epilogue = [&](int u, float nmc) {
     const int col = (u >> 1) * kTileCols + (u & 1) * 32 + r;     // this lane's column
@@ -327,17 +370,18 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         rstat[g] = fmaxf(rstat[g], x);
         cstat = fmaxf(cstat, x);
       }
-      cstat = fmaxf(cstat, __shfl_xor(cstat, 32));
+      cstat = combine_halves<false>(cstat);
       const float um = wave_max64(cstat);                         // block map for the sum pass
       if (lane == 0) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * (a.Sp / 32) + u] = um;
     } else if (MODE == 3) {
       // dense conf_matrix (coarse_matching_new.py:68,70): softmax(sim,1) * softmax(sim,2) from the
       // log-softmax offsets nmr2 = nmr - log2(row sum), nmc2 = nmc - log2(column sum)
       cstat = 0.f;
+      f32x4 nv4[4];
+      load_nmr(nv4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(nmr_lds + 8 * q + 4 * h);
-        const float nm[4] = {v.x, v.y, v.z, v.w};
+        const float nm[4] = {nv4[q][0], nv4[q][1], nv4[q][2], nv4[q][3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = wrow0 + 8 * q + 4 * h + e;
@@ -353,10 +397,13 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       float best4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       cstat = 0.f;
       float nmr[16];
+      {
+        f32x4 nv4[4];
+        load_nmr(nv4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(nmr_lds + 8 * q + 4 * h);
-        nmr[4 * q] = v.x; nmr[4 * q + 1] = v.y; nmr[4 * q + 2] = v.z; nmr[4 * q + 3] = v.w;
+        for (int q = 0; q < 4; ++q) {
+          nmr[4 * q] = nv4[q][0]; nmr[4 * q + 1] = nv4[q][1]; nmr[4 * q + 2] = nv4[q][2]; nmr[4 * q + 3] = nv4[q][3];
+        }
       }
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
@@ -369,7 +416,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         }
         best4[g >> 2] = fmaxf(best4[g >> 2], fminf(rr, cc));
       }
-      if (MODE == 1) cstat += __shfl_xor(cstat, 32);
+      if (MODE == 1) cstat = combine_halves<true>(cstat);
       const float best = fmaxf(fmaxf(best4[0], best4[1]), fmaxf(best4[2], best4[3]));
 #ifdef FM_ABL_NOCAND            // timing-only: no candidate recording
       if (false) {
@@ -392,8 +439,10 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
             const float cc = __builtin_fmaf(x, a.k, nmc);
             const int rl = rbase + e;                             // row inside this wave's 32
             if (rr > a.lt && cc > a.lt && wrow0 + rl < a.L && cvalid) {
-              const int qi = atomicAdd(qcnt, 1);                  // LDS, wave-private
-              if (qi < kCandQueue) { qkey[qi] = (col << 5) | rl; qx[qi] = x; }
+              int qi;                                             // LDS atomic on the wave-private counter
+              { const int one = 1;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(qi) : "v"(qcnt_a), "v"(one) : "memory"); }
+              if (qi < kCandQueue) { lds_store_b32(qkey_a + qi * 4, (col << 5) | rl); lds_store_b32(qx_a + qi * 4, x); }
               else record_candidate((long)b * a.Lp + wrow0 + rl, col, x);     // queue full: straight to the lists
             }
           }
@@ -403,7 +452,6 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     if (MODE <= 1 && h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
   };
 
-  meta_store(0, mv);
   // Tile hand-over: LDS-DMA writes are ordered for other waves' reads only by the issuing wave's vmcnt
   // followed by a barrier.  A counted vmcnt leaves the younger tiles of the ring in flight across the
   // barrier (`__syncthreads()` would drain them: hipcc emits vmcnt(0) in front of it); VMEM returns in
@@ -417,6 +465,16 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   };
   static_assert(NBUF <= 4 && 2 * GLDS_PER_TILE <= 63, "tile_barrier covers at most two tiles in flight");
   tile_barrier(min(NBUF - 2, t1 - t0 - 1));     // first tile and its metadata landed
+  // hipcc does not see the counted waits above (inline asm) and would otherwise wait for everything loaded
+  // before the loop at its first use INSIDE the loop - with `vmcnt(0)`, i.e. also for the tile prefetch just
+  // issued there.  Naming the registers here makes it place that wait now, where everything has landed.
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" ::"v"(ahi[ks]));
+  if (MODE) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" ::"v"(alo[ks]));
+  }
+  asm volatile("" ::"v"(emarg), "v"(wmax_nmr));
 #ifdef FM_DIAG_CLOCK
   diag_pro = __builtin_amdgcn_s_memtime() - diag_c0;
 #endif
@@ -438,13 +496,17 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #ifndef FM_ABL_NOSTAGE   // timing-only ablations (results are wrong): never defined in the shipped build
       if (t + NBUF - 1 < t1) stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF);
 #endif
-      if (t + 1 < t1) mv = meta_load(t + 1);
     }
 
-    const float nmc_u = MODE ? meta[par * META + (u & 1) * 32 + r] : 0.f;
+    float nmc_u = 0.f, um = 0.f;     // column stabiliser of this lane's column; largest raw f16 product of this unit
+    if (MODE) {
+      const unsigned ma = meta_a + (par * META + (u & 1) * 32 + r) * 4, mb = meta_a + (par * META + 64 + wv * 2 + (u & 1)) * 4;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(nmc_u) : "v"(ma));
+      asm volatile("ds_read_b32 %0, %1" : "=v"(um) : "v"(mb));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nmc_u), "+v"(um));
+    }
     bool skip = false;
     if (SPARSE) {
-      const float um = meta[par * META + 64 + wv * 2 + (u & 1)];    // largest raw f16 product of this unit
       const float top = __builtin_fmaf(um, a.k, emarg);             // >= k * (exact product), log2 domain
       const float cmax = wave_max64(t * kTileCols + (u & 1) * 32 + r < a.S ? nmc_u : -INFINITY);
       skip = __builtin_amdgcn_readfirstlane((int)((top + wmax_nmr < -kSkipLog2) && (top + cmax < -kSkipLog2)));
@@ -468,7 +530,6 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       colout[t * kTileCols + (u & 1) * 32 + r] = 0.f;               // skipped unit: contributes nothing
     }
     if (u & 1) {
-      if (t + 1 < t1) meta_store(par ^ 1, mv);
       // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
 #ifndef FM_ABL_NOBAR
       { DIAG_T0 tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1)); DIAG_ADD(diag_bar) }
@@ -515,7 +576,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   }
   commit_candidates();
 #ifdef FM_DIAG_CLOCK       // candidate slots of the padded rows (>= L, never used) carry the stamps of 64 waves
-  if (MODE <= 1 && t1 == a.tiles && panel < 8 && (a.Lp - a.L) * a.slots >= 512 && lane < 8) {
+  if (MODE <= 1 && split == 0 && panel < 8 && (a.Lp - a.L) * a.slots >= 512 && lane < 8) {
     const float vals[8] = {(float)(__builtin_amdgcn_s_memtime() - diag_c0),
                            (float)(__builtin_amdgcn_s_memrealtime() - diag_r0), (float)diag_units, (float)diag_mfma,
                            (float)diag_epi, (float)diag_bar, (float)diag_pro,
@@ -531,7 +592,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 template <int C, int MODE>
 static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
   constexpr int BUF_BYTES = (MODE ? 2 : 1) * kTileCols * C * 2;
-  constexpr int SMEM = (MODE ? 2 : 4) * BUF_BYTES + 8 * 32 * 4 + 2 * 80 * 4 + 16 * kCandQueue * 4 + 64;
+  constexpr int SMEM = (MODE ? 2 : 4) * BUF_BYTES;      // the tile ring; the small tables are static LDS
   static unsigned long long lds_set = 0;      // one flag word per template instance
   hipError_t e = ensure_dynamic_lds(&k_corr<C, MODE>, SMEM, &lds_set);
   if (e != hipSuccess) return e;

@@ -49,7 +49,7 @@ def main():
         torch.cuda.synchronize()
         o = off + lay["cand_conf"] + p.l * slots * 4          # candidate slots of the first padded row
         d = ws[o: o + 512 * 4].view(torch.float32).cpu().numpy().reshape(64, 8)     # [panel*8 + wave, stamp]
-        print(f"mode {mode}: {d.shape[0]} waves of the last split ({lay['splits']} splits, "
+        print(f"mode {mode}: {d.shape[0]} waves of split 0 ({lay['splits']} splits, "
               f"{-(-lay['tiles'] // lay['splits'])} tiles each); clock {np.median(d[:, 0]) / np.median(d[:, 1]) * 0.1:.2f} GHz")
         for k, nme in enumerate(names):
             col = d[:, k]
