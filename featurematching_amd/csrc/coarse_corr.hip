@@ -290,7 +290,6 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       asm volatile("ds_read_b128 %0, %1" : "=v"(bh[ks % RING]) : "v"(la));
       if (MODE) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[ks % RING]) : "v"(la), "i"(PLANE_BYTES));
     };
-    __builtin_amdgcn_s_setprio(1);   // the MFMA phase wins issue arbitration over the SIMD partner's epilogue
 #pragma unroll
     for (int ks = 0; ks < PF && ks < KSTEPS; ++ks) issue(ks);
 #pragma unroll
@@ -338,7 +337,6 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl[ks % RING], acc, 0, 0, 0);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
   };
 
   auto record_candidate = [&](long grow, int col, float x) {
@@ -479,11 +477,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   diag_pro = __builtin_amdgcn_s_memtime() - diag_c0;
 #endif
 
-  // Waves w and w+4 share a SIMD.  The second half of the workgroup runs one epilogue behind the
-  // first, so that on every SIMD one wave's exp/add epilogue overlaps the other's MFMA chain.
-  const bool late = wv >= 4;
-  int pend = -1;            // late waves: unit whose epilogue is still owed (its accumulator is live)
-  float nmc_pend = 0.f;
+  // (Waves w and w+4 share a SIMD; they drift apart by themselves, one in its MFMA chain while the other
+  // runs its epilogue.  A forced one-unit stagger and s_setprio around the chain both measured slower once
+  // the tile ring was truly asynchronous.)
 #ifdef FM_ABL_NOTILES     // timing-only: prologue + final reduction, no sweep
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int u = 2 * t0; u < 2 * t0; ++u) {
@@ -514,7 +510,6 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #ifdef FM_ABL_ALLSKIP     // timing-only: tile streaming and barriers, no unit work
     skip = true;
 #endif
-    if (late && pend >= 0) { DIAG_T0 epilogue(pend, nmc_pend); pend = -1; DIAG_ADD(diag_epi) }
     if (!skip) {
 #ifdef FM_DIAG_CLOCK
       ++diag_units;
@@ -523,8 +518,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #ifdef FM_ABL_NOEPI
       asm volatile("" :: "v"(acc));
 #else
-      if (late) { pend = u; nmc_pend = nmc_u; }
-      else { DIAG_T0 epilogue(u, nmc_u); DIAG_ADD(diag_epi) }
+      { DIAG_T0 epilogue(u, nmc_u); DIAG_ADD(diag_epi) }
 #endif
     } else if (MODE == 1 && h == 0) {
       colout[t * kTileCols + (u & 1) * 32 + r] = 0.f;               // skipped unit: contributes nothing
@@ -536,7 +530,6 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #endif
     }
   }
-  if (late && pend >= 0) { DIAG_T0 epilogue(pend, nmc_pend); DIAG_ADD(diag_epi) }
 #ifdef FM_DIAG_CLOCK
   diag_loop_end = __builtin_amdgcn_s_memtime();
 #endif
