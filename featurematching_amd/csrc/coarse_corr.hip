@@ -53,6 +53,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef FM_PF_MAX
 #define FM_PF_MAX 4
 #endif
+#ifndef FM_NBUF_MAX
+#define FM_NBUF_MAX 4       // LDS tile ring depth of the max pass (32 KiB hi tiles at C = 256)
+#endif
 constexpr float kSkipLog2 = 32.f;     // block-sparse threshold: entries below 2^-32 of every stabiliser
 constexpr int kCandQueue = 64;        // candidates a wave parks in LDS per sweep (one per lane at the hand-over)
 
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   constexpr int BUF_BYTES = PLANES * PLANE_BYTES;
   // LDS tile ring: the max pass needs only the hi plane (32 KiB per tile at C = 256), so it keeps 3 tiles
   // in flight; the other passes (hi + lo) double-buffer.
-  constexpr int NBUF = MODE ? 2 : 4;
+  constexpr int NBUF = MODE ? 2 : FM_NBUF_MAX;
   constexpr int GLDS_PER_TILE = PLANES * (PLANE_BYTES / 1024 / 8);     // LDS-DMA instructions per wave and tile
   constexpr int INSTR_PER_WAVE = PLANE_BYTES / 1024 / 8;
   constexpr bool SPARSE = (MODE == 1 || MODE == 2);
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 template <int C, int MODE>
 static hipError_t launch_corr_t(const CorrArgs& a, int blocks, hipStream_t st) {
   constexpr int BUF_BYTES = (MODE ? 2 : 1) * kTileCols * C * 2;
-  constexpr int SMEM = (MODE ? 2 : 4) * BUF_BYTES;      // the tile ring; the small tables are static LDS
+  constexpr int SMEM = (MODE ? 2 : FM_NBUF_MAX) * BUF_BYTES;      // the tile ring; the small tables are static LDS
   static unsigned long long lds_set = 0;      // one flag word per template instance
   hipError_t e = ensure_dynamic_lds(&k_corr<C, MODE>, SMEM, &lds_set);
   if (e != hipSuccess) return e;
