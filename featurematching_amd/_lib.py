@@ -40,6 +40,8 @@ SIGNATURES = {
     "fm_coarse_cell_maps": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_p),
                                  C.POINTER(_p), C.POINTER(_i), C.POINTER(_p)]),
     "fm_gather_windows_cells": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p]),
+    "fm_merge_pack_weights": (_i, [_p, _i, _p, _p]),
+    "fm_gather_merge_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
 }
 

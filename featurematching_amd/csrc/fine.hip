@@ -27,9 +27,78 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
 // (One workgroup per window, 3776 four-wave workgroups at 640x480, was bound by workgroup launch
 // rate: its time followed the number of workgroups, not the bytes.)
 // ----------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// In-place context merge of one window tile in LDS (fine_preprocess.py:56-59, the window half of
+// merge_feat): tile[r][n] <- sum_k W_w[n][k] * tile[r][k] + ctx[n], r = window position, k/n = channels.
+// (The context half W_c . down_proj(feat_c) + bias does not depend on the position: it arrives as ctx, one
+// row of a per-cell table the caller computes with a plain library GEMM.)  f32-equivalent product on the f16
+// matrix cores, as in the coarse stage: window values and weights are split x = hi + lo (f16 each) and
+// hi*hi + lo*hi + hi*lo is accumulated in f32 (~2^-22 relative).  wpack = the weights pre-split into MFMA B
+// fragments by fm_merge_pack_weights: [n-tile 2][k-step 4][hi|lo][lane 64] x 8 halfs.
 template <int W>
+__device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const half8* __restrict__ wpack,
+                                                const float* __restrict__ ctx_row) {
+  constexpr int WW = W * W, PITCH = 68, MT = (WW + 31) / 32;
+  const int r = lane & 31, h = lane >> 5;
+  const float c0 = ctx_row[r], c1 = ctx_row[32 + r];
+  half8 bhi[2][4], blo[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bhi[nt][ks] = wpack[((nt * 4 + ks) * 2 + 0) * 64 + lane];
+      blo[nt][ks] = wpack[((nt * 4 + ks) * 2 + 1) * 64 + lane];
+    }
+  // A fragments of all window rows first (the tile is overwritten below): lane (r, h) holds row r,
+  // channels 16*ks + 8*h .. +7; rows beyond the window re-read its last row (their outputs are dropped)
+  half8 ahi[MT][4], alo[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = min(32 * mt + r, WW - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float4 p = *reinterpret_cast<const float4*>(tile + row * PITCH + ks * 16 + 8 * h);
+      const float4 q = *reinterpret_cast<const float4*>(tile + row * PITCH + ks * 16 + 8 * h + 4);
+      const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)x[e];
+        ahi[mt][ks][e] = hh;
+        alo[mt][ks][e] = (_Float16)(x[e] - (float)hh);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[g] = nt ? c1 : c0;       // column n = 32*nt + r of the output
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mt][ks], bhi[nt][ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mt][ks], bhi[nt][ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mt][ks], blo[nt][ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = 32 * mt + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (row < WW) tile[row * PITCH + 32 * nt + r] = acc[g];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int W, bool MERGE = false>
 __device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int Wf, int oy, int ox,
-                                                   float* __restrict__ dst, float* tile, int lane) {
+                                                   float* __restrict__ dst, float* tile, int lane,
+                                                   const half8* __restrict__ wpack = nullptr,
+                                                   const float* __restrict__ ctx_row = nullptr) {
   constexpr int CF = 64, WW = W * W, TOTAL = CF * WW, PITCH = CF + 4;
   // lane -> (channel within the instruction, window position) is the same for every load: W = 5 puts two
   // channels x 32 position slots (25 used) in one wave-load, W = 7 one channel x 64 slots (49 used).  Only
@@ -62,6 +131,7 @@ __device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int
   for (int it = 0; it < NLOAD; ++it)
     if (rem < WW) slot[it * CPI] = v[it];
   __builtin_amdgcn_wave_barrier();       // same-wave LDS accesses are processed in order: no s_barrier needed
+  if (MERGE) wave_merge_tile<W>(tile, lane, wpack, ctx_row);
   float4* dst4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
   for (int it = 0; it < (TOTAL / 4 + 63) / 64; ++it) {
@@ -81,12 +151,13 @@ __device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int
 constexpr int kGatherTileFloats(int W) { return W * W * 68; }
 
 // list order: window m of the match list (any ids; the generic entry point)
-template <int W>
+template <int W, bool MERGE>
 __global__ __launch_bounds__(256) void k_gather_nchw64(const float* __restrict__ feat, int Hf, int Wf, int stride,
                                                        int pad, int w_c, const int64_t* __restrict__ b_ids,
                                                        const int64_t* __restrict__ ids,
                                                        const int32_t* __restrict__ d_count, int m_max,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, const half8* __restrict__ wpack,
+                                                       const float* __restrict__ ctx, int ctx_cells) {
   constexpr int CF = 64, TOTAL = CF * W * W;
   __shared__ __attribute__((aligned(16))) float tile[4 * kGatherTileFloats(W)];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -99,8 +170,9 @@ __global__ __launch_bounds__(256) void k_gather_nchw64(const float* __restrict__
   const int b = __builtin_amdgcn_readfirstlane((int)b_ids[m]);       // wave-uniform values into scalars
   const int id = __builtin_amdgcn_readfirstlane((int)ids[m]);
   const int cy = id / w_c;
-  wave_copy_window64<W>(feat + (long)b * CF * Hf * Wf, Hf, Wf, cy * stride - pad, (id - cy * w_c) * stride - pad,
-                        out + (long)m * TOTAL, tile + wv * kGatherTileFloats(W), lane);
+  wave_copy_window64<W, MERGE>(feat + (long)b * CF * Hf * Wf, Hf, Wf, cy * stride - pad, (id - cy * w_c) * stride - pad,
+                               out + (long)m * TOTAL, tile + wv * kGatherTileFloats(W), lane, wpack,
+                               MERGE ? ctx + ((long)b * ctx_cells + id) * CF : nullptr);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -113,7 +185,7 @@ __global__ __launch_bounds__(256) void k_gather_nchw64(const float* __restrict__
 // waves of the grid, one each; if that list overflowed (> kTieCap) every wave scans its slice of the
 // match list instead.
 // ----------------------------------------------------------------------------------------
-template <int W>
+template <int W, bool MERGE>
 __global__ __launch_bounds__(256) void k_gather_cellorder64(const float* __restrict__ feat, int Hf, int Wf, int stride,
                                                             int pad, int w_c, int cells, int total_cells,
                                                             const int32_t* __restrict__ cell_to_match, int cell_pitch,
@@ -121,7 +193,9 @@ __global__ __launch_bounds__(256) void k_gather_cellorder64(const float* __restr
                                                             const int64_t* __restrict__ b_ids,
                                                             const int64_t* __restrict__ ids,
                                                             const int32_t* __restrict__ d_count, int m_max,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out,
+                                                            const half8* __restrict__ wpack,
+                                                            const float* __restrict__ ctx) {
   constexpr int CF = 64, TOTAL = CF * W * W;
   __shared__ __attribute__((aligned(16))) float tile_all[4 * kGatherTileFloats(W)];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -147,8 +221,9 @@ __global__ __launch_bounds__(256) void k_gather_cellorder64(const float* __restr
       jm = __builtin_amdgcn_readfirstlane(jm); jb = __builtin_amdgcn_readfirstlane(jb);
       jcell = __builtin_amdgcn_readfirstlane(jcell);
       const int cy = jcell / w_c;
-      wave_copy_window64<W>(feat + (long)jb * CF * Hf * Wf, Hf, Wf, cy * stride - pad, (jcell - cy * w_c) * stride - pad,
-                            out + (long)jm * TOTAL, tile, lane);
+      wave_copy_window64<W, MERGE>(feat + (long)jb * CF * Hf * Wf, Hf, Wf, cy * stride - pad,
+                                   (jcell - cy * w_c) * stride - pad, out + (long)jm * TOTAL, tile, lane, wpack,
+                                   MERGE ? ctx + ((long)jb * cells + jcell) * CF : nullptr);
     }
     jm = -1;
     if (mode == 0) break;                                                // the common case: no exact ties
@@ -381,6 +456,39 @@ __global__ __launch_bounds__(256) void k_fine(const float* __restrict__ win0, co
 
 using namespace fm;
 
+// ---- launch helpers shared by the plain and the merging entry points ----
+template <bool MERGE>
+static void launch_list64(int W, int blocks, hipStream_t st, const float* feat_f, int Hf, int Wf, int stride, int pad,
+                          int w_c, const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max,
+                          float* out, const half8* wpack, const float* ctx, int ctx_cells) {
+  if (W == 5)
+    hipLaunchKernelGGL((k_gather_nchw64<5, MERGE>), dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
+                       b_ids, ids, d_count, m_max, out, wpack, ctx, ctx_cells);
+  else
+    hipLaunchKernelGGL((k_gather_nchw64<7, MERGE>), dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
+                       b_ids, ids, d_count, m_max, out, wpack, ctx, ctx_cells);
+}
+template <bool MERGE>
+static void launch_cells64(int W, int blocks, hipStream_t st, const float* feat_f, int Hf, int Wf, int stride, int pad,
+                           int w_c, int cells, int total, const int32_t* cell_to_match, int cell_pitch,
+                           const int32_t* ties, const int64_t* b_ids, const int64_t* ids, const int32_t* d_count,
+                           int m_max, float* out, const half8* wpack, const float* ctx) {
+  if (W == 5)
+    hipLaunchKernelGGL((k_gather_cellorder64<5, MERGE>), dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad,
+                       w_c, cells, total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, wpack, ctx);
+  else
+    hipLaunchKernelGGL((k_gather_cellorder64<7, MERGE>), dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad,
+                       w_c, cells, total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, wpack, ctx);
+}
+// the fast NCHW kernels address one sample's map with 31-bit byte offsets (buffer descriptor)
+static bool fast_nchw64(int Cf, int Hf, int Wf, int W) {
+  return Cf == 64 && (W == 5 || W == 7) && (long)Hf * Wf * 64 * 4 < (1L << 31);
+}
+// 8 XCD ranges of ceil(M/8) windows, four windows (waves) per workgroup
+static int list_blocks(int m_max) { return 8 * (((m_max + 7) / 8 + 3) / 4); }
+// one wave per cell, four per workgroup, grid a multiple of 8
+static int cell_blocks(long total) { return (int)(((total + 3) / 4 + 7) / 8 * 8); }
+
 extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int layout, int W, int stride,
                                  int pad, int w_c, const int64_t* b_ids, const int64_t* ids, const int32_t* d_count,
                                  int m_max, float* out, void* stream) {
@@ -389,16 +497,9 @@ extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int
   if (N <= 0 || Cf <= 0 || Hf <= 0 || Wf <= 0 || W <= 0 || stride <= 0 || w_c <= 0 || m_max < 0) return FM_E_SHAPE;
   if (W > 15 || Cf > 512 || (layout == 1 && Cf % 4) || (layout != 0 && layout != 1)) return FM_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  // the fast NCHW kernels address one sample's map with 31-bit byte offsets (buffer descriptor)
-  if (layout == 0 && Cf == 64 && (W == 5 || W == 7) && (long)Hf * Wf * 64 * 4 < (1L << 31)) {
-    // 8 XCD ranges of ceil(M/8) windows, four windows (waves) per workgroup
-    const int blocks = 8 * (((m_max + 7) / 8 + 3) / 4);
-    if (W == 5)
-      hipLaunchKernelGGL(k_gather_nchw64<5>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
-                         ids, d_count, m_max, out);
-    else
-      hipLaunchKernelGGL(k_gather_nchw64<7>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c, b_ids,
-                         ids, d_count, m_max, out);
+  if (layout == 0 && fast_nchw64(Cf, Hf, Wf, W)) {
+    launch_list64<false>(W, list_blocks(m_max), st, feat_f, Hf, Wf, stride, pad, w_c, b_ids, ids, d_count, m_max, out,
+                         nullptr, nullptr, 0);
   } else if (layout == 0) {
     const size_t smem = (size_t)W * W * (Cf + 1) * sizeof(float);
     if (smem > 64 * 1024) return FM_E_UNSUPPORTED;
@@ -419,16 +520,58 @@ extern "C" int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int H
   if (!feat_f || !cell_to_match || !ties || !b_ids || !ids || !out) return FM_E_NULL;
   if (N <= 0 || Hf <= 0 || Wf <= 0 || h_c <= 0 || w_c <= 0 || stride <= 0 || m_max < 0 || cell_pitch < h_c * w_c)
     return FM_E_SHAPE;
-  if (Cf != 64 || (W != 5 && W != 7) || (long)Hf * Wf * 64 * 4 >= (1L << 31)) return FM_E_UNSUPPORTED;
+  if (!fast_nchw64(Cf, Hf, Wf, W)) return FM_E_UNSUPPORTED;
+  const long total = (long)N * h_c * w_c;
+  launch_cells64<false>(W, cell_blocks(total), (hipStream_t)stream, feat_f, Hf, Wf, stride, pad, w_c, h_c * w_c,
+                        (int)total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, nullptr, nullptr);
+  return (int)hipGetLastError();
+}
+
+// merge_feat.weight[:, :64] (row-major [64, 128], fine_preprocess.py:26) -> MFMA B fragments, f16 hi and lo:
+// packed[((nt*4 + ks)*2 + plane)*64 + lane][j] = plane(W_w[32*nt + lane%32][16*ks + 8*(lane/32) + j])
+__global__ __launch_bounds__(256) void k_merge_pack(const float* __restrict__ merge_w, half8* __restrict__ packed) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // (nt, ks, lane): 2 * 4 * 64 = 512
+  if (idx >= 512) return;
+  const int lane = idx & 63, ks = (idx >> 6) & 3, nt = idx >> 8;
+  const float* src = merge_w + (32 * nt + (lane & 31)) * 128 + 16 * ks + 8 * (lane >> 5);
+  half8 hh, ll;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = src[j];
+    hh[j] = (_Float16)x;
+    ll[j] = (_Float16)(x - (float)hh[j]);
+  }
+  packed[((nt * 4 + ks) * 2 + 0) * 64 + lane] = hh;
+  packed[((nt * 4 + ks) * 2 + 1) * 64 + lane] = ll;
+}
+
+extern "C" int fm_merge_pack_weights(const float* merge_w, int Cf, void* packed, void* stream) {
+  if (!merge_w || !packed) return FM_E_NULL;
+  if (Cf != 64) return FM_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_merge_pack, dim3(2), dim3(256), 0, (hipStream_t)stream, merge_w, (half8*)packed);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fm_gather_merge_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int W, int stride, int pad,
+                                       int h_c, int w_c, const int32_t* cell_to_match, int cell_pitch,
+                                       const int32_t* ties, const void* packed_w, const float* ctx_bias,
+                                       const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max,
+                                       float* out, void* stream) {
+  if (m_max == 0) return FM_OK;
+  if (!feat_f || !packed_w || !ctx_bias || !b_ids || !ids || !out) return FM_E_NULL;
+  if (cell_to_match && !ties) return FM_E_NULL;
+  if (N <= 0 || Hf <= 0 || Wf <= 0 || h_c <= 0 || w_c <= 0 || stride <= 0 || m_max < 0) return FM_E_SHAPE;
+  if (cell_to_match && cell_pitch < h_c * w_c) return FM_E_SHAPE;
+  if (!fast_nchw64(Cf, Hf, Wf, W)) return FM_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const long total = (long)N * h_c * w_c;                 // one wave per cell, four per workgroup
-  const int blocks = (int)(((total + 3) / 4 + 7) / 8 * 8);
-  if (W == 5)
-    hipLaunchKernelGGL(k_gather_cellorder64<5>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
-                       h_c * w_c, (int)total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out);
+  const long total = (long)N * h_c * w_c;
+  if (cell_to_match)
+    launch_cells64<true>(W, cell_blocks(total), st, feat_f, Hf, Wf, stride, pad, w_c, h_c * w_c, (int)total,
+                         cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, (const half8*)packed_w,
+                         ctx_bias);
   else
-    hipLaunchKernelGGL(k_gather_cellorder64<7>, dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
-                       h_c * w_c, (int)total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out);
+    launch_list64<true>(W, list_blocks(m_max), st, feat_f, Hf, Wf, stride, pad, w_c, b_ids, ids, d_count, m_max, out,
+                        (const half8*)packed_w, ctx_bias, h_c * w_c);
   return (int)hipGetLastError();
 }
 

@@ -19,6 +19,7 @@ import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 
@@ -91,6 +92,26 @@ class FinePreprocess(nn.Module):
             if p.dim() > 1:
                 nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
 
+    def _fused_ok(self, feat_f0, feat_f1, W) -> bool:
+        """The fused crop+merge kernel serves eval mode (no autograd through the two Linear layers) on NCHW
+        maps with 64 fine channels and W in {5,7}; FM_FUSED_MERGE=0 forces the two-step path."""
+        return not self.training and self.d_model_f == 64 and W in (5, 7) and feat_f0.shape[1] == 64 \
+            and feat_f0.is_contiguous() and feat_f1.is_contiguous() and os.environ.get("FM_FUSED_MERGE", "1") != "0"
+
+    def _merge_constants(self):
+        """(packed W_w fragments, E = W_c . down_proj.weight [64, C], e = W_c . down_proj.bias + merge bias),
+        cached until one of the four parameters changes (in-place updates bump torch's version counters)."""
+        ps = (self.down_proj.weight, self.down_proj.bias, self.merge_feat.weight, self.merge_feat.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, '_merge_key', None) != key:
+            cf = self.d_model_f
+            w_c = self.merge_feat.weight[:, cf:].float()
+            self._merge_cache = (ops.pack_merge_weights(self.merge_feat.weight.detach()),
+                                 (w_c @ self.down_proj.weight.float()).detach().contiguous(),
+                                 (w_c @ self.down_proj.bias.float() + self.merge_feat.bias.float()).detach().contiguous())
+            self._merge_key = key
+        return self._merge_cache
+
     def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
         W = self.W
         stride = data['hw0_f'][0] // data['hw0_c'][0]
@@ -107,12 +128,23 @@ class FinePreprocess(nn.Module):
         buf = data.get('_fm_coarse') if os.environ.get("FM_GATHER", "cells") != "list" else None
         if buf is not None and buf.b_ids.data_ptr() == b_ids.data_ptr():     # ids are this coarse call's
             cells0, cells1 = buf.cell_maps()
+        hw0_c, hw1_c = data['hw0_c'], data['hw1_c']
+        if self.cat_c_feat and self._fused_ok(feat_f0, feat_f1, W):
+            # inference: crop + merge in one HIP kernel (fm_gather_merge_windows); the un-merged windows never
+            # reach memory.  The position-independent half of merge_feat becomes a per-cell table (plain GEMMs).
+            with torch.no_grad():
+                packed, e_w, e_b = self._merge_constants()
+                ctx0 = F.linear(feat_c0.float(), e_w, e_b)          # [N, L, 64] = W_c.(down_proj(feat_c)) + bias
+                ctx1 = F.linear(feat_c1.float(), e_w, e_b)
+                win0 = ops.gather_merge_windows(feat_f0, packed, ctx0, b_ids, i_ids, W, stride, hw0_c[0], hw0_c[1],
+                                                cells=cells0)
+                win1 = ops.gather_merge_windows(feat_f1, packed, ctx1, b_ids, j_ids, W, stride, hw1_c[0], hw1_c[1],
+                                                cells=cells1)
+            return win0, win1
         with torch.no_grad():
-            win0 = ops.gather_windows(feat_f0, b_ids, i_ids, W, stride, data['hw0_c'][1], cells=cells0,
-                                      h_c=data['hw0_c'][0])
-            win1 = ops.gather_windows(feat_f1, b_ids, j_ids, W, stride, data['hw1_c'][1], cells=cells1,
-                                      h_c=data['hw1_c'][0])
-        if self.cat_c_feat:
+            win0 = ops.gather_windows(feat_f0, b_ids, i_ids, W, stride, hw0_c[1], cells=cells0, h_c=hw0_c[0])
+            win1 = ops.gather_windows(feat_f1, b_ids, j_ids, W, stride, hw1_c[1], cells=cells1, h_c=hw1_c[0])
+        if self.cat_c_feat:      # training (autograd through the two Linear layers) or shapes outside the fused kernel
             feat_c_win = self.down_proj(torch.cat([feat_c0[b_ids, i_ids], feat_c1[b_ids, j_ids]], 0))
             feat_cf_win = self.merge_feat(torch.cat([
                 torch.cat([win0, win1], 0),

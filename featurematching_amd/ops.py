@@ -184,6 +184,45 @@ def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor,
     return out
 
 
+def pack_merge_weights(merge_w: torch.Tensor) -> torch.Tensor:
+    """merge_feat.weight [64, 128] -> the 16 KiB MFMA fragment buffer fm_gather_merge_windows reads."""
+    lib = _lib.load()
+    w = _f32c(merge_w, "merge_w")
+    if tuple(w.shape) != (64, 128):
+        raise ValueError(f"merge_feat.weight must be [64, 128], got {tuple(w.shape)}")
+    packed = torch.empty(16384, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.fm_merge_pack_weights(_ptr(w), 64, _ptr(packed), _stream(w.device)), "fm_merge_pack_weights")
+    return packed
+
+
+def gather_merge_windows(feat_f: torch.Tensor, packed_w: torch.Tensor, ctx_bias: torch.Tensor, b_ids: torch.Tensor,
+                         ids: torch.Tensor, w: int, stride: int, h_c: int, w_c: int, pad: int = 2,
+                         count: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                         cells=None) -> torch.Tensor:
+    """Window crop fused with FinePreprocess's context merge (fine_preprocess.py:43-60): returns
+    merge_feat(cat[window, down_proj(feat_c)]) for the selected cells, [M, WW, 64].  ctx_bias [N, h_c*w_c, 64]
+    is the position-independent half (W_c . down_proj(feat_c) + bias) per coarse cell."""
+    lib = _lib.load()
+    if not feat_f.is_cuda:
+        raise RuntimeError("feat_f must live on the GPU: the HIP path has no CPU fallback")
+    n, cf, hf, wf = feat_f.shape
+    feat_f = _f32c(feat_f, "feat_f")
+    ctx_bias = _f32c(ctx_bias, "ctx_bias")
+    if tuple(ctx_bias.shape) != (n, h_c * w_c, 64):
+        raise ValueError(f"ctx_bias must be [{n}, {h_c * w_c}, 64], got {tuple(ctx_bias.shape)}")
+    m_max = int(b_ids.shape[0])
+    if out is None:
+        out = torch.empty(m_max, w * w, cf, dtype=torch.float32, device=feat_f.device)
+    if m_max == 0:
+        return out
+    cm, cp, ct = (C.c_void_p(cells[0]), int(cells[1]), C.c_void_p(cells[2])) if cells is not None else (None, 0, None)
+    st = lib.fm_gather_merge_windows(_ptr(feat_f), n, cf, hf, wf, w, stride, pad, int(h_c), int(w_c), cm, cp, ct,
+                                     _ptr(packed_w), _ptr(ctx_bias), _ptr(b_ids), _ptr(ids), _ptr(count), m_max,
+                                     _ptr(out), _stream(feat_f.device))
+    _lib.check(st, "fm_gather_merge_windows")
+    return out
+
+
 def fine_match(win0: torch.Tensor, win1: torch.Tensor, mix0: torch.Tensor, mix1: torch.Tensor,
                mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor, scale_f: float,
                count: Optional[torch.Tensor] = None):

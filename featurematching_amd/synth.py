@@ -100,6 +100,20 @@ def mix_weights(seed: int, ww: int):
 
 
 # The five BASELINE.json configurations, as (name -> dict) used by tests and bench.
+def merge_weights(seed: int, c: int, cf: int):
+    """Weights of FinePreprocess's two Linear layers (fine_preprocess.py:25-26), torch's default init range:
+    (down_w [cf, c], down_b [cf], merge_w [cf, 2*cf], merge_b [cf]) float32, U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+    def lin(stream, fan_out, fan_in):
+        bound = 1.0 / np.sqrt(float(fan_in))
+        u = uniform(seed, stream, fan_out * fan_in + fan_out)
+        w = ((2.0 * u[:fan_out * fan_in] - 1.0) * bound).astype(np.float32).reshape(fan_out, fan_in)
+        b = ((2.0 * u[fan_out * fan_in:] - 1.0) * bound).astype(np.float32)
+        return w, b
+    dw, db = lin(21, cf, c)
+    mw, mb = lin(22, cf, 2 * cf)
+    return dw, db, mw, mb
+
+
 CONFIGS = {
     "cfg1": dict(n=1, h=128, w=128, c=64, cf=64, seed=0),
     "cfg2": dict(n=1, h=480, w=640, c=256, cf=64, seed=1),

@@ -133,6 +133,25 @@ int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int Hf, int Wf, 
                             float* out, void* stream);
 
 /*
+ * Window crop FUSED with the context merge of FinePreprocess (fine_preprocess.py:52-60,
+ * fine_concat_coarse_feat = True - the reference's only working setting):
+ *     out[m, r, :] = W_w . window[m, r, :] + ctx_bias[b_m, cell_m, :]
+ * where merge_feat.weight = [W_w | W_c] ([64, 128]) and
+ *     ctx_bias[b, cell, :] = W_c . (down_proj.weight . feat_c[b, cell, :] + down_proj.bias) + merge_feat.bias
+ * is a per-cell table [N, h_c*w_c, 64] the caller computes with two plain GEMMs (it does not depend on the
+ * window position).  The un-merged windows never reach memory.  packed_w = 16 KiB device buffer filled once
+ * per weight update by fm_merge_pack_weights(merge_feat.weight [64,128] row-major).  The product runs as
+ * hi/lo-split f16 MFMAs with f32 accumulation (f32-equivalent, ~2^-22 relative).
+ * cell_to_match / ties as in fm_gather_windows_cells, or both NULL for list order.  NCHW, Cf = 64, W in {5,7}.
+ */
+int fm_merge_pack_weights(const float* merge_w, int Cf, void* packed_w, void* stream);
+int fm_gather_merge_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int W, int stride, int pad,
+                            int h_c, int w_c, const int32_t* cell_to_match, int cell_pitch, const int32_t* ties,
+                            const void* packed_w, const float* ctx_bias,
+                            const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max,
+                            float* out, void* stream);
+
+/*
  * Fine stage (fine_matching_new.py:50-79): dual-direction window correlation,
  * softmax heat-map, spatial expectation, std.  win0/win1 [m_max, WW, Cf];
  * mix0/mix1 [dev] float32 [WW+1] = Linear(WW,1) weight then bias;

@@ -135,6 +135,34 @@ def full_case(name, cfgname, dist, with_fine=True, n=None):
     print(f"{name}: M={out['i_ids'].shape[0]}")
 
 
+def merge_case(name, cfgname, dist, w):
+    """FinePreprocess as the reference runs it (fine_concat_coarse_feat=True, fine_preprocess.py:52-60) with
+    seeded down_proj / merge_feat weights: per-window checksums of the merged windows + the first 3 in full."""
+    cfg = dict(synth.CONFIGS[cfgname])
+    sh = synth.config_shapes(cfg)
+    f0, f1 = synth.coarse_descriptors(cfg['seed'], cfg['n'], sh['l'], cfg['c'], dist)
+    hw_i, hw_c = (cfg['h'], cfg['w']), (sh['hc'], sh['wc'])
+    data = ref_coarse(f0, f1, hw_i, hw_i, hw_c, hw_c)
+    ff0, ff1 = synth.fine_maps(cfg['seed'], cfg['n'], cfg['cf'], sh['hf'], sh['wf'])
+    dw, db, mw, mb = synth.merge_weights(cfg['seed'], cfg['c'], cfg['cf'])
+    fp = FinePreprocess({'fine_concat_coarse_feat': True, 'fine_window_size': w,
+                         'coarse': {'d_model': cfg['c']}, 'fine': {'d_model': cfg['cf']}}).eval()
+    with torch.no_grad():
+        fp.down_proj.weight.copy_(torch.as_tensor(dw)); fp.down_proj.bias.copy_(torch.as_tensor(db))
+        fp.merge_feat.weight.copy_(torch.as_tensor(mw)); fp.merge_feat.bias.copy_(torch.as_tensor(mb))
+        d = dict(data, hw0_f=(sh['hf'], sh['wf']), hw1_f=(sh['hf'], sh['wf']))
+        m0, m1 = fp(torch.as_tensor(ff0), torch.as_tensor(ff1), torch.as_tensor(f0), torch.as_tensor(f1), d)
+    pos = torch.arange(1, w * w + 1, dtype=torch.float64).view(1, w * w, 1)
+    ch = torch.arange(1, cfg['cf'] + 1, dtype=torch.float64).view(1, 1, -1)
+    out = pack_coarse(data)
+    out.update(meta=np.array([cfg['n'], cfg['h'], cfg['w'], cfg['c'], cfg['cf'], cfg['seed'], w], np.int64),
+               merged0_sum=(m0.double() * pos * ch).sum((1, 2)).numpy(),
+               merged1_sum=(m1.double() * pos * ch).sum((1, 2)).numpy(),
+               merged0_head=m0[:3].numpy(), merged1_head=m1[:3].numpy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: M={out['i_ids'].shape[0]}")
+
+
 def kat_cases():
     """Small adversarial known-answer cases; inputs are stored with the outputs."""
     cases = {}
@@ -197,3 +225,5 @@ if __name__ == "__main__":
     full_case("cfg2_borderline", "cfg2", "borderline")
     full_case("cfg3_first2_peaky", "cfg3", "peaky", n=2)
     full_case("cfg5_peaky", "cfg5", "peaky", with_fine=False)
+    merge_case("merge_cfg1_w7", "cfg1", "peaky", 7)
+    merge_case("merge_cfg2_w5", "cfg2", "borderline", 5)

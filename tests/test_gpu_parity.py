@@ -343,3 +343,67 @@ def test_cell_ordered_gather_equals_list_ordered_gather(w):
         got = ops.gather_windows(t, o['b_ids'], ids, w, 4, wc, cells=cells, h_c=hc)
         assert torch.equal(got, ref)
         assert torch.equal(ref.cpu(), orc.crop_windows(ff, o['b_ids'].cpu(), ids.cpu(), w, 4, wc))
+
+
+# ------------------------------------------------------------------ crop fused with the context merge (row a5)
+@pytest.mark.parametrize("name,dist", [("merge_cfg1_w7", "peaky"), ("merge_cfg2_w5", "borderline")])
+def test_fused_crop_and_context_merge(name, dist):
+    """fm_gather_merge_windows (crop + merge_feat(cat[window, down_proj(feat_c)]), fine_preprocess.py:43-60) against
+    the reference module's own output (fixture) and the oracle, in list order and in cell order."""
+    g = load_golden(name)
+    w = int(g['meta'][6])
+    c = case_inputs(g['meta'][:6], dist)
+    hc, wc = c['hw_c']
+    dw, db, mw, mb = (torch.as_tensor(a, device=DEV) for a in synth.merge_weights(c['cfg']['seed'], c['cfg']['c'], 64))
+    fc0, fc1 = torch.as_tensor(c['f0'], device=DEV), torch.as_tensor(c['f1'], device=DEV)
+    buf = ops.coarse_match_async(fc0, fc1, c['hw_c'], c['hw_c'], 8.0)
+    m = buf.read_count()
+    o = buf.sliced(m)
+    assert np.array_equal(o['i_ids'].cpu().numpy(), g['i_ids']) and np.array_equal(o['j_ids'].cpu().numpy(), g['j_ids'])
+    packed = ops.pack_merge_weights(mw)
+    w_c = mw[:, 64:]
+    e_w, e_b = (w_c @ dw).contiguous(), (w_c @ db + mb).contiguous()
+    ref0, ref1 = orc.fine_preprocess(c['ff0'], c['ff1'], c['f0'], c['f1'], g['b_ids'], g['i_ids'], g['j_ids'], w, 4, wc, wc,
+                                     down_proj=(dw.cpu(), db.cpu()), merge_feat=(mw.cpu(), mb.cpu()))
+    pos = torch.arange(1, w * w + 1, dtype=torch.float64).view(1, w * w, 1)
+    ch = torch.arange(1, 65, dtype=torch.float64).view(1, 1, -1)
+    cells = buf.cell_maps()
+    for ff, fc, ids, ref, key, cm in ((c['ff0'], fc0, o['i_ids'], ref0, 'merged0', cells[0]),
+                                      (c['ff1'], fc1, o['j_ids'], ref1, 'merged1', cells[1])):
+        ctx = torch.nn.functional.linear(fc, e_w, e_b)
+        t = torch.as_tensor(ff, device=DEV)
+        for use_cells in (None, cm):
+            got = ops.gather_merge_windows(t, packed, ctx, o['b_ids'], ids, w, 4, hc, wc, cells=use_cells).cpu()
+            assert (got - ref).abs().max().item() <= 2e-5
+            np.testing.assert_allclose(got[:3].numpy(), g[key + '_head'], rtol=0, atol=2e-5)
+            # weighted checksum of all windows against the reference's: 1e-6 of the total weight (elementwise
+            # errors of ~1e-6 add up over W*W*64 weighted terms)
+            np.testing.assert_allclose((got.double() * pos * ch).sum((1, 2)).numpy(), g[key + '_sum'], rtol=0,
+                                       atol=1e-6 * float((pos * ch).sum()))
+
+
+def test_fine_preprocess_module_fused_equals_two_step(monkeypatch):
+    """modules.FinePreprocess in eval mode (fused HIP crop+merge) against its own two-step path (HIP crop, then
+    the two nn.Linear layers), random weights, W = 7 with a tie-free cfg1 case."""
+    g = load_golden("cfg1_peaky")
+    inp = case_inputs(g['meta'], "peaky")
+    cfg = {'fine_concat_coarse_feat': True, 'fine_window_size': 7, 'coarse': {'d_model': 64}, 'fine': {'d_model': 64}}
+    cm = modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1}).eval()
+    torch.manual_seed(3)
+    fp = modules.FinePreprocess(cfg).to(DEV).eval()
+    data = {'hw0_i': inp['hw_i'], 'hw1_i': inp['hw_i'], 'hw0_c': inp['hw_c'], 'hw1_c': inp['hw_c'],
+            'hw0_f': inp['hw_f'], 'hw1_f': inp['hw_f'], 'bs': 1}
+    fc0, fc1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    ff0, ff1 = torch.as_tensor(inp['ff0'], device=DEV), torch.as_tensor(inp['ff1'], device=DEV)
+    cm(fc0, fc1, data)
+    with torch.no_grad():
+        a0, a1 = fp(ff0, ff1, fc0, fc1, data)
+        monkeypatch.setenv("FM_FUSED_MERGE", "0")
+        b0, b1 = fp(ff0, ff1, fc0, fc1, data)
+        monkeypatch.delenv("FM_FUSED_MERGE")
+        with torch.no_grad():
+            fp.merge_feat.bias.add_(1.0)            # an in-place weight update must invalidate the cached constants
+        c0, _ = fp(ff0, ff1, fc0, fc1, data)
+    scale = max(1.0, b0.abs().max().item())
+    assert (a0 - b0).abs().max().item() <= 2e-5 * scale and (a1 - b1).abs().max().item() <= 2e-5 * scale
+    assert (c0 - (b0 + 1.0)).abs().max().item() <= 2e-5 * scale

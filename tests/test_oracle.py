@@ -116,3 +116,22 @@ def test_synth_is_portable():
     assert p.tolist() == [9, 0, 8, 3, 7, 5, 2, 4, 6, 1]
     f0, f1 = synth.coarse_descriptors(1, 1, 16, 8, "peaky")
     assert f0.shape == (1, 16, 8) and abs(float(f0.std()) - 4.0) < 1.0
+
+
+@pytest.mark.parametrize("name,dist", [("merge_cfg1_w7", "peaky"), ("merge_cfg2_w5", "borderline")])
+def test_context_merge_matches_reference(name, dist):
+    """fine_preprocess.py:52-60 (down_proj + merge_feat over [2M, WW, 2*Cf]) with seeded weights: the oracle's
+    merged windows against the reference module's own output (checksums of all, first three in full)."""
+    g = load_golden(name)
+    w = int(g['meta'][6])
+    c = case_inputs(g['meta'][:6], dist)
+    dw, db, mw, mb = synth.merge_weights(c['cfg']['seed'], c['cfg']['c'], c['cfg']['cf'])
+    m0, m1 = orc.fine_preprocess(c['ff0'], c['ff1'], c['f0'], c['f1'], g['b_ids'], g['i_ids'], g['j_ids'], w, 4,
+                                 c['hw_c'][1], c['hw_c'][1], down_proj=(torch.as_tensor(dw), torch.as_tensor(db)),
+                                 merge_feat=(torch.as_tensor(mw), torch.as_tensor(mb)))
+    pos = torch.arange(1, w * w + 1, dtype=torch.float64).view(1, w * w, 1)
+    ch = torch.arange(1, c['cfg']['cf'] + 1, dtype=torch.float64).view(1, 1, -1)
+    for m, key in ((m0, 'merged0'), (m1, 'merged1')):
+        np.testing.assert_allclose(m[:3].numpy(), g[key + '_head'], rtol=0, atol=2e-5)
+        s = (m.double() * pos * ch).sum((1, 2)).numpy()
+        np.testing.assert_allclose(s, g[key + '_sum'], rtol=0, atol=5e-2)       # sums of ~1e5 weighted terms
