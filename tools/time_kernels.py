@@ -81,6 +81,13 @@ def main():
         p.ff0, buf.b_ids, buf.i_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win0, cells=c0, h_c=p.hw_c[0]), a.iters)))
     rows.append(("  gather image 1, cell order", timed(lambda: ops.gather_windows(
         p.ff1, buf.b_ids, buf.j_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win1, cells=c1, h_c=p.hw_c[0]), a.iters)))
+    mw = torch.as_tensor(synth.merge_weights(7, p.c, 64)[2], device=dev)
+    packed = ops.pack_merge_weights(mw)
+    ctx = torch.randn(p.n, p.l, 64, device=dev)
+    rows.append(("  crop + context merge, image 0", timed(lambda: ops.gather_merge_windows(
+        p.ff0, packed, ctx, buf.b_ids, buf.i_ids, w, 4, p.hw_c[0], p.hw_c[1], count=buf.count, out=p.win0, cells=c0), a.iters)))
+    rows.append(("  crop + context merge, image 1", timed(lambda: ops.gather_merge_windows(
+        p.ff1, packed, ctx, buf.b_ids, buf.j_ids, w, 4, p.hw_c[0], p.hw_c[1], count=buf.count, out=p.win1, cells=c1), a.iters)))
     rows.append(("fine match", timed(lambda: ops.fine_match(p.win0, p.win1, p.mix0, p.mix1, buf.mkpts0_c, buf.mkpts1_c,
                                                               2.0, count=buf.count), a.iters)))
     rows.append(("whole step (eager)", timed(lambda: p.step(), a.iters)))
