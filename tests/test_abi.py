@@ -61,6 +61,22 @@ def test_workspace_query_and_argument_checks():
     assert lib.fm_gather_windows(null, 1, 64, 8, 8, 0, 7, 4, 2, 2, null, null, null, 0, null, null) == 0   # M == 0
     assert lib.fm_fine_match(null, null, 0, null, 49, 64, null, null, null, null, 2.0, null, null, null) == 0
     assert lib.fm_fine_match(null, null, 3, null, 49, 64, null, null, null, null, 2.0, null, null, null) == -1
+    # cell-ordered and merging crops: M == 0 is a no-op, NULL pointers are refused, the shape limits hold
+    one = C.c_void_p(256)        # a non-NULL address that is never dereferenced on these paths
+    assert lib.fm_gather_windows_cells(null, 1, 64, 8, 8, 7, 4, 2, 2, 2, null, 4, null, null, null, null, 0, null, null) == 0
+    assert lib.fm_gather_windows_cells(null, 1, 64, 8, 8, 7, 4, 2, 2, 2, null, 4, null, null, null, null, 3, null, null) == -1
+    assert lib.fm_gather_windows_cells(one, 1, 64, 8, 8, 7, 4, 2, 2, 2, one, 3, one, one, one, null, 3, one, null) == -2  # pitch < cells
+    assert lib.fm_gather_windows_cells(one, 1, 32, 8, 8, 7, 4, 2, 2, 2, one, 4, one, one, one, null, 3, one, null) == -3  # Cf != 64
+    assert lib.fm_gather_merge_windows(null, 1, 64, 8, 8, 7, 4, 2, 2, 2, null, 0, null, null, null, null, null, null, 0,
+                                       null, null) == 0
+    assert lib.fm_gather_merge_windows(one, 1, 64, 8, 8, 7, 4, 2, 2, 2, null, 0, null, null, one, one, one, null, 3,
+                                       one, null) == -1          # packed weights missing
+    assert lib.fm_gather_merge_windows(one, 1, 64, 8, 8, 7, 4, 2, 2, 2, one, 4, null, one, one, one, one, null, 3,
+                                       one, null) == -1          # cell map without its tie list
+    assert lib.fm_gather_merge_windows(one, 1, 64, 8, 8, 9, 4, 2, 2, 2, null, 0, null, one, one, one, one, null, 3,
+                                       one, null) == -3          # W not in {5,7}
+    assert lib.fm_merge_pack_weights(null, 64, null, null) == -1
+    assert lib.fm_merge_pack_weights(one, 32, one, null) == -3
 
 
 def test_layout_query_is_consistent():
