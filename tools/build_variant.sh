@@ -10,6 +10,6 @@ for f in api coarse_prep $CORR coarse_select fine; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$ROOT/featurematching_amd/csrc "$@" \
     -c $ROOT/featurematching_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
-wait
+wait || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libfmatch_$NAME.so $OUT/obj_$NAME/*.o -Wl,-rpath,/opt/rocm/lib
 echo $OUT/libfmatch_$NAME.so
