@@ -79,11 +79,12 @@ class Pair:
         if self.stages == "coarse" and self.last is not None:
             self.last = (buf,) + self.last[1:]
             return self.last
-        cells0, cells1 = buf.cell_maps() if self.gather != "list" else (None, None)
-        ops.gather_windows(self.ff0, buf.b_ids, buf.i_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win0,
-                           cells=cells0, h_c=self.hw_c[0])
-        ops.gather_windows(self.ff1, buf.b_ids, buf.j_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win1,
-                           cells=cells1, h_c=self.hw_c[0])
+        if self.gather == "cells":      # both images' crops in one launch, cell order
+            ops.gather_windows_pair(self.ff0, self.ff1, buf.b_ids, buf.i_ids, buf.j_ids, w, 4, self.hw_c, self.hw_c,
+                                    buf.cell_maps(), count=buf.count, out0=self.win0, out1=self.win1)
+        else:                           # "list": one list-ordered launch per image
+            ops.gather_windows(self.ff0, buf.b_ids, buf.i_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win0)
+            ops.gather_windows(self.ff1, buf.b_ids, buf.j_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win1)
         k0, k1 = ops.fine_match(self.win0, self.win1, self.mix0, self.mix1, buf.mkpts0_c, buf.mkpts1_c,
                                 self.hw_i[0] / self.hw_f[0], count=buf.count)
         self.last = (buf, k0, k1)

@@ -185,29 +185,34 @@ __global__ __launch_bounds__(256) void k_gather_nchw64(const float* __restrict__
 // waves of the grid, one each; if that list overflowed (> kTieCap) every wave scans its slice of the
 // match list instead.
 // ----------------------------------------------------------------------------------------
+// One launch can serve BOTH images of the pairs (blockIdx.y = image): the two crops are independent and each
+// is bound by one round of memory latency at 640x480, so a second launch only adds its ramp and tail.
+struct CellImage {
+  const float* feat; int Hf, Wf, w_c, cells, total_cells;
+  const int32_t* cell_to_match; int cell_pitch; const int32_t* ties;
+  const int64_t* ids; float* out; const float* ctx;
+};
+struct CellArgs {
+  CellImage im[2];
+  int stride, pad, m_max;
+  const int64_t* b_ids; const int32_t* d_count; const half8* wpack;
+};
+
 template <int W, bool MERGE>
-__global__ __launch_bounds__(256) void k_gather_cellorder64(const float* __restrict__ feat, int Hf, int Wf, int stride,
-                                                            int pad, int w_c, int cells, int total_cells,
-                                                            const int32_t* __restrict__ cell_to_match, int cell_pitch,
-                                                            const int32_t* __restrict__ ties,
-                                                            const int64_t* __restrict__ b_ids,
-                                                            const int64_t* __restrict__ ids,
-                                                            const int32_t* __restrict__ d_count, int m_max,
-                                                            float* __restrict__ out,
-                                                            const half8* __restrict__ wpack,
-                                                            const float* __restrict__ ctx) {
+__global__ __launch_bounds__(256) void k_gather_cellorder64(CellArgs a) {
   constexpr int CF = 64, TOTAL = CF * W * W;
   __shared__ __attribute__((aligned(16))) float tile_all[4 * kGatherTileFloats(W)];
+  const CellImage& I = a.im[blockIdx.y];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* tile = tile_all + wv * kGatherTileFloats(W);
-  const int M = d_count ? min(d_count[0], m_max) : m_max;
-  const int nties = ties[0];
-  const int lid = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;      // grid is a multiple of 8
+  const int M = a.d_count ? min(a.d_count[0], a.m_max) : a.m_max;
+  const int nties = I.ties[0];
+  const int lid = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;      // grid.x is a multiple of 8
   // job = (match, sample, cell) this wave copies next; first its own cell, then tie losers (rare)
   int jm = -1, jb = 0, jcell = 0;
-  if (lid < total_cells) {
-    const int b = lid / cells, cell = lid - b * cells;
-    const int m = cell_to_match[(long)b * cell_pitch + cell] - 1;
+  if (lid < I.total_cells) {
+    const int b = lid / I.cells, cell = lid - b * I.cells;
+    const int m = I.cell_to_match[(long)b * I.cell_pitch + cell] - 1;
     if (m >= 0 && m < M) { jm = m; jb = b; jcell = cell; }
   }
   const int gwave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
@@ -220,23 +225,23 @@ __global__ __launch_bounds__(256) void k_gather_cellorder64(const float* __restr
     if (jm >= 0) {
       jm = __builtin_amdgcn_readfirstlane(jm); jb = __builtin_amdgcn_readfirstlane(jb);
       jcell = __builtin_amdgcn_readfirstlane(jcell);
-      const int cy = jcell / w_c;
-      wave_copy_window64<W, MERGE>(feat + (long)jb * CF * Hf * Wf, Hf, Wf, cy * stride - pad,
-                                   (jcell - cy * w_c) * stride - pad, out + (long)jm * TOTAL, tile, lane, wpack,
-                                   MERGE ? ctx + ((long)jb * cells + jcell) * CF : nullptr);
+      const int cy = jcell / I.w_c;
+      wave_copy_window64<W, MERGE>(I.feat + (long)jb * CF * I.Hf * I.Wf, I.Hf, I.Wf, cy * a.stride - a.pad,
+                                   (jcell - cy * I.w_c) * a.stride - a.pad, I.out + (long)jm * TOTAL, tile, lane,
+                                   a.wpack, MERGE ? I.ctx + ((long)jb * I.cells + jcell) * CF : nullptr);
     }
     jm = -1;
     if (mode == 0) break;                                                // the common case: no exact ties
     if (mode == 1) {
       if (q >= nties) break;
-      const int m = ties[1 + q];
+      const int m = I.ties[1 + q];
       q += nwaves;
-      if (m >= 0 && m < M) { jm = m; jb = (int)b_ids[m]; jcell = (int)ids[m]; }
+      if (m >= 0 && m < M) { jm = m; jb = (int)a.b_ids[m]; jcell = (int)I.ids[m]; }
     } else {
       if (scan >= scan_end) break;
       const int m = scan++;
-      const int mb = (int)b_ids[m], id = (int)ids[m];
-      if (cell_to_match[(long)mb * cell_pitch + id] != m + 1) { jm = m; jb = mb; jcell = id; }
+      const int mb = (int)a.b_ids[m], id = (int)I.ids[m];
+      if (I.cell_to_match[(long)mb * I.cell_pitch + id] != m + 1) { jm = m; jb = mb; jcell = id; }
     }
   }
 }
@@ -470,16 +475,16 @@ static void launch_list64(int W, int blocks, hipStream_t st, const float* feat_f
                        b_ids, ids, d_count, m_max, out, wpack, ctx, ctx_cells);
 }
 template <bool MERGE>
-static void launch_cells64(int W, int blocks, hipStream_t st, const float* feat_f, int Hf, int Wf, int stride, int pad,
-                           int w_c, int cells, int total, const int32_t* cell_to_match, int cell_pitch,
-                           const int32_t* ties, const int64_t* b_ids, const int64_t* ids, const int32_t* d_count,
-                           int m_max, float* out, const half8* wpack, const float* ctx) {
-  if (W == 5)
-    hipLaunchKernelGGL((k_gather_cellorder64<5, MERGE>), dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad,
-                       w_c, cells, total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, wpack, ctx);
-  else
-    hipLaunchKernelGGL((k_gather_cellorder64<7, MERGE>), dim3(blocks), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad,
-                       w_c, cells, total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, wpack, ctx);
+static void launch_cells64(int W, int blocks, int nimg, hipStream_t st, const CellArgs& a) {
+  if (W == 5) hipLaunchKernelGGL((k_gather_cellorder64<5, MERGE>), dim3(blocks, nimg), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_gather_cellorder64<7, MERGE>), dim3(blocks, nimg), dim3(256), 0, st, a);
+}
+static CellImage cell_image(const float* feat, int N, int Hf, int Wf, int h_c, int w_c, const int32_t* map, int pitch,
+                            const int32_t* ties, const int64_t* ids, float* out, const float* ctx) {
+  CellImage im;
+  im.feat = feat; im.Hf = Hf; im.Wf = Wf; im.w_c = w_c; im.cells = h_c * w_c; im.total_cells = N * h_c * w_c;
+  im.cell_to_match = map; im.cell_pitch = pitch; im.ties = ties; im.ids = ids; im.out = out; im.ctx = ctx;
+  return im;
 }
 // the fast NCHW kernels address one sample's map with 31-bit byte offsets (buffer descriptor)
 static bool fast_nchw64(int Cf, int Hf, int Wf, int W) {
@@ -522,9 +527,10 @@ extern "C" int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int H
   if (N <= 0 || Hf <= 0 || Wf <= 0 || h_c <= 0 || w_c <= 0 || stride <= 0 || m_max < 0 || cell_pitch < h_c * w_c)
     return FM_E_SHAPE;
   if (!fast_nchw64(Cf, Hf, Wf, W)) return FM_E_UNSUPPORTED;
-  const long total = (long)N * h_c * w_c;
-  launch_cells64<false>(W, cell_blocks(total), (hipStream_t)stream, feat_f, Hf, Wf, stride, pad, w_c, h_c * w_c,
-                        (int)total, cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, nullptr, nullptr);
+  CellArgs a;
+  a.im[0] = a.im[1] = cell_image(feat_f, N, Hf, Wf, h_c, w_c, cell_to_match, cell_pitch, ties, ids, out, nullptr);
+  a.stride = stride; a.pad = pad; a.m_max = m_max; a.b_ids = b_ids; a.d_count = d_count; a.wpack = nullptr;
+  launch_cells64<false>(W, cell_blocks((long)N * h_c * w_c), 1, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -566,13 +572,43 @@ extern "C" int fm_gather_merge_windows(const float* feat_f, int N, int Cf, int H
   if (!fast_nchw64(Cf, Hf, Wf, W)) return FM_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)N * h_c * w_c;
-  if (cell_to_match)
-    launch_cells64<true>(W, cell_blocks(total), st, feat_f, Hf, Wf, stride, pad, w_c, h_c * w_c, (int)total,
-                         cell_to_match, cell_pitch, ties, b_ids, ids, d_count, m_max, out, (const half8*)packed_w,
-                         ctx_bias);
+  if (cell_to_match) {
+    CellArgs a;
+    a.im[0] = a.im[1] = cell_image(feat_f, N, Hf, Wf, h_c, w_c, cell_to_match, cell_pitch, ties, ids, out, ctx_bias);
+    a.stride = stride; a.pad = pad; a.m_max = m_max; a.b_ids = b_ids; a.d_count = d_count;
+    a.wpack = (const half8*)packed_w;
+    launch_cells64<true>(W, cell_blocks(total), 1, st, a);
+  }
   else
     launch_list64<true>(W, list_blocks(m_max), st, feat_f, Hf, Wf, stride, pad, w_c, b_ids, ids, d_count, m_max, out,
                         (const half8*)packed_w, ctx_bias, h_c * w_c);
+  return (int)hipGetLastError();
+}
+
+extern "C" int fm_gather_windows_pair(const float* feat_f0, const float* feat_f1, int N, int Cf, int Hf0, int Wf0,
+                                      int Hf1, int Wf1, int W, int stride, int pad, int h0c, int w0c, int h1c, int w1c,
+                                      const int32_t* cell0, int pitch0, const int32_t* ties0, const int32_t* cell1,
+                                      int pitch1, const int32_t* ties1, const void* packed_w, const float* ctx0,
+                                      const float* ctx1, const int64_t* b_ids, const int64_t* i_ids,
+                                      const int64_t* j_ids, const int32_t* d_count, int m_max, float* out0,
+                                      float* out1, void* stream) {
+  if (m_max == 0) return FM_OK;
+  if (!feat_f0 || !feat_f1 || !cell0 || !cell1 || !ties0 || !ties1 || !b_ids || !i_ids || !j_ids || !out0 || !out1)
+    return FM_E_NULL;
+  if (packed_w && (!ctx0 || !ctx1)) return FM_E_NULL;
+  if (N <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0 || h0c <= 0 || w0c <= 0 || h1c <= 0 || w1c <= 0 ||
+      stride <= 0 || m_max < 0 || pitch0 < h0c * w0c || pitch1 < h1c * w1c)
+    return FM_E_SHAPE;
+  if (!fast_nchw64(Cf, Hf0, Wf0, W) || !fast_nchw64(Cf, Hf1, Wf1, W)) return FM_E_UNSUPPORTED;
+  CellArgs a;
+  a.im[0] = cell_image(feat_f0, N, Hf0, Wf0, h0c, w0c, cell0, pitch0, ties0, i_ids, out0, ctx0);
+  a.im[1] = cell_image(feat_f1, N, Hf1, Wf1, h1c, w1c, cell1, pitch1, ties1, j_ids, out1, ctx1);
+  a.stride = stride; a.pad = pad; a.m_max = m_max; a.b_ids = b_ids; a.d_count = d_count;
+  a.wpack = (const half8*)packed_w;
+  const long t0 = (long)N * h0c * w0c, t1 = (long)N * h1c * w1c;
+  const int blocks = cell_blocks(t0 > t1 ? t0 : t1);
+  if (packed_w) launch_cells64<true>(W, blocks, 2, (hipStream_t)stream, a);
+  else launch_cells64<false>(W, blocks, 2, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

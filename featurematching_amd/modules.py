@@ -136,10 +136,12 @@ class FinePreprocess(nn.Module):
                 packed, e_w, e_b = self._merge_constants()
                 ctx0 = F.linear(feat_c0.float(), e_w, e_b)          # [N, L, 64] = W_c.(down_proj(feat_c)) + bias
                 ctx1 = F.linear(feat_c1.float(), e_w, e_b)
-                win0 = ops.gather_merge_windows(feat_f0, packed, ctx0, b_ids, i_ids, W, stride, hw0_c[0], hw0_c[1],
-                                                cells=cells0)
-                win1 = ops.gather_merge_windows(feat_f1, packed, ctx1, b_ids, j_ids, W, stride, hw1_c[0], hw1_c[1],
-                                                cells=cells1)
+                if cells0 is not None and feat_f1.shape[1] == 64:
+                    win0, win1 = ops.gather_windows_pair(feat_f0, feat_f1, b_ids, i_ids, j_ids, W, stride, hw0_c, hw1_c,
+                                                         (cells0, cells1), packed_w=packed, ctx0=ctx0, ctx1=ctx1)
+                else:
+                    win0 = ops.gather_merge_windows(feat_f0, packed, ctx0, b_ids, i_ids, W, stride, hw0_c[0], hw0_c[1])
+                    win1 = ops.gather_merge_windows(feat_f1, packed, ctx1, b_ids, j_ids, W, stride, hw1_c[0], hw1_c[1])
             return win0, win1
         with torch.no_grad():
             win0 = ops.gather_windows(feat_f0, b_ids, i_ids, W, stride, hw0_c[1], cells=cells0, h_c=hw0_c[0])

@@ -223,6 +223,34 @@ def gather_merge_windows(feat_f: torch.Tensor, packed_w: torch.Tensor, ctx_bias:
     return out
 
 
+def gather_windows_pair(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, j_ids, w: int, stride: int,
+                        hw0_c, hw1_c, cells, pad: int = 2, count: Optional[torch.Tensor] = None, out0=None, out1=None,
+                        packed_w: Optional[torch.Tensor] = None, ctx0=None, ctx1=None):
+    """Both images' window crops in one launch (cell order; cells = CoarseBuffers.cell_maps()); with
+    packed_w / ctx0 / ctx1 the crop is fused with the context merge.  NCHW maps, Cf = 64, W in {5,7}."""
+    lib = _lib.load()
+    f0, f1 = _f32c(feat_f0, "feat_f0"), _f32c(feat_f1, "feat_f1")
+    n, cf, hf0, wf0 = f0.shape
+    hf1, wf1 = f1.shape[2:]
+    m_max = int(b_ids.shape[0])
+    if out0 is None:
+        out0 = torch.empty(m_max, w * w, cf, dtype=torch.float32, device=f0.device)
+    if out1 is None:
+        out1 = torch.empty(m_max, w * w, cf, dtype=torch.float32, device=f0.device)
+    if m_max == 0:
+        return out0, out1
+    if packed_w is not None:
+        ctx0, ctx1 = _f32c(ctx0, "ctx0"), _f32c(ctx1, "ctx1")
+    (m0, p0, t0), (m1, p1, t1) = cells
+    st = lib.fm_gather_windows_pair(_ptr(f0), _ptr(f1), n, cf, hf0, wf0, hf1, wf1, w, stride, pad, int(hw0_c[0]),
+                                    int(hw0_c[1]), int(hw1_c[0]), int(hw1_c[1]), C.c_void_p(m0), int(p0), C.c_void_p(t0),
+                                    C.c_void_p(m1), int(p1), C.c_void_p(t1), _ptr(packed_w), _ptr(ctx0), _ptr(ctx1),
+                                    _ptr(b_ids), _ptr(i_ids), _ptr(j_ids), _ptr(count), m_max, _ptr(out0), _ptr(out1),
+                                    _stream(f0.device))
+    _lib.check(st, "fm_gather_windows_pair")
+    return out0, out1
+
+
 def fine_match(win0: torch.Tensor, win1: torch.Tensor, mix0: torch.Tensor, mix1: torch.Tensor,
                mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor, scale_f: float,
                count: Optional[torch.Tensor] = None):

@@ -152,6 +152,20 @@ int fm_gather_merge_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, 
                             float* out, void* stream);
 
 /*
+ * Both images' crops in ONE launch (cell order; what FinePreprocess.forward does in a row,
+ * fine_preprocess.py:43-50 / 52-60): out0 from feat_f0 / i_ids, out1 from feat_f1 / j_ids.
+ * packed_w NULL = plain crop; non-NULL = crop fused with the context merge (ctx0/ctx1 required).
+ * Each crop is bound by one round of memory latency at 640x480, so a second launch only adds ramp and tail.
+ */
+int fm_gather_windows_pair(const float* feat_f0, const float* feat_f1, int N, int Cf, int Hf0, int Wf0, int Hf1,
+                           int Wf1, int W, int stride, int pad, int h0c, int w0c, int h1c, int w1c,
+                           const int32_t* cell0, int pitch0, const int32_t* ties0,
+                           const int32_t* cell1, int pitch1, const int32_t* ties1,
+                           const void* packed_w, const float* ctx0, const float* ctx1,
+                           const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids,
+                           const int32_t* d_count, int m_max, float* out0, float* out1, void* stream);
+
+/*
  * Fine stage (fine_matching_new.py:50-79): dual-direction window correlation,
  * softmax heat-map, spatial expectation, std.  win0/win1 [m_max, WW, Cf];
  * mix0/mix1 [dev] float32 [WW+1] = Linear(WW,1) weight then bias;

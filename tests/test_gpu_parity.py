@@ -407,3 +407,34 @@ def test_fine_preprocess_module_fused_equals_two_step(monkeypatch):
     scale = max(1.0, b0.abs().max().item())
     assert (a0 - b0).abs().max().item() <= 2e-5 * scale and (a1 - b1).abs().max().item() <= 2e-5 * scale
     assert (c0 - (b0 + 1.0)).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("w", [5, 7])
+def test_pair_gather_equals_two_single_gathers(w):
+    """fm_gather_windows_pair (both images in one launch, plain and fused with the merge) against the per-image
+    entry points, on a rectangular case (L != S, different map sizes) with exact ties."""
+    h0, w0, h1, w1 = 9, 12, 11, 10
+    f0 = 4.0 * synth.normal(81, 1, (2, h0 * w0, 64))
+    perm = synth.permutation(81, 3, h1 * w1)
+    f1 = 4.0 * synth.normal(81, 2, (2, h1 * w1, 64))
+    k = min(h0 * w0, h1 * w1) - 10
+    f1[:, perm[:k]] = f0[:, :k] + 0.4 * synth.normal(81, 4, (2, k, 64))
+    f1[0, perm[k]] = f1[0, perm[0]]                                  # tie: cell 0 of image 0 -> two cells of image 1
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    buf = ops.coarse_match_async(t0, t1, (h0, w0), (h1, w1), 8.0, border_rm=0)
+    m = buf.read_count()
+    o = buf.sliced(m)
+    assert m > 100
+    ff0 = torch.as_tensor(synth.fine_maps(81, 2, 64, h0 * 4, w0 * 4)[0], device=DEV)
+    ff1 = torch.as_tensor(synth.fine_maps(82, 2, 64, h1 * 4, w1 * 4)[1], device=DEV)
+    cells = buf.cell_maps()
+    a0, a1 = ops.gather_windows_pair(ff0, ff1, o['b_ids'], o['i_ids'], o['j_ids'], w, 4, (h0, w0), (h1, w1), cells)
+    assert torch.equal(a0, ops.gather_windows(ff0, o['b_ids'], o['i_ids'], w, 4, w0))
+    assert torch.equal(a1, ops.gather_windows(ff1, o['b_ids'], o['j_ids'], w, 4, w1))
+    packed = ops.pack_merge_weights(torch.as_tensor(synth.merge_weights(81, 64, 64)[2], device=DEV))
+    ctx0 = torch.as_tensor(synth.normal(81, 7, (2, h0 * w0, 64)), device=DEV)
+    ctx1 = torch.as_tensor(synth.normal(81, 8, (2, h1 * w1, 64)), device=DEV)
+    b0, b1 = ops.gather_windows_pair(ff0, ff1, o['b_ids'], o['i_ids'], o['j_ids'], w, 4, (h0, w0), (h1, w1), cells,
+                                     packed_w=packed, ctx0=ctx0, ctx1=ctx1)
+    assert torch.equal(b0, ops.gather_merge_windows(ff0, packed, ctx0, o['b_ids'], o['i_ids'], w, 4, h0, w0))
+    assert torch.equal(b1, ops.gather_merge_windows(ff1, packed, ctx1, o['b_ids'], o['j_ids'], w, 4, h1, w1, cells=cells[1]))
