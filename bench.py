@@ -277,7 +277,6 @@ def main():
                      "achieved": round(ach_b, 2), "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach_b / PEAK_F16_DENSE_TFLOPS, 4), "traffic": pmc_traffic_bytes(a),
                      "avg_ms": round(t_b, 5), "algorithmic_flop": flops,
-                     "mfma_issued_frac": round(3 * ach_b / PEAK_F16_DENSE_TFLOPS, 4),
                      "max_pass_avg_ms": round(t_a, 5),
                      "both_passes_frac": round(flops / ((t_a + t_b) * 1e-3) / 1e12 / PEAK_F16_DENSE_TFLOPS, 4)},
     }

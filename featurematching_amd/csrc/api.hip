@@ -1,5 +1,6 @@
 // Host side of the C ABI (include/fmatch.h): argument checks, workspace layout, launch order.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "fm_internal.h"
@@ -10,7 +11,11 @@ int choose_splits(int N, int panels, int tiles) {
   // One workgroup per (sample, panel, split); aim at one full round of the 256 CUs when the
   // batch alone cannot fill them (a split shorter than 2 tiles is not worth its prologue).
   const int wg = N * panels;
-  int s = 256 / (wg > 0 ? wg : 1);
+  int target = 256;
+#ifdef FM_TUNE_ENV
+  if (const char* e = getenv("FM_TARGET_WGS")) target = atoi(e) > 0 ? atoi(e) : 256;
+#endif
+  int s = target / (wg > 0 ? wg : 1);
   if (s < 1) s = 1;
   const int smax = tiles / 2 > 0 ? tiles / 2 : 1;
   if (s > smax) s = smax;
