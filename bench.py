@@ -158,8 +158,8 @@ def cpu_baseline(wl, window, seed, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--window", type=int, default=5, choices=[5, 7])
     ap.add_argument("--dist", default="peaky", choices=["peaky", "borderline"])
