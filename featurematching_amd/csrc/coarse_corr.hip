@@ -16,7 +16,7 @@
 //                    column stabiliser of its 32 columns is skipped: each of its entries adds
 //                    < 2^-32 to a sum that is >= e^-2E ~ 1 (at most S * 2^-32 ~ 1e-6 relative in total,
 //                    inside the 1e-5 parity bar) and none can be a candidate.  With dual-softmax-
-//                    trained (peaked) descriptors ~85 % of the units qualify; with flat similarity
+//                    trained (peaked) descriptors ~81 % of the units qualify; with flat similarity
 //                    nothing is skipped and the sweep is dense.
 //   pass C (MODE 2): only when pass B's screening overflowed a row's candidate slots (flat
 //                    similarity rows, e.g. an untrained network): the same product again, screened
@@ -29,9 +29,13 @@
 // Structure (one workgroup = 8 waves = 256 rows of image 0; cf. SURVEY.md 7, hard part 2):
 //   * each wave keeps its 32 rows x C of image-0 descriptors as MFMA A-fragments in
 //     registers for the whole sweep (no K loop, no re-read);
-//   * image-1 descriptors stream through LDS in 64-column tiles, double buffered, filled by LDS-DMA
-//     (global_load_lds_dwordx4) one 1 KiB fragment block at a time; planes are fragment-major
-//     (k_prep_split), so the LDS image is lane-linear and every ds_read_b128 is bank-conflict free;
+//   * image-1 descriptors stream through LDS in 64-column tiles - a 4-deep ring of hi tiles in the max pass,
+//     a double buffer of hi+lo tiles otherwise - filled by LDS-DMA (global_load_lds_dwordx4) one 1 KiB
+//     fragment block at a time, handed over by counted vmcnt + raw s_barrier; planes are fragment-major
+//     (k_prep_split), so the LDS image is lane-linear and every ds_read_b128 is bank-conflict free; the
+//     tile's metadata (column stabilisers, unit maxima) arrives by 4-byte LDS-DMA next to it;
+//   * inside the sweep every LDS access is inline asm and no register carries a global load across
+//     iterations: hipcc would otherwise order them against the ring's DMAs with vmcnt(0) (see below);
 //   * the f32 accumulator tile (32 rows x 32 cols per wave and unit) never leaves registers:
 //     the epilogue turns it into exp2 terms, accumulates row sums in registers across
 //     the whole sweep and reduces column sums lane-locally (rows live in registers,
