@@ -40,7 +40,8 @@
 //     the epilogue turns it into exp2 terms, accumulates row sums in registers across
 //     the whole sweep and reduces column sums lane-locally (rows live in registers,
 //     columns on lanes: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5));
-//     each wave writes the column partial of its own 32 rows (8 partials per panel).
+//     the 8 waves' column partials of a tile meet in LDS and one wave folds them (fixed order) into the
+//     workgroup's single column partial per panel.
 #include <stdlib.h>
 
 #include "fm_internal.h"
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   // the tile prefetch it had just issued (the whole ring was serialised: ~1 us per tile).
   __shared__ float s_nmr[8 * 32];                 // row stabilisers of the 8 waves' rows
   __shared__ float s_meta[2 * META];              // per tile: 64 column stabilisers + 16 unit maxima
+  __shared__ float s_colred[2 * 8 * 64];          // per tile parity: the 8 waves' column partials of 64 columns
   // wave-private candidate queue (sum / screening passes): candidates found during the sweep are parked
   // here and handed to the global per-row slot lists once, after the sweep.  (A global atomicAdd with
   // return per find stalls the wave for a memory round trip in the middle of the MFMA pipeline: 10 us of
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   float* qx = s_qx + wv * kCandQueue;
   int* qcnt = s_qcnt + wv;
   if (SPARSE && lane == 0) *qcnt = 0;
+  const unsigned colred_a = lds_addr(s_colred);
   const unsigned meta_a = lds_addr(meta), nmr_a = lds_addr(nmr_lds), qcnt_a = lds_addr(qcnt), qkey_a = lds_addr(qkey),
                  qx_a = lds_addr(qx);
 
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   }
   const bool row_edge = (wrow0 + 32 > a.L);     // wave-uniform: some of this wave's rows are padding
 
-  float* colout = a.colpart + (((long)b * a.panels + panel) * kColParts + wv) * a.Sp;
+  float* colout = a.colpart + ((long)b * a.panels + panel) * a.Sp;       // one partial per workgroup
 
   f32x16 acc;
 
@@ -454,7 +457,8 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         }
       }
     }
-    if (MODE <= 1 && h == 0) colout[col] = cstat;      // this wave's 32 rows of column `col`
+    if (MODE <= 1 && h == 0)      // this wave's 32 rows of column `col`: parked for the fold after the tile barrier
+      lds_store_b32(colred_a + ((((((u >> 1) - t0) & 1) * 8 + wv) * 64 + (u & 1) * 32 + r) * 4), cstat);
   };
 
   // Tile hand-over: LDS-DMA writes are ordered for other waves' reads only by the issuing wave's vmcnt
@@ -528,13 +532,27 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       { DIAG_T0 epilogue(u, nmc_u); DIAG_ADD(diag_epi) }
 #endif
     } else if (MODE == 1 && h == 0) {
-      colout[t * kTileCols + (u & 1) * 32 + r] = 0.f;               // skipped unit: contributes nothing
+      lds_store_b32(colred_a + (((par * 8 + wv) * 64 + (u & 1) * 32 + r) * 4), 0.f);     // skipped unit: contributes nothing
     }
     if (u & 1) {
       // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
 #ifndef FM_ABL_NOBAR
       { DIAG_T0 tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1)); DIAG_ADD(diag_bar) }
 #endif
+      if (MODE <= 1 && wv == (t & 7)) {
+        // every wave's column partials of tile t are in LDS (their writes precede the barrier): this wave folds
+        // the 8 partials of the 64 columns in a fixed order (deterministic sums) and stores the workgroup's one
+        float pv[8];
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8)
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(pv[w8]) : "v"(colred_a + (par * 8 * 64 + lane) * 4), "i"(w8 * 256));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
+                     "+v"(pv[6]), "+v"(pv[7]));
+        float cv = pv[0];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) cv = MODE ? cv + pv[w8] : fmaxf(cv, pv[w8]);
+        colout[t * kTileCols + lane] = cv;
+      }
     }
   }
 #ifdef FM_DIAG_CLOCK

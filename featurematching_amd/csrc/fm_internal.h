@@ -10,7 +10,7 @@ namespace fm {
 
 constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup owns
 // column partials each panel writes (one per wave: 8 waves x 32 rows)
-constexpr int kColParts = 8;
+constexpr int kColParts = 1;         // column partials per 256-row panel (the 8 waves' partials are folded in LDS)
 constexpr int kTieCap = 1023;        // listed tie losers per image; beyond it the gathers scan the match list
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
 constexpr float kLog2e = 1.4426950408889634f;
@@ -36,7 +36,7 @@ struct CoarseWs {
   // per-row / per-column statistics
   size_t norm0, norm1, bmax0, bmax1;          // row norms, per-prep-block max norms
   size_t rowA, colA, rowB, colB;              // partial max (pass A) / sum-exp (pass B): rows [N][splits][Lp],
-                                              // columns [N][panels*8][Sp] (one partial per wave)
+                                              // columns [N][panels][Sp] (one partial per workgroup)
   size_t nmr, nmc;                            // -stabiliser*log2e per row / column
   size_t rsum, csum;                          // softmax denominators per row / column
   size_t nmr2, nmc2;                          // nmr - log2(rsum), nmc - log2(csum): log-softmax offsets

@@ -43,7 +43,7 @@ def test_workspace_query_and_argument_checks():
     n = C.c_size_t(0)
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n)) == 0
     per_pair = n.value
-    assert 15e6 < per_pair < 60e6          # 4 float16 planes (9.96 MB) + partial statistics
+    assert 10e6 < per_pair < 60e6          # 4 float16 planes (9.96 MB) + partial statistics
     assert lib.fm_coarse_workspace_bytes(64, 4800, 4800, 256, 8, C.byref(n)) == 0
     assert n.value < 64 * per_pair * 1.2
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 102, 8, C.byref(n)) == -3     # C % 4 != 0

@@ -82,7 +82,7 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     ok &= ok_n
 
     rowA = view(ws, base, lay["rowA"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).max(1)
-    colA = view(ws, base, lay["colA"], n * panels * 8 * Sp, torch.float32).reshape(n, panels * 8, Sp).max(1)
+    colA = view(ws, base, lay["colA"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).max(1)
     nmr = view(ws, base, lay["nmr"], n * Lp, torch.float32).reshape(n, Lp)
     nmc = view(ws, base, lay["nmc"], n * Sp, torch.float32).reshape(n, Sp)
     rsum = view(ws, base, lay["rsum"], n * Lp, torch.float32).reshape(n, Lp)
