@@ -7,11 +7,10 @@
 
 namespace fm {
 
-int choose_splits(int N, int panels, int tiles) {
+int choose_splits(int N, int panels, int tiles, int target) {
   // One workgroup per (sample, panel, split); aim at one full round of the 256 CUs when the
   // batch alone cannot fill them (a split shorter than 2 tiles is not worth its prologue).
   const int wg = N * panels;
-  int target = 256;
 #ifdef FM_TUNE_ENV
   if (const char* e = getenv("FM_TARGET_WGS")) target = atoi(e) > 0 ? atoi(e) : 256;
 #endif
@@ -33,6 +32,10 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.panels = w.Lp / kPanelRows;
   w.tiles = w.Sp / kTileCols;
   w.splits = choose_splits(N, w.panels, w.tiles);
+  w.splits0 = w.splits;
+#ifdef FM_TUNE_ENV
+  if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : 256);
+#endif
   const size_t rows = (size_t)N * w.Lp, cols = (size_t)N * w.Sp;
   const size_t nblk = (rows * slots + 255) / 256;
   size_t o = 0;
@@ -51,7 +54,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
   w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
   w.bmax0 = take(rows / 32 * 4); w.bmax1 = take(cols / 32 * 4);
-  w.rowA = take(rows * w.splits * 4); w.colA = take(cols * w.panels * kColParts * 4);
+  w.rowA = take(rows * w.splits0 * 4); w.colA = take(cols * w.panels * kColParts * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * kColParts * 4);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
   w.rsum = take(rows * 4); w.csum = take(cols * 4);

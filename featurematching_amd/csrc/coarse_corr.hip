@@ -632,22 +632,22 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.cand_x = (float*)(base + w.cand_conf);   // raw dot product now, replaced by conf in k_cand_conf
   a.flags = (unsigned*)(base + w.scalars);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
-  a.splits = w.splits; a.tiles_per_split = (w.tiles + w.splits - 1) / w.splits; a.slots = w.slots;
+  a.splits = mode ? w.splits : w.splits0; a.tiles_per_split = (w.tiles + a.splits - 1) / a.splits; a.slots = w.slots;
   {
     // one XCD runs ~blocks/8 workgroups: make its block of (panels x splits) as square as the bytes are
     // (a panel contributes 256 rows of A, a split tiles_per_split*64 columns of B)
-    const int blocks_all = w.N * w.splits * w.panels;
+    const int blocks_all = w.N * a.splits * w.panels;
     const float share = fmaxf(1.f, (float)blocks_all / 8.f);
     int pgr = (int)lroundf(sqrtf(share * (float)(a.tiles_per_split * kTileCols) / (float)kPanelRows));
     a.pgroup = pgr < 1 ? 1 : (pgr > w.panels ? w.panels : pgr);
-    if (w.splits == 1) a.pgroup = w.panels;
+    if (a.splits == 1) a.pgroup = w.panels;
 #ifdef FM_TUNE_ENV
     if (const char* e = getenv("FM_PGROUP")) a.pgroup = atoi(e) < 1 ? 1 : (atoi(e) > w.panels ? w.panels : atoi(e));
 #endif
   }
   a.k = inv_ct * kLog2e;
   a.lt = log2f(thr) - (mode == 2 ? 2e-4f : 0.f);   // pass C compares rounded log-softmax values: small guard
-  const int blocks = w.N * w.splits * w.panels;
+  const int blocks = w.N * a.splits * w.panels;
 #define FM_CORR_CASE(CC)                                                     \
   case CC: return mode == 3 ? launch_corr_t<CC, 3>(a, blocks, st)            \
                  : mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)          \

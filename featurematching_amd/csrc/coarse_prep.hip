@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
   const int idx = blockIdx.x * 16 + cx;       // len is a multiple of 64
 
   __shared__ float fold[16][17];
-  __shared__ float sm[4];
+  __shared__ float sm[4], sm_own[4];
   float acc = MODE ? 0.f : -INFINITY;
 #pragma unroll 4
   for (int p = pg; p < nparts; p += 16) {
@@ -183,6 +183,13 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) om = fmaxf(om, __shfl_xor(om, m));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = om;
+    if (side == 0 && blockIdx.x == 0) {          // this workgroup also publishes the pair's f16 error margin
+      float own = 0.f;
+      for (int k = threadIdx.x; k < Lp / prows0; k += 256) own = fmaxf(own, bmax0[(long)b * (Lp / prows0) + k]);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) own = fmaxf(own, __shfl_xor(own, m));
+      if ((threadIdx.x & 63) == 0) sm_own[threadIdx.x >> 6] = own;
+    }
   }
   __syncthreads();
   if (pg != 0) return;
@@ -204,8 +211,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, 
   if (side == 0 && blockIdx.x == 0 && cx == 0) {
     // log2-domain bound of k * |f16 product - exact product| over the whole pair: lets pass B turn the
     // unit maxima of pass A into upper bounds of the exact similarity (block-sparse skipping)
-    float own = 0.f;
-    for (int k = 0; k < Lp / prows0; ++k) own = fmaxf(own, bmax0[(long)b * (Lp / prows0) + k]);
+    const float own = fmaxf(fmaxf(sm_own[0], sm_own[1]), fmaxf(sm_own[2], sm_own[3]));
     emarg[b] = ((9.8633e-4f * own * om + 5.9605e-8f * sqrt_c * (own + om)) * inv_ct + 1e-6f) * kLog2e + 1e-3f;
   }
   float raw = v;
@@ -224,7 +230,7 @@ hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, 
   if (mode == 0)
     hipLaunchKernelGGL(k_reduce<0>, grid, dim3(256), 0, st, (const float*)(base + w.rowA),
                        (const float*)(base + w.colA), n0, n1, b0, b1, (float*)(base + w.nmr), (float*)(base + w.nmc),
-                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, 32, nullptr, nullptr,
+                       w.Lp, w.Sp, w.splits0, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, 32, nullptr, nullptr,
                        nullptr, nullptr, nullptr, (unsigned*)(base + w.scalars), (float*)(base + w.emarg));
   else
     hipLaunchKernelGGL(k_reduce<1>, grid, dim3(256), 0, st, (const float*)(base + w.rowB),

@@ -26,6 +26,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // Device workspace of the coarse stage; all offsets in bytes from the base.
 struct CoarseWs {
   int N, L, S, C, Lp, Sp, panels, tiles, splits, slots;
+  int splits0;                                // column splits of the max pass (its own grid size)
   // zeroed on every call (contiguous, starts at the base)
   size_t zero_begin, cand_count, colbest, blocktot, scalars, zero_end;
   size_t cell0, cell1;                        // (zeroed) match index + 1 of every image-0 / image-1 cell
@@ -47,7 +48,7 @@ struct CoarseWs {
 };
 
 // splits of the column sweep so that panels*splits*N fills the chip once
-int choose_splits(int N, int panels, int tiles);
+int choose_splits(int N, int panels, int tiles, int target = 256);
 CoarseWs coarse_layout(int N, int L, int S, int C, int slots);
 
 struct Scalars {          // lives at ws.scalars (zeroed per call)
