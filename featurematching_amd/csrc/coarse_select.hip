@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
   __shared__ int sm[4];
   __shared__ int rowoff[256];
   const int lane = threadIdx.x & 63;
+  const int rows_per_block = 256 / a.slots;                  // <= 64: this workgroup's rows fit one wave
+  const long row0 = (long)blockIdx.x * rows_per_block;
+  const long total_rows = (long)a.N * a.Lp;
+  // this workgroup's row counts, issued together with the totals of the workgroups before it
+  int cntq = 0;
+  if (threadIdx.x < rows_per_block && row0 + threadIdx.x < total_rows) cntq = a.rowcnt[row0 + threadIdx.x];
   // exclusive prefix of the workgroup totals before this one (fixed order -> deterministic)
   int pre = 0;
   for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) pre += a.blocktot[k];
@@ -113,17 +119,16 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
   if (lane == 0) sm[threadIdx.x >> 6] = pre;
   __syncthreads();
   pre = sm[0] + sm[1] + sm[2] + sm[3];
-
-  const int rows_per_block = 256 / a.slots;
-  const long row0 = (long)blockIdx.x * rows_per_block;
-  const long total_rows = (long)a.N * a.Lp;
-  if (threadIdx.x == 0) {
-    int run = pre;
-    for (int q = 0; q < rows_per_block; ++q) {
-      rowoff[q] = run;
-      if (row0 + q < total_rows) run += a.rowcnt[row0 + q];
+  if (threadIdx.x < 64) {       // wave 0: inclusive scan of the row counts
+    int incl = cntq;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
     }
-    if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < rows_per_block) rowoff[threadIdx.x] = pre + incl - cntq;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 63) {
+      const int run = pre + incl;
       a.d_count[0] = run;
       a.d_count[1] = (int)((a.scal->flags & 7u) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
     }
