@@ -31,7 +31,7 @@ SIGNATURES = {
     "fm_default_cand_slots": (_i, [_f]),
     "fm_coarse_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "fm_coarse_match": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
-                             _p, C.c_size_t, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+                             _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
     "fm_debug_launch_corr": (_i, [_p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),

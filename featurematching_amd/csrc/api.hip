@@ -126,9 +126,9 @@ extern "C" int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots
 extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S, int C, int h0c, int w0c,
                                int h1c, int w1c, float temperature, float thr, int border_rm, float scale_px,
                                const float* scale0, const float* scale1, void* workspace, size_t workspace_bytes,
-                               int cand_slots, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* mkpts0_c,
-                               float* mkpts1_c, float* mconf, int cap, int32_t* d_count, float* conf_matrix,
-                               void* stream) {
+                               int cand_slots, int exact_screening, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                               float* mkpts0_c, float* mkpts1_c, float* mconf, int cap, int32_t* d_count,
+                               float* conf_matrix, void* stream) {
   if (!feat0 || !feat1 || !workspace || !d_count) return FM_E_NULL;
   if (cap > 0 && (!b_ids || !i_ids || !j_ids || !mkpts0_c || !mkpts1_c || !mconf)) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
@@ -149,16 +149,23 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   if (e != hipSuccess) return (int)e;
   e = launch_corr(1, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
-  e = launch_reduce(1, w, base, inv_ct, st);
-  if (e != hipSuccess) return (int)e;
-  e = launch_corr(2, w, base, inv_ct, thr, st);   // exits immediately unless pass B's screening overflowed
-  if (e != hipSuccess) return (int)e;
-  if (conf_matrix) {                              // dense data['conf_matrix'] on request (a fourth sweep)
+  // The common path goes straight to the assignment (k_cand_conf folds the softmax denominators of its
+  // candidates from the partial sums itself).  The denominators / log-softmax offsets of EVERY row and column
+  // are only needed by the exact screening and by the dense conf_matrix:
+  if (exact_screening || conf_matrix) {
+    e = launch_reduce(1, w, base, inv_ct, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (exact_screening) {       // exits immediately unless pass B's screening overflowed a row's slots
+    e = launch_corr(2, w, base, inv_ct, thr, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (conf_matrix) {           // dense data['conf_matrix'] on request (one more sweep)
     e = launch_corr(3, w, base, inv_ct, thr, st, conf_matrix);
     if (e != hipSuccess) return (int)e;
   }
   e = launch_select(w, base, feat0, feat1, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
-                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, st);
+                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, exact_screening, st);
   return (int)e;
 }
 

@@ -13,7 +13,9 @@ namespace fm {
 
 struct SelArgs {
   const float* feat0; const float* feat1;
-  const float* nmr; const float* nmc; const float* rsum; const float* csum;
+  const float* nmr; const float* nmc;
+  const float* rowB; const float* colB;   // partial sums of pass B: rows [N][splits][Lp], columns [N][panels][Sp]
+  int exact;                              // pass C ran (exact screening): its overflow is then FM_DEV_CANDIDATES already
   const int* cand_count; const int* cand_j;
   float* cand_conf; float* rowbest; unsigned* colbest;
   int* keep_j; float* keep_conf; int* rowcnt; int* blocktot; Scalars* scal;
@@ -41,7 +43,11 @@ __global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
     // the accumulator value pass B produced for this entry: the same number that entered the row
     // and column sums, so numerator and denominator are consistent (as in the reference's softmax)
     const float x = a.cand_conf[grow * a.slots + slot];
-    const float rs = a.rsum[grow], cs = a.csum[(long)b * a.Sp + j];
+    // softmax denominators of this row and this column, folded from pass B's partials in a fixed order
+    // (all loads independent: one round trip; no separate reduction kernel on the common path)
+    float rs = 0.f, cs = 0.f;
+    for (int p = 0; p < a.splits; ++p) rs += a.rowB[((long)b * a.splits + p) * a.Lp + i];
+    for (int p = 0; p < a.panels; ++p) cs += a.colB[((long)b * a.panels + p) * a.Sp + j];
     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmr[grow])) / rs;
     const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmc[(long)b * a.Sp + j])) / cs;
     conf = pr * pc;
@@ -130,7 +136,10 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 63) {
       const int run = pre + incl;
       a.d_count[0] = run;
-      a.d_count[1] = (int)((a.scal->flags & 7u) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
+      // without the exact-screening pass an overflow of pass B's candidate slots is final
+      unsigned fl = a.scal->flags;
+      if (!a.exact && (fl & (unsigned)FM_INT_SCREEN_OVERFLOW)) fl |= (unsigned)FM_DEV_CANDIDATES;
+      a.d_count[1] = (int)((fl & 7u) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
     }
   }
   __syncthreads();
@@ -169,11 +178,12 @@ hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, cons
                          int h1c, int w1c, float inv_ct, float thr, int border, float scale_px,
                          const float* scale0, const float* scale1, int64_t* b_ids, int64_t* i_ids,
                          int64_t* j_ids, float* k0, float* k1, float* mconf, int cap, int32_t* d_count,
-                         hipStream_t st) {
+                         int exact_screening, hipStream_t st) {
   SelArgs a;
+  a.exact = exact_screening;
   a.feat0 = feat0; a.feat1 = feat1;
   a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
-  a.rsum = (const float*)(base + w.rsum); a.csum = (const float*)(base + w.csum);
+  a.rowB = (const float*)(base + w.rowB); a.colB = (const float*)(base + w.colB);
   a.cand_count = (const int*)(base + w.cand_count); a.cand_j = (const int*)(base + w.cand_j);
   a.cand_conf = (float*)(base + w.cand_conf); a.rowbest = (float*)(base + w.rowbest);
   a.colbest = (unsigned*)(base + w.colbest);

@@ -66,7 +66,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, cons
                          int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,
                          float scale_px, const float* scale0, const float* scale1,
                          int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* k0, float* k1,
-                         float* mconf, int cap, int32_t* d_count, hipStream_t st);
+                         float* mconf, int cap, int32_t* d_count, int exact_screening, hipStream_t st);
 hipError_t launch_conf_dense(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, device) instead of on every launch: the

@@ -78,9 +78,11 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        thr: float = 0.2, border_rm: int = 2, temperature: float = 0.1,
                        scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
-                       conf_matrix: bool = False) -> CoarseBuffers:
+                       conf_matrix: bool = False, exact_screening: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
-    capacity-sized device buffers without synchronising."""
+    capacity-sized device buffers without synchronising.  exact_screening adds the two kernels that
+    re-screen the candidates with exact softmax denominators (needed for nearly flat similarity rows;
+    without it such rows report FM_E_CANDIDATES through read_count)."""
     lib = _lib.load()
     f0 = _f32c(feat_c0, "feat_c0")
     f1 = _f32c(feat_c1, "feat_c1")
@@ -109,7 +111,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
     st = lib.fm_coarse_match(_ptr(f0), _ptr(f1), n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
                              int(hw1_c[1]), float(temperature), float(thr), int(border_rm), float(scale_px),
-                             _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots,
+                             _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots, int(bool(exact_screening)),
                              _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids), _ptr(out.mkpts0_c),
                              _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), _ptr(out.conf_matrix),
                              _stream(dev))
@@ -121,10 +123,11 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
                  scale0=None, scale1=None, conf_matrix: bool = False) -> dict:
-    """Synchronous form: sliced outputs.  Retries once with a larger capacity (exact ties can
-    exceed N*min(L,S)) or more candidate slots when the device reports either overflow."""
-    kw = dict(cap=None, cand_slots=None)
-    for _ in range(4):
+    """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
+    N*min(L,S)), with the exact screening pass, then with more candidate slots when the device reports
+    the corresponding overflow."""
+    kw = dict(cap=None, cand_slots=None, exact_screening=False)
+    for _ in range(6):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
                                  scale0, scale1, conf_matrix=conf_matrix, **kw)
         try:
@@ -132,6 +135,9 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
         except _lib.FMatchError as e:
             if e.status == _lib.FM_E_CAPACITY:
                 kw['cap'] = int(e.required)
+                continue
+            if e.status == _lib.FM_E_CANDIDATES and not kw['exact_screening']:
+                kw['exact_screening'] = True
                 continue
             if e.status == _lib.FM_E_CANDIDATES and (kw['cand_slots'] or 8) < 64:
                 base = kw['cand_slots'] or _lib.load().fm_default_cand_slots(float(thr))

@@ -42,7 +42,8 @@ enum fm_status {
   FM_E_UNSUPPORTED = -3, /* C > 256 or C % 4 != 0, Cf != 64, W not in {5,7}, thr <= 0 ... */
   FM_E_WORKSPACE = -4,   /* workspace too small / misaligned */
   FM_E_CAPACITY = -5,    /* (device status) more matches than `cap`; M_out = required */
-  FM_E_CANDIDATES = -6,  /* (device status) a row produced more than cand_slots candidates */
+  FM_E_CANDIDATES = -6,  /* (device status) a row produced more than cand_slots candidates: call again with
+                            exact_screening = 1 (then with more cand_slots if it persists) */
   FM_E_RANGE = -7        /* (device status) descriptor not finite or |x| >= 32768 */
 };
 
@@ -74,12 +75,17 @@ int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t
  *   b_ids,i_ids,j_ids int64[cap]; mkpts0_c,mkpts1_c float32[cap,2] (x,y px);
  *   mconf float32[cap]; d_count int32[2] = {M, status bits}.
  *   conf_matrix: optional [dev] float32 [N,L,S] (data['conf_matrix'], :70) or NULL.
+ *   exact_screening: 0 = candidates are screened in the sum sweep against lower bounds of the row /
+ *   column maxima (enough for dual-softmax-trained descriptors; rows with nearly flat similarity - an
+ *   untrained network, a tiny thr - can overflow their cand_slots: FM_E_CANDIDATES);  1 = two more
+ *   kernels repeat the screening with the exact softmax denominators, decided on the device (they exit at
+ *   once when the first screening sufficed), after which at most 1/thr entries of a row can be candidates.
  */
 int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S, int C,
                     int h0c, int w0c, int h1c, int w1c,
                     float temperature, float thr, int border_rm, float scale_px,
                     const float* scale0, const float* scale1,
-                    void* workspace, size_t workspace_bytes, int cand_slots,
+                    void* workspace, size_t workspace_bytes, int cand_slots, int exact_screening,
                     int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
                     float* mkpts0_c, float* mkpts1_c, float* mconf,
                     int cap, int32_t* d_count, float* conf_matrix, void* stream);

@@ -54,7 +54,7 @@ def test_workspace_query_and_argument_checks():
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, None) == -1
     # NULL / shape checks return before any device work
     null = None
-    args = [null, null, 1, 64, 64, 64, 8, 8, 8, 8, 0.1, 0.2, 2, 8.0, null, null, null, 0, 8,
+    args = [null, null, 1, 64, 64, 64, 8, 8, 8, 8, 0.1, 0.2, 2, 8.0, null, null, null, 0, 8, 0,
             null, null, null, null, null, null, 0, null, null, null]
     assert lib.fm_coarse_match(*args) == -1
     assert lib.fm_gather_windows(null, 1, 64, 8, 8, 0, 7, 4, 2, 2, null, null, null, 4, null, null) == -1

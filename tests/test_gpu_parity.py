@@ -139,15 +139,24 @@ def test_small_magnitude_descriptors():
 
 
 def test_flat_rows_take_the_exact_screening_pass():
-    """Half of the image-0 cells have near-constant similarity rows: every entry of such a row is
-    within ln(thr) of the row maximum, the max-based screening of the sum pass overflows its
-    candidate slots and the (device-side, conditional) third sweep must recover the exact set."""
+    """Half of the cells of BOTH images carry almost no signal: every (flat row, flat column) entry is
+    within ln(thr) of its row and its column maximum, the max-based screening of the sum pass overflows the
+    candidate slots of those rows, and the exact screening pass (opt-in, decided on the device) must recover
+    the exact set."""
     f0, f1 = synth.coarse_descriptors(43, 2, 30 * 40, 128, "peaky")
-    f0[:, ::2] *= 0.01
+    f0[:, ::2] *= 1e-4
+    f1[:, ::2] *= 1e-4
     ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
-    out = _run_coarse(f0, f1, (240, 320), (30, 40), (30, 40))
+    out = _run_coarse(f0, f1, (240, 320), (30, 40), (30, 40))          # ops.coarse_match: retries with the exact pass
     _assert_coarse(out, ref)
     assert 100 < ref['i_ids'].shape[0] < 900
+    # the asynchronous entry: without the exact pass the overflow is reported, with it one call suffices
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    with pytest.raises(_lib.FMatchError) as e:
+        ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0).read_count()
+    assert e.value.status == _lib.FM_E_CANDIDATES
+    buf = ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0, exact_screening=True)
+    assert buf.read_count() == ref['i_ids'].shape[0]
 
 
 def test_non_finite_input_is_reported():
