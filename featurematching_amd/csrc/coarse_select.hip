@@ -46,8 +46,22 @@ __global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
     // softmax denominators of this row and this column, folded from pass B's partials in a fixed order
     // (all loads independent: one round trip; no separate reduction kernel on the common path)
     float rs = 0.f, cs = 0.f;
-    for (int p = 0; p < a.splits; ++p) rs += a.rowB[((long)b * a.splits + p) * a.Lp + i];
-    for (int p = 0; p < a.panels; ++p) cs += a.colB[((long)b * a.panels + p) * a.Sp + j];
+    const float* rp = a.rowB + (long)b * a.splits * a.Lp + i;
+    const float* cp = a.colB + (long)b * a.panels * a.Sp + j;
+    for (int p = 0; p < a.splits; p += 8) {         // 8 loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (p + q < a.splits) ? rp[(long)(p + q) * a.Lp] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rs += v[q];
+    }
+    for (int p = 0; p < a.panels; p += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (p + q < a.panels) ? cp[(long)(p + q) * a.Sp] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cs += v[q];
+    }
     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmr[grow])) / rs;
     const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmc[(long)b * a.Sp + j])) / cs;
     conf = pr * pc;
