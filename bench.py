@@ -20,7 +20,9 @@ import sys
 import time
 
 # One hardware queue per HIP stream (+ the null stream): with the runtime's default of 4 queues two of the
-# bench's 4 streams share a queue and their kernels serialise (measured 9.6k -> 11.4k pairs/s at 640x480).
+# bench's streams share a queue and their kernels serialise (measured 9.6k -> 11.4k pairs/s at 640x480).
+# Three pairs in flight measured best: a fourth adds 110 MB of working set against the 256 MB Infinity Cache,
+# and more than four active queues are time-sliced by the command processor (5+ streams lose 20 %).
 # A runtime setting of the HIP process, read when the runtime initialises - hence before `import torch`.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -163,8 +165,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--window", type=int, default=5, choices=[5, 7])
     ap.add_argument("--dist", default="peaky", choices=["peaky", "borderline"])
-    ap.add_argument("--pairs", type=int, default=4, help="distinct resident input sets cycled through")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are spread over")
+    ap.add_argument("--pairs", type=int, default=3, help="distinct resident input sets cycled through")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the independent steps are spread over")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--stages", default="all", choices=["all", "coarse", "fine"],
