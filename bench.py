@@ -21,8 +21,8 @@ import time
 
 # One hardware queue per HIP stream (+ the null stream): with the runtime's default of 4 queues two of the
 # bench's streams share a queue and their kernels serialise (measured 9.6k -> 11.4k pairs/s at 640x480).
-# Three pairs in flight measured best: a fourth adds 110 MB of working set against the 256 MB Infinity Cache,
-# and more than four active queues are time-sliced by the command processor (5+ streams lose 20 %).
+# Four pairs in flight measured best with inputs streamed from HBM (12 resident input sets); more than four
+# active queues are time-sliced by the command processor (5+ streams lose 20 %).
 # A runtime setting of the HIP process, read when the runtime initialises - hence before `import torch`.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -43,9 +43,10 @@ WORKLOADS = {
 
 
 class Pair:
-    """Device-resident inputs of one batch of pairs plus the launch of one step on them."""
+    """Device-resident inputs of one batch of pairs plus the launch of one step on them.  The window
+    buffers belong to the stream the pair runs on (`share`: pairs of one stream run one after the other)."""
 
-    def __init__(self, wl, seed, window, dev, dist):
+    def __init__(self, wl, seed, window, dev, dist, share=None):
         sh = synth.config_shapes(wl)
         self.n, self.l, self.c = wl["n"], sh["l"], wl["c"]
         self.hw_c, self.hw_f, self.hw_i = (sh["hc"], sh["wc"]), (sh["hf"], sh["wf"]), (wl["h"], wl["w"])
@@ -63,8 +64,11 @@ class Pair:
         self.mix0 = torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=dev)
         self.mix1 = torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=dev)
         self.cap = self.n * self.l
-        self.win0 = torch.empty(self.cap, window * window, wl["cf"], device=dev)
-        self.win1 = torch.empty_like(self.win0)
+        if share is None:
+            self.win0 = torch.empty(self.cap, window * window, wl["cf"], device=dev)
+            self.win1 = torch.empty_like(self.win0)
+        else:
+            self.win0, self.win1 = share.win0, share.win1
         self.last = None
         self.gather = os.environ.get("FM_GATHER", "cells")      # cells | list (see ops.gather_windows)
         self.stages = "all"      # diagnostic only (--stages): "coarse" or "fine" time a part of the step
@@ -165,8 +169,10 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--window", type=int, default=5, choices=[5, 7])
     ap.add_argument("--dist", default="peaky", choices=["peaky", "borderline"])
-    ap.add_argument("--pairs", type=int, default=3, help="distinct resident input sets cycled through")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the independent steps are spread over")
+    ap.add_argument("--pairs", type=int, default=12,
+                    help="distinct resident input sets cycled through (12 x 59 MB of inputs: far beyond the 256 MB "
+                         "Infinity Cache, so every step reads its inputs from HBM)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are spread over")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--stages", default="all", choices=["all", "coarse", "fine"],
@@ -192,12 +198,15 @@ def main():
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     wl = WORKLOADS[a.workload]
     npairs = max(1, min(a.pairs, 2 if wl["n"] > 4 else a.pairs))
-    pairs = [Pair(wl, 1000 * (rank + 1) + 17 * p, a.window, dev, a.dist) for p in range(npairs)]
+    nstreams = max(1, min(a.streams, npairs))
+    pairs = []
+    for p in range(npairs):      # pair p runs on stream p % nstreams and shares that stream's window buffers
+        pairs.append(Pair(wl, 1000 * (rank + 1) + 17 * p, a.window, dev, a.dist,
+                          share=pairs[p % nstreams] if p >= nstreams else None))
 
     # Steps are independent pairs: consecutive steps go round-robin to `--streams` HIP streams so that
     # the (mostly latency-bound, small-grid) kernels of different pairs overlap on the chip.  Every input
     # set has its own buffers and its own captured graph; the timed region still covers K complete steps.
-    nstreams = max(1, min(a.streams, npairs))
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     graphs = []
     for i, p in enumerate(pairs):

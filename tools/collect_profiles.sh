@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
 rm -rf $O && mkdir -p $O
 COMMON="--steps 200 --warmup 20 --skip-cpu"
-# (1) the default command (hipGraph replay, 3 streams): per-kernel time under the bench's own concurrency
+# (1) the default command (hipGraph replay, 4 streams): per-kernel time under the bench's own concurrency
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -- python bench.py $COMMON > $O/default.json 2> $O/default.err
 echo "default done"
 # (2) the same step, one stream, eager: kernel durations without overlap (these must agree with roofline.avg_ms)
