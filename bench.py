@@ -197,7 +197,11 @@ def main():
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     wl = WORKLOADS[a.workload]
-    npairs = max(1, min(a.pairs, 2 if wl["n"] > 4 else a.pairs))
+    # enough distinct input sets to exceed the Infinity Cache several times over, not more (generating them
+    # with the portable hash RNG is the slow part of the set-up)
+    sh0 = synth.config_shapes(wl)
+    set_bytes = 4.0 * wl["n"] * (2 * sh0["l"] * wl["c"] + 2 * wl["cf"] * sh0["hf"] * sh0["wf"])
+    npairs = max(1, min(a.pairs, max(a.streams if wl["n"] <= 4 else 2, int(math.ceil(768e6 / set_bytes)))))
     nstreams = max(1, min(a.streams, npairs))
     pairs = []
     for p in range(npairs):      # pair p runs on stream p % nstreams and shares that stream's window buffers
