@@ -85,8 +85,10 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     colA = view(ws, base, lay["colA"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).max(1)
     nmr = view(ws, base, lay["nmr"], n * Lp, torch.float32).reshape(n, Lp)
     nmc = view(ws, base, lay["nmc"], n * Sp, torch.float32).reshape(n, Sp)
-    rsum = view(ws, base, lay["rsum"], n * Lp, torch.float32).reshape(n, Lp)
-    csum = view(ws, base, lay["csum"], n * Sp, torch.float32).reshape(n, Sp)
+    # softmax denominators = the sum pass's partials folded (k_cand_conf does the same for its candidates;
+    # the rsum / csum arrays are only written on the exact-screening / conf_matrix paths)
+    rsum = view(ws, base, lay["rowB"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).sum(1)
+    csum = view(ws, base, lay["colB"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
     ccount = view(ws, base, lay["cand_count"], n * Lp, torch.int32).reshape(n, Lp)
     cand_j = view(ws, base, lay["cand_j"], n * Lp * slots, torch.int32).reshape(n, Lp, slots)
     log2e = 1.4426950408889634
