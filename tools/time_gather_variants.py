@@ -48,7 +48,7 @@ def main():
         v = _lib.load()
         if path != "<shipped>":
             v = C.CDLL(os.path.abspath(path))
-            for name in ("fm_gather_windows", "fm_gather_windows_cells"):
+            for name in ("fm_gather_windows", "fm_gather_windows_cells", "fm_fine_match"):
                 res, args = _lib.SIGNATURES[name]
                 getattr(v, name).restype, getattr(v, name).argtypes = res, args
         P = lambda t: C.c_void_p(t.data_ptr())
@@ -59,6 +59,10 @@ def main():
             out.append(timed(lambda: v.fm_gather_windows_cells(P(ff), 1, 64, hf, wf, w, 4, 2, hc, wc, C.c_void_p(cells[0]),
                                                                 cells[1], C.c_void_p(cells[2]), P(buf.b_ids), P(ids),
                                                                 P(buf.count), p.cap, P(win), st))[0])
+        k0 = torch.empty(p.cap, 3, device=dev); k1 = torch.empty(p.cap, 3, device=dev)
+        tf = timed(lambda: v.fm_fine_match(P(p.win0), P(p.win1), p.cap, P(buf.count), w * w, 64, P(p.mix0), P(p.mix1),
+                                           P(buf.mkpts0_c), P(buf.mkpts1_c), 2.0, P(k0), P(k1), st))[0]
+        print(f"{os.path.basename(path):32s} fine {tf:6.1f} us")
         print(f"{os.path.basename(path):32s} img0 list {out[0]:6.1f}  cells {out[1]:6.1f}   img1 list {out[2]:6.1f}  cells {out[3]:6.1f} us")
 
 
