@@ -22,6 +22,24 @@ int choose_splits(int N, int panels, int tiles, int target) {
   return s;
 }
 
+// column splits of the sparse sum kernel: independent waves, so twice the chip's workgroup slots balance the
+// uneven number of live units per wave; a split covers at most kUnitsPerSplitMax 32-column units
+static int choose_splits_sparse(int N, int panels, int nunits, int* units_per_split) {
+  constexpr int kUnitsPerSplitMax = kUnitsPerSplit;
+  int target = 256;
+#ifdef FM_TUNE_ENV
+  if (const char* e = getenv("FM_TARGET_WGS_S")) target = atoi(e) > 0 ? atoi(e) : 256;
+#endif
+  int s = target / (N * panels > 0 ? N * panels : 1);
+  const int smin = (nunits + kUnitsPerSplitMax - 1) / kUnitsPerSplitMax;
+  if (s < smin) s = smin;
+  if (s > nunits) s = nunits;
+  if (s < 1) s = 1;
+  const int per = (nunits + s - 1) / s;
+  *units_per_split = per;
+  return (nunits + per - 1) / per;
+}
+
 CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   CoarseWs w;
   memset(&w, 0, sizeof(w));
@@ -36,6 +54,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
 #ifdef FM_TUNE_ENV
   if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : 256);
 #endif
+  w.splits_s = choose_splits_sparse(N, w.panels, w.Sp / 32, &w.units_s);
   const size_t rows = (size_t)N * w.Lp, cols = (size_t)N * w.Sp;
   const size_t nblk = (rows * slots + 255) / 256;
   size_t o = 0;
@@ -47,21 +66,24 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.cell1 = take(cols * 4);
   w.ties0 = take((kTieCap + 1) * 4);
   w.ties1 = take((kTieCap + 1) * 4);
+  w.rowmax_u = take(rows * 4);
+  w.colmax_u = take(cols * 4);
+  w.blocktot = take(nblk * 4);
   w.scalars = take(sizeof(Scalars));
   w.zero_end = o;
-  w.blocktot = take(nblk * 4);
   w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
   w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
   w.bmax0 = take(rows / 32 * 4); w.bmax1 = take(cols / 32 * 4);
-  w.rowA = take(rows * w.splits0 * 4); w.colA = take(cols * w.panels * kColParts * 4);
+  w.emarg = take((size_t)N * 4);
+  w.rowS = take(rows * w.splits_s * 4); w.colS = take(cols * w.panels * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * kColParts * 4);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
   w.rsum = take(rows * 4); w.csum = take(cols * 4);
   w.nmr2 = take(rows * 4); w.nmc2 = take(cols * 4);
-  w.umax = take(rows / 32 * (cols / N / 32) * 4); w.emarg = take((size_t)N * 4);
+  w.umax = take(rows / 32 * (cols / N / 32) * 4);
+  w.dense_map = take(rows / 32 * (cols / N / 32) * 4);
   w.cand_j = take(rows * slots * 4); w.cand_conf = take(rows * slots * 4); w.rowbest = take(rows * 4);
-  w.keep_j = take(rows * slots * 4); w.keep_conf = take(rows * slots * 4); w.rowcnt = take(rows * 4);
   w.total = o;
   return w;
 }
@@ -94,7 +116,8 @@ extern "C" int fm_default_cand_slots(float thr) {
   return s;
 }
 
-static bool valid_slots(int s) { return s >= 1 && s <= 64 && (s & (s - 1)) == 0; }
+// a power of two in [4, 64]: a row's slots are adjacent lanes of one wave and k_keep_emit keeps 256/slots <= 64 rows
+static bool valid_slots(int s) { return s >= 4 && s <= 64 && (s & (s - 1)) == 0; }
 
 extern "C" int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t* bytes) {
   if (!bytes) return FM_E_NULL;
@@ -104,22 +127,32 @@ extern "C" int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_sl
   return FM_OK;
 }
 
+static int check_coarse_shape(int N, int L, int S, int C, int cand_slots) {
+  if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
+  if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
+  return FM_OK;
+}
+
 // Diagnostic: the workspace layout (ints then byte offsets), so that tests can inspect the
 // intermediate statistics of a run.  out[0..9] = N,L,S,C,Lp,Sp,panels,tiles,splits,slots;
 // out[10..] = cand_count, colbest, scalars, blocktot, hi0, lo0, hi1, lo1, norm0, norm1, bmax0, bmax1,
-// rowA, colA, rowB, colB, nmr, nmc, rsum, csum, cand_j, cand_conf, rowbest, keep_j, keep_conf, rowcnt, total.
+// rowS, colS, rowB, colB, nmr, nmc, rsum, csum, cand_j, cand_conf, rowbest, umax, dense_map, rowmax_u,
+// colmax_u, splits_s, units_s, total  (40 values).
 extern "C" int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out) {
   if (!out) return FM_E_NULL;
-  if (n_out < 37) return FM_E_SHAPE;
+  if (n_out < 40) return FM_E_SHAPE;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  const int64_t v[37] = {w.N, w.L, w.S, w.C, w.Lp, w.Sp, w.panels, w.tiles, w.splits, w.slots,
+  const int64_t v[40] = {w.N, w.L, w.S, w.C, w.Lp, w.Sp, w.panels, w.tiles, w.splits, w.slots,
                          (int64_t)w.cand_count, (int64_t)w.colbest, (int64_t)w.scalars, (int64_t)w.blocktot,
                          (int64_t)w.hi0, (int64_t)w.lo0, (int64_t)w.hi1, (int64_t)w.lo1, (int64_t)w.norm0,
-                         (int64_t)w.norm1, (int64_t)w.bmax0, (int64_t)w.bmax1, (int64_t)w.rowA, (int64_t)w.colA,
+                         (int64_t)w.norm1, (int64_t)w.bmax0, (int64_t)w.bmax1, (int64_t)w.rowS, (int64_t)w.colS,
                          (int64_t)w.rowB, (int64_t)w.colB, (int64_t)w.nmr, (int64_t)w.nmc, (int64_t)w.rsum,
                          (int64_t)w.csum, (int64_t)w.cand_j, (int64_t)w.cand_conf, (int64_t)w.rowbest,
-                         (int64_t)w.keep_j, (int64_t)w.keep_conf, (int64_t)w.rowcnt, (int64_t)w.total};
-  for (int i = 0; i < 37; ++i) out[i] = v[i];
+                         (int64_t)w.umax, (int64_t)w.dense_map, (int64_t)w.rowmax_u, (int64_t)w.colmax_u,
+                         w.splits_s, w.units_s, (int64_t)w.total};
+  for (int i = 0; i < 40; ++i) out[i] = v[i];
   return FM_OK;
 }
 
@@ -143,10 +176,14 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   // one dispatch: clear the per-call counters, split both images into float16 planes
   hipError_t e = launch_prep(feat0, feat1, C, w, base, st);
   if (e != hipSuccess) return (int)e;
+  // max pass: row / column / unit maxima of the hi x hi product (atomicMax: no partials, no reduction kernel)
   e = launch_corr(0, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
-  e = launch_reduce(0, w, base, inv_ct, st);
+  // sparse sum kernel: stabilisers, live units, exact terms of the few significant entries, candidates;
+  // flags the units with too many significant entries (flat similarity) for the dense kernel
+  e = launch_sum_sparse(feat0, feat1, C, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
+  // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): exits at once when nothing is flagged
   e = launch_corr(1, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
   // The common path goes straight to the assignment (k_cand_conf folds the softmax denominators of its
@@ -156,7 +193,7 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
     e = launch_reduce(1, w, base, inv_ct, st);
     if (e != hipSuccess) return (int)e;
   }
-  if (exact_screening) {       // exits immediately unless pass B's screening overflowed a row's slots
+  if (exact_screening) {       // exits immediately unless the sum kernels' screening overflowed a row's slots
     e = launch_corr(2, w, base, inv_ct, thr, st);
     if (e != hipSuccess) return (int)e;
   }
@@ -164,7 +201,7 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
     e = launch_corr(3, w, base, inv_ct, thr, st, conf_matrix);
     if (e != hipSuccess) return (int)e;
   }
-  e = launch_select(w, base, feat0, feat1, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
+  e = launch_select(w, base, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
                     b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, exact_screening, st);
   return (int)e;
 }
@@ -189,19 +226,35 @@ extern "C" int fm_coarse_cell_maps(void* workspace, int N, int L, int S, int C, 
 extern "C" int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_slots, float temperature,
                                     float thr, int mode, void* stream) {
   if (!workspace) return FM_E_NULL;
-  if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
-  if (!valid_channels(C) || !valid_slots(cand_slots) || (mode < 0 || mode > 2)) return FM_E_UNSUPPORTED;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
+  if (mode < 0 || mode > 2) return FM_E_UNSUPPORTED;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   hipStream_t st = (hipStream_t)stream;
   return (int)launch_corr(mode, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st);
 }
 
-// Diagnostic: zero the per-call counters (what fm_coarse_match does first).
+// Diagnostic: launch the sparse sum kernel alone on a workspace a previous fm_coarse_match filled.
+extern "C" int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
+                                          int C, int cand_slots, float temperature, float thr, void* stream) {
+  if (!workspace || !feat0 || !feat1) return FM_E_NULL;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  return (int)launch_sum_sparse(feat0, feat1, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr,
+                                (hipStream_t)stream);
+}
+
+// Diagnostic: zero the candidate counters and the scalars, so that the sum kernels can be launched again on a
+// workspace whose max-pass results are kept.
 extern "C" int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream) {
   if (!workspace) return FM_E_NULL;
-  if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  return (int)hipMemsetAsync((char*)workspace + w.zero_begin, 0, w.zero_end - w.zero_begin, (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync((char*)workspace + w.cand_count, 0, (size_t)w.N * w.Lp * 4, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemsetAsync((char*)workspace + w.scalars, 0, sizeof(Scalars), (hipStream_t)stream);
 }
 
 extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, void* stream) {

@@ -44,7 +44,7 @@
 //     workgroup's single column partial per panel.
 #include <stdlib.h>
 
-#include "fm_internal.h"
+#include "fm_device.h"
 
 namespace fm {
 
@@ -61,14 +61,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef FM_NBUF_MAX
 #define FM_NBUF_MAX 4       // LDS tile ring depth of the max pass (32 KiB hi tiles at C = 256)
 #endif
-constexpr float kSkipLog2 = 32.f;     // block-sparse threshold: entries below 2^-32 of every stabiliser
 constexpr int kCandQueue = 64;        // candidates a wave parks in LDS per sweep (one per lane at the hand-over)
 
 struct CorrArgs {
   const _Float16* hi0; const _Float16* lo0; const _Float16* hi1; const _Float16* lo1;
   const float* nmr; const float* nmc;
   float* rowpart; float* colpart;
+  unsigned* rowmax_u; unsigned* colmax_u;   // MODE 0: row / column maxima of the f16 product (ord_encode, atomicMax)
   float* umax;            // [N][Lp/32][Sp/32] unit maxima of the raw f16 product (written by MODE 0)
+  const float* dense_map; // MODE 1: [N][Lp/32][Sp/32] 1.0 = unit left to this kernel by the sparse sum kernel
+  const int* dense_units; // MODE 1: number of such units (0: nothing to do)
   const float* emarg;     // [N] log2-domain bound of |f16 product - exact product| * k
   int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
   float* conf;            // MODE 3: dense [N,L,S] output
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   if (MODE == 2 && !(*a.flags & FM_INT_SCREEN_OVERFLOW)) return;   // uniform: fast screening sufficed
+  if (MODE == 1 && *a.dense_units == 0) return;                    // uniform: the sparse sum kernel handled every unit
 #ifdef FM_DIAG_CLOCK       // diagnostic build only: shader-clock stamps (s_memtime) per phase of every wave
   const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long diag_mfma = 0, diag_epi = 0, diag_bar = 0, diag_pro = 0, diag_loop_end = 0;
@@ -196,6 +199,22 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const int t0 = split * a.tiles_per_split;
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
+  if (MODE == 1) {
+    // Does the sparse sum kernel leave anything to this workgroup's block (8 row blocks x 2 units per tile)?
+    // Usually not: then its partial sums are zero and nothing is loaded.
+    const int nu = 2 * (t1 - t0);
+    bool any = false;
+    for (int idx = tid; idx < 8 * nu; idx += 512) {
+      const int rb = idx / nu, u = idx - rb * nu;
+      any = any || a.dense_map[((long)b * (a.Lp / 32) + panel * 8 + rb) * (a.Sp / 32) + 2 * t0 + u] != 0.f;
+    }
+    if (!__syncthreads_or((int)any)) {
+      if (tid < kPanelRows) a.rowpart[((long)b * a.splits + split) * a.Lp + panel * kPanelRows + tid] = 0.f;
+      float* co = a.colpart + ((long)b * a.panels + panel) * a.Sp;
+      for (int c = t0 * kTileCols + tid; c < t1 * kTileCols; c += 512) co[c] = 0.f;
+      return;
+    }
+  }
   const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};   // fragment-major
   // Small per-workgroup tables live in their OWN static LDS objects, not in the dynamic tile ring: hipcc
   // orders every LDS access it can see against outstanding LDS-DMA writes it cannot tell apart from it -
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     // wave 0 brings the 64 column stabilisers, wave 1 the 16 unit maxima of (wave, unit) = (lane/2, lane%2).
     if (MODE && wv == 0) glds4(a.nmc + (long)b * a.Sp + t * kTileCols + lane, meta + (buf & 1) * META);
     if (SPARSE && wv == 1 && lane < 16)
-      glds4(a.umax + ((long)b * (a.Lp / 32) + panel * 8 + (lane >> 1)) * (a.Sp / 32) + 2 * t + (lane & 1),
+      glds4((MODE == 1 ? a.dense_map : a.umax) + ((long)b * (a.Lp / 32) + panel * 8 + (lane >> 1)) * (a.Sp / 32) + 2 * t + (lane & 1),
             meta + (buf & 1) * META + 64);
   };
 #pragma unroll
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     const float nv = lane < 32 ? a.nmr[(long)b * a.Lp + wrow0 + lane] : -INFINITY;
     if (lane < 32) nmr_lds[lane] = nv;
     // padded rows (>= L) never contribute: keep them out of the wave's largest stabiliser
-    if (SPARSE) { wmax_nmr = wave_max64(wrow0 + lane < a.L ? nv : -INFINITY); emarg = a.emarg[b]; }
+    if (MODE == 2) { wmax_nmr = wave_max64(wrow0 + lane < a.L ? nv : -INFINITY); emarg = a.emarg[b]; }
   }
   const bool row_edge = (wrow0 + 32 > a.L);     // wave-uniform: some of this wave's rows are padding
 
@@ -513,7 +532,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nmc_u), "+v"(um));
     }
     bool skip = false;
-    if (SPARSE) {
+    if (MODE == 1) {        // only the units the sparse sum kernel flagged (um = 1.0 / 0.0)
+      skip = __builtin_amdgcn_readfirstlane((int)(um == 0.f));
+    } else if (MODE == 2) {
       const float top = __builtin_fmaf(um, a.k, emarg);             // >= k * (exact product), log2 domain
       const float cmax = wave_max64(t * kTileCols + (u & 1) * 32 + r < a.S ? nmc_u : -INFINITY);
       skip = __builtin_amdgcn_readfirstlane((int)((top + wmax_nmr < -kSkipLog2) && (top + cmax < -kSkipLog2)));
@@ -551,7 +572,10 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         float cv = pv[0];
 #pragma unroll
         for (int w8 = 1; w8 < 8; ++w8) cv = MODE ? cv + pv[w8] : fmaxf(cv, pv[w8]);
-        colout[t * kTileCols + lane] = cv;
+        if (MODE) colout[t * kTileCols + lane] = cv;
+        else if (t * kTileCols + lane < a.S)      // max is exact and order independent: no partials, no reduction kernel
+          __hip_atomic_fetch_max(a.colmax_u + (long)b * a.Sp + t * kTileCols + lane, ord_encode(cv), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -588,9 +612,18 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #pragma unroll
   for (int g = 0; g < 16; ++g) rstat[g] = half_reduce32<MODE != 0>(rstat[g]);
   if (r == 0) {
-    float* out = a.rowpart + ((long)b * a.splits + split) * a.Lp + wrow0 + 4 * h;
+    if (MODE) {
+      float* out = a.rowpart + ((long)b * a.splits + split) * a.Lp + wrow0 + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) out[(g & 3) + 8 * (g >> 2)] = rstat[g];
+      for (int g = 0; g < 16; ++g) out[(g & 3) + 8 * (g >> 2)] = rstat[g];
+    } else {
+      unsigned* out = a.rowmax_u + (long)b * a.Lp + wrow0 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        if (wrow0 + 4 * h + (g & 3) + 8 * (g >> 2) < a.L)
+          __hip_atomic_fetch_max(out + (g & 3) + 8 * (g >> 2), ord_encode(rstat[g]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   commit_candidates();
 #ifdef FM_DIAG_CLOCK       // candidate slots of the padded rows (>= L, never used) carry the stamps of 64 waves
@@ -625,8 +658,11 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.nmr = (const float*)(base + (mode >= 2 ? w.nmr2 : w.nmr));
   a.nmc = (const float*)(base + (mode >= 2 ? w.nmc2 : w.nmc));
   a.conf = conf;
-  a.rowpart = (float*)(base + (mode ? w.rowB : w.rowA));
-  a.colpart = (float*)(base + (mode ? w.colB : w.colA));
+  a.rowpart = (float*)(base + w.rowB);
+  a.colpart = (float*)(base + w.colB);
+  a.rowmax_u = (unsigned*)(base + w.rowmax_u); a.colmax_u = (unsigned*)(base + w.colmax_u);
+  a.dense_map = (const float*)(base + w.dense_map);
+  a.dense_units = &((const Scalars*)(base + w.scalars))->dense_units;
   a.umax = (float*)(base + w.umax); a.emarg = (const float*)(base + w.emarg);
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
   a.cand_x = (float*)(base + w.cand_conf);   // raw dot product now, replaced by conf in k_cand_conf

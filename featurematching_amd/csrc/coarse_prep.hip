@@ -1,14 +1,14 @@
 // Coarse stage, kernels around the correlation sweeps:
 //   k_prep_split  : float32 descriptors -> two float16 planes (hi, lo = x - hi) + row norms
-//   k_reduce      : partial maxima of pass A -> per-row / per-column stabilisers;
-//                   partial sums of pass B -> softmax denominators
+//   k_reduce_sums : partial sums of the sum kernels -> softmax denominators of every row / column
+//                   (exact screening and dense conf_matrix only)
 //
 // Reference arithmetic being reproduced: network/utils/coarse_matching_new.py:64-68
 // (sim = (f0/sqrt(C)) . (f1/sqrt(C)) / T, softmax over dim 1 and dim 2).  The float16
 // pair (hi, lo) carries 22 mantissa bits, so hi*hi + hi*lo + lo*hi on the f16 matrix
 // cores reproduces the float32 product to ~2^-22 relative while running at the f16
 // MFMA rate; the single-plane product (hi*hi) is only used to bound the row/column
-// maxima, with the rigorous margin computed in k_reduce.
+// maxima, with the rigorous margin of fm_device.h.
 #include "fm_internal.h"
 
 namespace fm {
@@ -38,7 +38,7 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 //   straight into registers; image 1 blocks are copied 1 KiB at a time into LDS by LDS-DMA (lane-linear
 //   image: the ds_read_b128 of lane l at l*16 is bank-conflict free with no swizzle), or fetched directly
 //   by the block-sparse path.
-// A workgroup that sees a non-finite / out-of-range value reports +inf as its block norm; k_reduce<0>
+// A workgroup that sees a non-finite / out-of-range value reports +inf as its block norm; k_sum_sparse
 // turns that into FM_DEV_RANGE (the flag word itself is cleared by this kernel, so it cannot be set here).
 template <int C>
 __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
@@ -133,111 +133,65 @@ hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const C
   return hipGetLastError();
 }
 
-// grid (chunks, N, 2): z = 0 rows of image 0 (statistic over j), z = 1 columns (over i).
-// MODE 0: part = raw dot-product maxima of pass A (float16 hi plane only) -> stabilisers.
-//   Error of that product against the exact one: |fl16(a) fl16(b) - a b| <= 2^-10 (1+2^-12) |a||b|
-//   for normal halves, + 2^-25 per operand below the half normal range, so
-//     |max~ - max| <= E = (2^-10 * 1.01 * |a_i| * max_j|b_j| + 2^-24 sqrt(C) (|a_i| + max_j|b_j|)) / (C T).
-//   The stabiliser is the LOWER bound m^ = max~ - E: then every s - m^ <= 2E (no overflow in exp)
-//   and conf > thr  =>  softmax > thr  =>  s - m^ > ln(thr), which is the screening test of pass B.
-//   out = -m^ * log2(e).
-// MODE 1: part = partial sums of exp(s - m^) of pass B -> out = their sum (fixed order: deterministic).
+// Softmax denominators of EVERY row and column (only the exact screening pass and the dense conf_matrix need
+// them; the common path folds the denominators of its candidates in k_select).
+// grid (chunks, N, 2): z = 0 rows of image 0 (sum over j), z = 1 columns (over i).
+// The partial sums come from the sparse sum kernel (partS) and, when it flagged units, from the dense one
+// (partB); out = their sum in a fixed order (deterministic), nm2 = nm - log2(out) the log-softmax offset.
 // Workgroup = 16 consecutive entries x 16 part-groups: every thread folds ~nparts/16 partials (all
 // loads independent and in flight together), then the 16 groups are folded through LDS in a fixed order.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ rowP, const float* __restrict__ colP,
-                                                const float* __restrict__ norm0, const float* __restrict__ norm1,
-                                                const float* __restrict__ bmax0, const float* __restrict__ bmax1,
-                                                float* __restrict__ rout, float* __restrict__ cout_, int Lp, int Sp,
-                                                int rparts, int cparts, float inv_ct, float sqrt_c, int prows0, int prows1,
-                                                const float* __restrict__ nm_r, const float* __restrict__ nm_c,
-                                                float* __restrict__ nm2_r, float* __restrict__ nm2_c,
-                                                int* __restrict__ cand_count, unsigned* __restrict__ flags,
-                                                float* __restrict__ emarg) {
+__global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ rowS, const float* __restrict__ colS,
+                                                     const float* __restrict__ rowB, const float* __restrict__ colB,
+                                                     float* __restrict__ rout, float* __restrict__ cout_, int Lp, int Sp,
+                                                     int rpartsS, int rpartsB, int cparts,
+                                                     const float* __restrict__ nm_r, const float* __restrict__ nm_c,
+                                                     float* __restrict__ nm2_r, float* __restrict__ nm2_c,
+                                                     int* __restrict__ cand_count, const Scalars* __restrict__ scal) {
   const int side = blockIdx.z;
   const int b = blockIdx.y;
   const int len = side ? Sp : Lp;
   if ((int)blockIdx.x * 16 >= len) return;
-  const int nparts = side ? cparts : rparts;
-  const float* part = (side ? colP : rowP) + (long)b * nparts * len;
-  float* out = (side ? cout_ : rout) + (long)b * len;
+  const bool dense = scal->dense_units > 0;
   const int cx = threadIdx.x & 15, pg = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + cx;       // len is a multiple of 64
-
   __shared__ float fold[16][17];
-  __shared__ float sm[4], sm_own[4];
-  float acc = MODE ? 0.f : -INFINITY;
+  float acc = 0.f;
+  {
+    const int nparts = side ? cparts : rpartsS;
+    const float* part = (side ? colS : rowS) + (long)b * nparts * len;
 #pragma unroll 4
-  for (int p = pg; p < nparts; p += 16) {
-    const float v = part[(long)p * len + idx];
-    acc = MODE ? acc + v : fmaxf(acc, v);
+    for (int p = pg; p < nparts; p += 16) acc += part[(long)p * len + idx];
+  }
+  if (dense) {
+    const int nparts = side ? cparts : rpartsB;
+    const float* part = (side ? colB : rowB) + (long)b * nparts * len;
+#pragma unroll 4
+    for (int p = pg; p < nparts; p += 16) acc += part[(long)p * len + idx];
   }
   fold[pg][cx] = acc;
-
-  float om = 0.f;
-  if (MODE == 0) {   // largest descriptor norm of the OTHER image (for the screening margin)
-    const int other_len = side ? Lp : Sp;
-    const int prows = side ? prows0 : prows1;      // granularity of the OTHER image's block norms
-    const float* obm = (side ? bmax0 : bmax1) + (long)b * (other_len / prows);
-    for (int k = threadIdx.x; k < other_len / prows; k += 256) om = fmaxf(om, obm[k]);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) om = fmaxf(om, __shfl_xor(om, m));
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = om;
-    if (side == 0 && blockIdx.x == 0) {          // this workgroup also publishes the pair's f16 error margin
-      float own = 0.f;
-      for (int k = threadIdx.x; k < Lp / prows0; k += 256) own = fmaxf(own, bmax0[(long)b * (Lp / prows0) + k]);
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) own = fmaxf(own, __shfl_xor(own, m));
-      if ((threadIdx.x & 63) == 0) sm_own[threadIdx.x >> 6] = own;
-    }
-  }
   __syncthreads();
   if (pg != 0) return;
   float v = fold[0][cx];
 #pragma unroll
-  for (int g = 1; g < 16; ++g) v = MODE ? v + fold[g][cx] : fmaxf(v, fold[g][cx]);
-  if (MODE == 1) {
-    out[idx] = v;
-    // log-softmax offset for the exact screening of pass C: log2 P = x*k + (nm - log2(sum))
-    const long gi = (long)b * len + idx;
-    (side ? nm2_c : nm2_r)[gi] = (side ? nm_c : nm_r)[gi] - __log2f(v);
-    // pass B overflowed some row's candidate slots: pass C refills the lists from scratch
-    if (side == 0 && (*flags & FM_INT_SCREEN_OVERFLOW)) cand_count[gi] = 0;
-    return;
-  }
-  om = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-  // a prep workgroup that met NaN/Inf/|x| >= 32768 reported +inf (either image is seen by one side)
-  if (!(om < INFINITY) && blockIdx.x == 0 && cx == 0) atomicOr(flags, (unsigned)FM_DEV_RANGE);
-  if (side == 0 && blockIdx.x == 0 && cx == 0) {
-    // log2-domain bound of k * |f16 product - exact product| over the whole pair: lets pass B turn the
-    // unit maxima of pass A into upper bounds of the exact similarity (block-sparse skipping)
-    const float own = fmaxf(fmaxf(sm_own[0], sm_own[1]), fmaxf(sm_own[2], sm_own[3]));
-    emarg[b] = ((9.8633e-4f * own * om + 5.9605e-8f * sqrt_c * (own + om)) * inv_ct + 1e-6f) * kLog2e + 1e-3f;
-  }
-  float raw = v;
-  if (!(raw > -INFINITY)) raw = 0.f;   // padded row/column: never used
-  const float nrm = ((side ? norm1 : norm0) + (long)b * len)[idx];
-  const float e = (9.8633e-4f * nrm * om + 5.9605e-8f * sqrt_c * (nrm + om)) * inv_ct + 1e-6f;
-  const float mhat = raw * inv_ct - e;
-  out[idx] = -mhat * kLog2e;
+  for (int g = 1; g < 16; ++g) v += fold[g][cx];
+  float* out = (side ? cout_ : rout) + (long)b * len;
+  out[idx] = v;
+  // log-softmax offset for the exact screening / dense conf_matrix sweeps: log2 P = x*k + (nm - log2(sum))
+  const long gi = (long)b * len + idx;
+  (side ? nm2_c : nm2_r)[gi] = (side ? nm_c : nm_r)[gi] - __log2f(v);
+  // the sum kernels overflowed some row's candidate slots: the exact screening sweep refills the lists from scratch
+  if (side == 0 && (scal->flags & FM_INT_SCREEN_OVERFLOW)) cand_count[gi] = 0;
 }
 
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st) {
+  (void)mode; (void)inv_ct;
   const int chunks = (max(w.Lp, w.Sp) + 15) / 16;
   const dim3 grid(chunks, w.N, 2);
-  const float* n0 = (const float*)(base + w.norm0); const float* n1 = (const float*)(base + w.norm1);
-  const float* b0 = (const float*)(base + w.bmax0); const float* b1 = (const float*)(base + w.bmax1);
-  if (mode == 0)
-    hipLaunchKernelGGL(k_reduce<0>, grid, dim3(256), 0, st, (const float*)(base + w.rowA),
-                       (const float*)(base + w.colA), n0, n1, b0, b1, (float*)(base + w.nmr), (float*)(base + w.nmc),
-                       w.Lp, w.Sp, w.splits0, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, 32, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, (unsigned*)(base + w.scalars), (float*)(base + w.emarg));
-  else
-    hipLaunchKernelGGL(k_reduce<1>, grid, dim3(256), 0, st, (const float*)(base + w.rowB),
-                       (const float*)(base + w.colB), n0, n1, b0, b1, (float*)(base + w.rsum), (float*)(base + w.csum),
-                       w.Lp, w.Sp, w.splits, w.panels * kColParts, inv_ct, sqrtf((float)w.C), 32, 32,
-                       (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
-                       (float*)(base + w.nmc2), (int*)(base + w.cand_count), (unsigned*)(base + w.scalars), nullptr);
+  hipLaunchKernelGGL(k_reduce_sums, grid, dim3(256), 0, st, (const float*)(base + w.rowS), (const float*)(base + w.colS),
+                     (const float*)(base + w.rowB), (const float*)(base + w.colB), (float*)(base + w.rsum),
+                     (float*)(base + w.csum), w.Lp, w.Sp, w.splits_s, w.splits, w.panels,
+                     (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
+                     (float*)(base + w.nmc2), (int*)(base + w.cand_count), (const Scalars*)(base + w.scalars));
   return hipGetLastError();
 }
 

@@ -1,7 +1,7 @@
-// Coarse stage, sparse assignment on the candidate list of pass B:
-//   k_cand_conf : float32 conf of every candidate from its pass-B dot product, best conf per row / column
-//   k_cand_keep : threshold + mutual nearest neighbour + border, sort a row's matches by j
-//   k_emit      : deterministic prefix offsets -> outputs in (b, i, j) order
+// Coarse stage, sparse assignment on the candidate list of the sum kernels:
+//   k_cand_conf : float32 conf of every candidate from its dot product, best conf per row / column
+//   k_keep_emit : threshold + mutual nearest neighbour + border, a row's matches sorted by j, deterministic
+//                 prefix offsets (ticket-ordered look-back over the workgroup totals) -> outputs in (b, i, j) order
 //
 // Follows network/utils/coarse_matching_new.py:99-141.  Every entry of the L x S matrix
 // that is not a candidate has conf <= thr, so it can neither pass :99 nor beat a surviving
@@ -12,14 +12,14 @@
 namespace fm {
 
 struct SelArgs {
-  const float* feat0; const float* feat1;
   const float* nmr; const float* nmc;
-  const float* rowB; const float* colB;   // partial sums of pass B: rows [N][splits][Lp], columns [N][panels][Sp]
-  int exact;                              // pass C ran (exact screening): its overflow is then FM_DEV_CANDIDATES already
+  const float* rowS; const float* colS;   // partial sums of the sparse sum kernel: rows [N][splits_s][Lp], columns [N][panels][Sp]
+  const float* rowB; const float* colB;   // ... of the dense sum kernel (valid when it had units): rows [N][splits][Lp]
+  int exact;                              // exact screening ran: its overflow is then FM_DEV_CANDIDATES already
   const int* cand_count; const int* cand_j;
   float* cand_conf; float* rowbest; unsigned* colbest;
-  int* keep_j; float* keep_conf; int* rowcnt; int* blocktot; Scalars* scal;
-  int N, L, S, C, Lp, Sp, splits, panels, slots;
+  int* blocktot; Scalars* scal;
+  int N, L, S, C, Lp, Sp, splits, splits_s, panels, slots;
   int h0c, w0c, h1c, w1c, border;
   float k, thr, scale_px;
   const float* scale0; const float* scale1;
@@ -46,21 +46,22 @@ __global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
     // softmax denominators of this row and this column, folded from pass B's partials in a fixed order
     // (all loads independent: one round trip; no separate reduction kernel on the common path)
     float rs = 0.f, cs = 0.f;
-    const float* rp = a.rowB + (long)b * a.splits * a.Lp + i;
-    const float* cp = a.colB + (long)b * a.panels * a.Sp + j;
-    for (int p = 0; p < a.splits; p += 8) {         // 8 loads in flight, added in index order
-      float v[8];
+    auto fold = [](const float* p, int n, long pitch) {       // 8 loads in flight, added in index order
+      float t = 0.f;
+      for (int q0 = 0; q0 < n; q0 += 8) {
+        float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = (p + q < a.splits) ? rp[(long)(p + q) * a.Lp] : 0.f;
+        for (int q = 0; q < 8; ++q) v[q] = (q0 + q < n) ? p[(long)(q0 + q) * pitch] : 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) rs += v[q];
-    }
-    for (int p = 0; p < a.panels; p += 8) {
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = (p + q < a.panels) ? cp[(long)(p + q) * a.Sp] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) cs += v[q];
+        for (int q = 0; q < 8; ++q) t += v[q];
+      }
+      return t;
+    };
+    rs = fold(a.rowS + (long)b * a.splits_s * a.Lp + i, a.splits_s, a.Lp);
+    cs = fold(a.colS + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
+    if (a.scal->dense_units > 0) {      // the dense sum kernel had units of its own
+      rs += fold(a.rowB + (long)b * a.splits * a.Lp + i, a.splits, a.Lp);
+      cs += fold(a.colB + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
     }
     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmr[grow])) / rs;
     const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmc[(long)b * a.Sp + j])) / cs;
@@ -79,8 +80,19 @@ __device__ __forceinline__ bool interior(int id, int hh, int ww, int bd) {
   return y >= bd && y < hh - bd && x >= bd && x < ww - bd;
 }
 
-__global__ __launch_bounds__(256) void k_cand_keep(SelArgs a) {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+// One workgroup = 256 (row, slot) pairs = 256/slots consecutive rows.  Workgroups take a TICKET (their logical
+// index in row order) so that a workgroup only ever waits for workgroups that have already started.
+__global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
+  __shared__ int s_ticket;
+  __shared__ int sm[4];
+  __shared__ int rowoff[64], rowcnt[64];
+  __shared__ int s_kj[256];
+  __shared__ float s_kc[256];
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&a.scal->ticket, 1);
+  __syncthreads();
+  const int blk = s_ticket;
+  const int lane = threadIdx.x & 63;
+  const long gid = (long)blk * 256 + threadIdx.x;
   const long grow = gid / a.slots;
   const int slot = (int)(gid - grow * a.slots);
   const int b = (int)(grow / a.Lp);
@@ -99,47 +111,40 @@ __global__ __launch_bounds__(256) void k_cand_keep(SelArgs a) {
   // rank among the row's kept entries by ascending j (torch.where order, :109)
   const int kj = keep ? j : 0x7fffffff;
   int rank = 0, nkeep = 0;
-  const int lane = threadIdx.x & 63;
   const int base = lane - slot;
   for (int s = 0; s < a.slots; ++s) {
     const int oj = __shfl(kj, base + s);
     rank += (oj < kj) ? 1 : 0;
     nkeep += (oj != 0x7fffffff) ? 1 : 0;
   }
-  if (keep) {
-    a.keep_j[grow * a.slots + rank] = j;
-    a.keep_conf[grow * a.slots + rank] = conf;
-  }
-  if (slot == 0 && b < a.N) a.rowcnt[grow] = nkeep;
-  // matches of this workgroup's rows
-  __shared__ int sm[4];
+  const int q = threadIdx.x / a.slots;                 // row within the workgroup (< 64: slots >= 4)
+  if (keep) { s_kj[q * a.slots + rank] = j; s_kc[q * a.slots + rank] = conf; }
+  if (slot == 0) rowcnt[q] = nkeep;
+  // matches of this workgroup's rows -> published at once (value and flag in one word)
   int tot = (slot == 0) ? nkeep : 0;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
   if (lane == 0) sm[threadIdx.x >> 6] = tot;
   __syncthreads();
-  if (threadIdx.x == 0) a.blocktot[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
-}
-
-__global__ __launch_bounds__(256) void k_emit(SelArgs a) {
-  __shared__ int sm[4];
-  __shared__ int rowoff[256];
-  const int lane = threadIdx.x & 63;
-  const int rows_per_block = 256 / a.slots;                  // <= 64: this workgroup's rows fit one wave
-  const long row0 = (long)blockIdx.x * rows_per_block;
-  const long total_rows = (long)a.N * a.Lp;
-  // this workgroup's row counts, issued together with the totals of the workgroups before it
-  int cntq = 0;
-  if (threadIdx.x < rows_per_block && row0 + threadIdx.x < total_rows) cntq = a.rowcnt[row0 + threadIdx.x];
-  // exclusive prefix of the workgroup totals before this one (fixed order -> deterministic)
+  const int total = sm[0] + sm[1] + sm[2] + sm[3];
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&a.blocktot[blk], total | (int)0x40000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // exclusive prefix of the totals of the workgroups before this one (fixed order of integer adds)
   int pre = 0;
-  for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) pre += a.blocktot[k];
+  for (int k = threadIdx.x; k < blk; k += 256) {
+    int v;
+    do { v = __hip_atomic_load(&a.blocktot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v & 0x40000000));
+    pre += v & 0x3fffffff;
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m);
+  __syncthreads();
   if (lane == 0) sm[threadIdx.x >> 6] = pre;
   __syncthreads();
   pre = sm[0] + sm[1] + sm[2] + sm[3];
+  const int rows_per_block = 256 / a.slots;
   if (threadIdx.x < 64) {       // wave 0: inclusive scan of the row counts
+    const int cntq = threadIdx.x < rows_per_block ? rowcnt[threadIdx.x] : 0;
     int incl = cntq;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -147,27 +152,21 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
       if (lane >= d) incl += o;
     }
     if (threadIdx.x < rows_per_block) rowoff[threadIdx.x] = pre + incl - cntq;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 63) {
+    if (blk == (int)gridDim.x - 1 && threadIdx.x == 63) {
       const int run = pre + incl;
       a.d_count[0] = run;
-      // without the exact-screening pass an overflow of pass B's candidate slots is final
+      // without the exact-screening pass an overflow of the sum kernels' candidate slots is final
       unsigned fl = a.scal->flags;
       if (!a.exact && (fl & (unsigned)FM_INT_SCREEN_OVERFLOW)) fl |= (unsigned)FM_DEV_CANDIDATES;
       a.d_count[1] = (int)((fl & 7u) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
     }
   }
   __syncthreads();
-  const int q = threadIdx.x / a.slots;
-  const int slot = threadIdx.x - q * a.slots;
-  const long grow = row0 + q;
-  if (grow >= total_rows) return;
-  if (slot >= a.rowcnt[grow]) return;
+  if (b >= a.N || slot >= rowcnt[q]) return;
   const long o = (long)rowoff[q] + slot;
   if (o >= a.cap) return;
-  const int b = (int)(grow / a.Lp);
-  const int i = (int)(grow - (long)b * a.Lp);
-  const int j = a.keep_j[grow * a.slots + slot];
-  a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = j;
+  const int jj = s_kj[q * a.slots + slot];
+  a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = jj;
   // cell -> match maps: with exact ties the largest match index keeps the cell, every other tied match
   // is listed once (whoever loses the atomicMax, now or when it is displaced later, is the one listed)
   {
@@ -175,36 +174,35 @@ __global__ __launch_bounds__(256) void k_emit(SelArgs a) {
     int old = atomicMax(&a.cell0[grow], me);
     int loser = old > me ? me : old;
     if (loser > 0) { const int p = atomicAdd(&a.ties0[0], 1); if (p < kTieCap) a.ties0[1 + p] = loser - 1; }
-    old = atomicMax(&a.cell1[(long)b * a.Sp + j], me);
+    old = atomicMax(&a.cell1[(long)b * a.Sp + jj], me);
     loser = old > me ? me : old;
     if (loser > 0) { const int p = atomicAdd(&a.ties1[0], 1); if (p < kTieCap) a.ties1[1 + p] = loser - 1; }
   }
-  a.mconf[o] = a.keep_conf[grow * a.slots + slot];
+  a.mconf[o] = s_kc[q * a.slots + slot];
   // coarse_matching_new.py:126-134: (x, y) = (id % w, id // w) * scale [* scale{0,1}[b]]
   float s0x = a.scale_px, s0y = a.scale_px, s1x = a.scale_px, s1y = a.scale_px;
   if (a.scale0) { s0x = a.scale_px * a.scale0[b * 2]; s0y = a.scale_px * a.scale0[b * 2 + 1]; }
   if (a.scale1) { s1x = a.scale_px * a.scale1[b * 2]; s1y = a.scale_px * a.scale1[b * 2 + 1]; }
   a.k0[o * 2] = (float)(i % a.w0c) * s0x; a.k0[o * 2 + 1] = (float)(i / a.w0c) * s0y;
-  a.k1[o * 2] = (float)(j % a.w1c) * s1x; a.k1[o * 2 + 1] = (float)(j / a.w1c) * s1y;
+  a.k1[o * 2] = (float)(jj % a.w1c) * s1x; a.k1[o * 2 + 1] = (float)(jj / a.w1c) * s1y;
 }
 
-hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, const float* feat1, int h0c, int w0c,
+hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
                          int h1c, int w1c, float inv_ct, float thr, int border, float scale_px,
                          const float* scale0, const float* scale1, int64_t* b_ids, int64_t* i_ids,
                          int64_t* j_ids, float* k0, float* k1, float* mconf, int cap, int32_t* d_count,
                          int exact_screening, hipStream_t st) {
   SelArgs a;
   a.exact = exact_screening;
-  a.feat0 = feat0; a.feat1 = feat1;
   a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
+  a.rowS = (const float*)(base + w.rowS); a.colS = (const float*)(base + w.colS);
   a.rowB = (const float*)(base + w.rowB); a.colB = (const float*)(base + w.colB);
   a.cand_count = (const int*)(base + w.cand_count); a.cand_j = (const int*)(base + w.cand_j);
   a.cand_conf = (float*)(base + w.cand_conf); a.rowbest = (float*)(base + w.rowbest);
   a.colbest = (unsigned*)(base + w.colbest);
-  a.keep_j = (int*)(base + w.keep_j); a.keep_conf = (float*)(base + w.keep_conf);
-  a.rowcnt = (int*)(base + w.rowcnt); a.blocktot = (int*)(base + w.blocktot);
+  a.blocktot = (int*)(base + w.blocktot);
   a.scal = (Scalars*)(base + w.scalars);
-  a.N = w.N; a.L = w.L; a.S = w.S; a.C = w.C; a.Lp = w.Lp; a.Sp = w.Sp; a.splits = w.splits; a.panels = w.panels;
+  a.N = w.N; a.L = w.L; a.S = w.S; a.C = w.C; a.Lp = w.Lp; a.Sp = w.Sp; a.splits = w.splits; a.splits_s = w.splits_s; a.panels = w.panels;
   a.slots = w.slots; a.h0c = h0c; a.w0c = w0c; a.h1c = h1c; a.w1c = w1c; a.border = border;
   a.k = inv_ct * kLog2e; a.thr = thr; a.scale_px = scale_px; a.scale0 = scale0; a.scale1 = scale1;
   a.b_ids = b_ids; a.i_ids = i_ids; a.j_ids = j_ids; a.k0 = k0; a.k1 = k1; a.mconf = mconf;
@@ -213,8 +211,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, cons
   a.ties0 = (int*)(base + w.ties0); a.ties1 = (int*)(base + w.ties1);
   const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
   hipLaunchKernelGGL(k_cand_conf, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_cand_keep, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_keep_emit, dim3(blocks), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

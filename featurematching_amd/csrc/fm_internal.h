@@ -13,7 +13,9 @@ constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup o
 constexpr int kColParts = 1;         // column partials per 256-row panel (the 8 waves' partials are folded in LDS)
 constexpr int kTieCap = 1023;        // listed tie losers per image; beyond it the gathers scan the match list
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
+constexpr int kUnitsPerSplit = 16; // 32-column units one workgroup of the sparse sum kernel covers at most
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kSkipLog2 = 32.f;    // terms more than 2^32 below every stabiliser are negligible (see coarse_sum_sparse.hip)
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
 constexpr unsigned FM_INT_SCREEN_OVERFLOW = 8u;
 
@@ -27,23 +29,30 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 struct CoarseWs {
   int N, L, S, C, Lp, Sp, panels, tiles, splits, slots;
   int splits0;                                // column splits of the max pass (its own grid size)
+  int splits_s, units_s;                      // sparse sum kernel: column splits and 32-column units per split
   // zeroed on every call (contiguous, starts at the base)
-  size_t zero_begin, cand_count, colbest, blocktot, scalars, zero_end;
+  size_t zero_begin, cand_count, colbest, scalars, zero_end;
   size_t cell0, cell1;                        // (zeroed) match index + 1 of every image-0 / image-1 cell
   size_t ties0, ties1;                        // (zeroed) [0] = count, [1..kTieCap] = matches that lost their cell to an
                                               // exactly tied match (the cell-ordered gathers pick them up)
+  size_t rowmax_u, colmax_u;                  // (zeroed) order-preserving uint code of the row / column maxima of the
+                                              // f16 product (max pass: atomicMax, exact and order independent)
+  size_t blocktot;                            // (zeroed) k_keep_emit: matches per workgroup | published flag
   // float16 planes
   size_t hi0, lo0, hi1, lo1;
   // per-row / per-column statistics
-  size_t norm0, norm1, bmax0, bmax1;          // row norms, per-prep-block max norms
-  size_t rowA, colA, rowB, colB;              // partial max (pass A) / sum-exp (pass B): rows [N][splits][Lp],
+  size_t norm0, norm1, bmax0, bmax1;          // descriptor norms, largest norm per 32-row prep block
+  size_t emarg;                               // [N] log2-domain bound of k * |f16 product - exact product|
+  size_t rowS, colS;                          // partial sum-exp of the sparse sum kernel: rows [N][splits_s][Lp],
+                                              // columns [N][panels][Sp]
+  size_t rowB, colB;                          // partial sum-exp of the dense sum kernel: rows [N][splits][Lp],
                                               // columns [N][panels][Sp] (one partial per workgroup)
   size_t nmr, nmc;                            // -stabiliser*log2e per row / column
   size_t rsum, csum;                          // softmax denominators per row / column
   size_t nmr2, nmc2;                          // nmr - log2(rsum), nmc - log2(csum): log-softmax offsets
-  size_t umax, emarg;                         // unit maxima [N][Lp/32][Sp/32] of pass A; f16 error margin [N]
+  size_t umax;                                // unit maxima [N][Lp/32][Sp/32] of the max pass
+  size_t dense_map;                           // [N][Lp/32][Sp/32] float 0/1: unit left to the dense sum kernel
   size_t cand_j, cand_conf, rowbest;          // candidate columns, exact conf, best conf per row
-  size_t keep_j, keep_conf, rowcnt;           // selected matches per row (sorted by j)
   size_t total;
 };
 
@@ -53,7 +62,8 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots);
 
 struct Scalars {          // lives at ws.scalars (zeroed per call)
   unsigned flags;         // FM_DEV_* bits
-  int total_matches;
+  int dense_units;        // 32x32 units the sparse sum kernel left to the dense one (0: that kernel exits at once)
+  int ticket;             // k_keep_emit: next logical workgroup index
 };
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
@@ -62,12 +72,12 @@ hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const C
 hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st,
                        float* conf = nullptr);
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);
-hipError_t launch_select(const CoarseWs& w, char* base, const float* feat0, const float* feat1,
-                         int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,
+hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,
                          float scale_px, const float* scale0, const float* scale1,
                          int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* k0, float* k1,
                          float* mconf, int cap, int32_t* d_count, int exact_screening, hipStream_t st);
-hipError_t launch_conf_dense(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
+hipError_t launch_sum_sparse(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
+                             float inv_ct, float thr, hipStream_t st);
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, device) instead of on every launch: the
 // attribute call costs tens of host microseconds, which an eager (non-graph) caller would pay per step.

@@ -90,15 +90,20 @@ int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S,
                     float* mkpts0_c, float* mkpts1_c, float* mconf,
                     int cap, int32_t* d_count, float* conf_matrix, void* stream);
 
-/* Diagnostic only: workspace layout of fm_coarse_match (10 ints, then 27 byte offsets;
- * order documented in csrc/api.hip) so tests can inspect intermediate statistics. */
+/* Diagnostic only: workspace layout of fm_coarse_match (40 values: 10 ints, byte offsets, the sparse
+ * sum kernel's split geometry, total; order documented in csrc/api.hip) so tests can inspect
+ * intermediate statistics. */
 int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out);
 
-/* Diagnostic only: launch one correlation sweep (mode 0 = max pass, 1 = sum pass) on a workspace
- * filled by a previous fm_coarse_match of the same shapes / zero the per-call counters; used by
- * bench.py to bracket the dominant kernel with events on its own stream. */
+/* Diagnostic only: launch one kernel of the coarse stage (fm_debug_launch_corr: mode 0 = max pass,
+ * 1 = dense sum kernel, 2 = exact screening sweep; fm_debug_launch_sum_sparse: the sparse sum kernel) on a
+ * workspace filled by a previous fm_coarse_match of the same shapes and inputs / zero the candidate counters
+ * and scalars so that the sum kernels can run again; used by bench.py to bracket the dominant kernels with
+ * events on their own stream. */
 int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_slots,
                          float temperature, float thr, int mode, void* stream);
+int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
+                               int C, int cand_slots, float temperature, float thr, void* stream);
 int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream);
 
 /* Copy {M, status} to the host and wait for the stream (the one host sync of the

@@ -81,14 +81,15 @@ def test_workspace_query_and_argument_checks():
 
 def test_layout_query_is_consistent():
     lib = _lib.load()
-    arr = (C.c_int64 * 37)()
-    assert lib.fm_debug_coarse_layout(1, 4800, 4800, 256, 8, arr, 37) == 0
+    arr = (C.c_int64 * 40)()
+    assert lib.fm_debug_coarse_layout(1, 4800, 4800, 256, 8, arr, 40) == 0
     v = list(arr)
     assert v[:4] == [1, 4800, 4800, 256]
     assert v[4] == 4864 and v[5] == 4800 and v[6] == 19 and v[7] == 75      # Lp, Sp, panels, tiles
     assert 1 <= v[8] <= 32 and v[6] * v[8] <= 256                            # one round of the 256 CUs
-    offs = v[10:]
+    offs = v[10:37] + v[39:]
     assert all(o % 256 == 0 for o in offs)
+    assert v[37] * v[38] >= 150 and v[38] <= 16      # sparse sum kernel: splits x units per split cover Sp/32
     n = C.c_size_t(0)
     lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n))
     assert offs[-1] == n.value

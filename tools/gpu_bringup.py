@@ -20,14 +20,14 @@ from featurematching_amd import _lib, ops, synth  # noqa: E402
 from oracle import matcher_ref as orc  # noqa: E402  (checker only)
 
 NAMES = ["cand_count", "colbest", "scalars", "blocktot", "hi0", "lo0", "hi1", "lo1", "norm0", "norm1", "bmax0",
-         "bmax1", "rowA", "colA", "rowB", "colB", "nmr", "nmc", "rsum", "csum", "cand_j", "cand_conf", "rowbest",
-         "keep_j", "keep_conf", "rowcnt", "total"]
+         "bmax1", "rowS", "colS", "rowB", "colB", "nmr", "nmc", "rsum", "csum", "cand_j", "cand_conf", "rowbest",
+         "umax", "dense_map", "rowmax_u", "colmax_u", "splits_s", "units_s", "total"]
 
 
 def layout(n, l, s, c, slots):
     lib = _lib.load()
-    arr = (C.c_int64 * 37)()
-    _lib.check(lib.fm_debug_coarse_layout(n, l, s, c, slots, arr, 37), "layout")
+    arr = (C.c_int64 * 40)()
+    _lib.check(lib.fm_debug_coarse_layout(n, l, s, c, slots, arr, 40), "layout")
     v = list(arr)
     d = dict(zip(["N", "L", "S", "C", "Lp", "Sp", "panels", "tiles", "splits", "slots"], v[:10]))
     d.update(dict(zip(NAMES, v[10:])))
@@ -81,14 +81,26 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     print("   norms ok:", ok_n)
     ok &= ok_n
 
-    rowA = view(ws, base, lay["rowA"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).max(1)
-    colA = view(ws, base, lay["colA"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).max(1)
+    def ord_decode(u):                  # fm_device.h: order-preserving uint code -> float (0 = nothing recorded)
+        u = u.astype(np.uint32)
+        bits = np.where(u & np.uint32(0x80000000), u & np.uint32(0x7fffffff), ~u)
+        return np.where(u == 0, np.float32(0), bits.view(np.float32))
+
+    rowA = ord_decode(view(ws, base, lay["rowmax_u"], n * Lp, torch.int32)).reshape(n, Lp)
+    colA = ord_decode(view(ws, base, lay["colmax_u"], n * Sp, torch.int32)).reshape(n, Sp)
     nmr = view(ws, base, lay["nmr"], n * Lp, torch.float32).reshape(n, Lp)
     nmc = view(ws, base, lay["nmc"], n * Sp, torch.float32).reshape(n, Sp)
     # softmax denominators = the sum pass's partials folded (k_cand_conf does the same for its candidates;
     # the rsum / csum arrays are only written on the exact-screening / conf_matrix paths)
-    rsum = view(ws, base, lay["rowB"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).sum(1)
-    csum = view(ws, base, lay["colB"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
+    splits_s = lay["splits_s"]
+    rsum = view(ws, base, lay["rowS"], n * splits_s * Lp, torch.float32).reshape(n, splits_s, Lp).sum(1)
+    csum = view(ws, base, lay["colS"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
+    scal = view(ws, base, lay["scalars"], 3, torch.int32)
+    dmap = view(ws, base, lay["dense_map"], n * (Lp // 32) * (Sp // 32), torch.float32)
+    print(f"   scalars: flags={scal[0]} dense_units={scal[1]} (dense_map sum {int(dmap.sum())}); sparse splits {splits_s} x {lay['units_s']} units")
+    if scal[1] > 0:                     # the dense sum kernel had units of its own
+        rsum = rsum + view(ws, base, lay["rowB"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).sum(1)
+        csum = csum + view(ws, base, lay["colB"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
     ccount = view(ws, base, lay["cand_count"], n * Lp, torch.int32).reshape(n, Lp)
     cand_j = view(ws, base, lay["cand_j"], n * Lp * slots, torch.int32).reshape(n, Lp, slots)
     log2e = 1.4426950408889634
