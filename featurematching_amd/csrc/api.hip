@@ -22,8 +22,9 @@ int choose_splits(int N, int panels, int tiles, int target) {
   return s;
 }
 
-// column splits of the sparse sum kernel: independent waves, so twice the chip's workgroup slots balance the
-// uneven number of live units per wave; a split covers at most kUnitsPerSplitMax 32-column units
+// column splits of the sparse sum kernel: one round of the chip's workgroup slots (its waves are bound by a chain of
+// memory round trips, which a second round would repeat); when the batch alone fills the chip a split covers up to
+// kUnitsPerSplit 32-column units, which amortises those round trips over more live units
 static int choose_splits_sparse(int N, int panels, int nunits, int* units_per_split) {
   constexpr int kUnitsPerSplitMax = kUnitsPerSplit;
   int target = 256;
@@ -61,6 +62,8 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   auto take = [&](size_t bytes) { size_t at = o; o = align256(o + bytes); return at; };
   w.zero_begin = o;
   w.cand_count = take(rows * 4);
+  w.cand_count_b = take(rows * 4);
+  w.dense_cnt = take((size_t)N * 4);
   w.colbest = take(cols * 4);
   w.cell0 = take(rows * 4);
   w.cell1 = take(cols * 4);
@@ -73,8 +76,11 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.zero_end = o;
   w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
-  w.norm0 = take(rows * 4); w.norm1 = take(cols * 4);
-  w.bmax0 = take(rows / 32 * 4); w.bmax1 = take(cols / 32 * 4);
+  w.q0 = take(rows * C); w.q1 = take(cols * C);
+  w.sig0 = take(rows * 4); w.sig1 = take(cols * 4);
+  w.bsig0 = take(rows / 32 * 4); w.bsig1 = take(cols / 32 * 4);
+  w.l1_0 = take(rows * 4); w.l1_1 = take(cols * 4);
+  w.bl1_0 = take(rows / 32 * 4); w.bl1_1 = take(cols / 32 * 4);
   w.emarg = take((size_t)N * 4);
   w.rowS = take(rows * w.splits_s * 4); w.colS = take(cols * w.panels * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * kColParts * 4);
@@ -82,8 +88,8 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.rsum = take(rows * 4); w.csum = take(cols * 4);
   w.nmr2 = take(rows * 4); w.nmc2 = take(cols * 4);
   w.umax = take(rows / 32 * (cols / N / 32) * 4);
-  w.dense_map = take(rows / 32 * (cols / N / 32) * 4);
   w.cand_j = take(rows * slots * 4); w.cand_conf = take(rows * slots * 4); w.rowbest = take(rows * 4);
+  w.cand_j_b = take(rows * slots * 4); w.cand_conf_b = take(rows * slots * 4);
   w.total = o;
   return w;
 }
@@ -135,8 +141,8 @@ static int check_coarse_shape(int N, int L, int S, int C, int cand_slots) {
 
 // Diagnostic: the workspace layout (ints then byte offsets), so that tests can inspect the
 // intermediate statistics of a run.  out[0..9] = N,L,S,C,Lp,Sp,panels,tiles,splits,slots;
-// out[10..] = cand_count, colbest, scalars, blocktot, hi0, lo0, hi1, lo1, norm0, norm1, bmax0, bmax1,
-// rowS, colS, rowB, colB, nmr, nmc, rsum, csum, cand_j, cand_conf, rowbest, umax, dense_map, rowmax_u,
+// out[10..] = cand_count, colbest, scalars, blocktot, hi0, lo0, hi1, lo1, q0, q1, sig0, sig1,
+// rowS, colS, rowB, colB, nmr, nmc, rsum, csum, cand_j, cand_conf, rowbest, umax, dense_cnt, rowmax_u,
 // colmax_u, splits_s, units_s, total  (40 values).
 extern "C" int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out) {
   if (!out) return FM_E_NULL;
@@ -146,11 +152,11 @@ extern "C" int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   const int64_t v[40] = {w.N, w.L, w.S, w.C, w.Lp, w.Sp, w.panels, w.tiles, w.splits, w.slots,
                          (int64_t)w.cand_count, (int64_t)w.colbest, (int64_t)w.scalars, (int64_t)w.blocktot,
-                         (int64_t)w.hi0, (int64_t)w.lo0, (int64_t)w.hi1, (int64_t)w.lo1, (int64_t)w.norm0,
-                         (int64_t)w.norm1, (int64_t)w.bmax0, (int64_t)w.bmax1, (int64_t)w.rowS, (int64_t)w.colS,
+                         (int64_t)w.hi0, (int64_t)w.lo0, (int64_t)w.hi1, (int64_t)w.lo1, (int64_t)w.q0,
+                         (int64_t)w.q1, (int64_t)w.sig0, (int64_t)w.sig1, (int64_t)w.rowS, (int64_t)w.colS,
                          (int64_t)w.rowB, (int64_t)w.colB, (int64_t)w.nmr, (int64_t)w.nmc, (int64_t)w.rsum,
                          (int64_t)w.csum, (int64_t)w.cand_j, (int64_t)w.cand_conf, (int64_t)w.rowbest,
-                         (int64_t)w.umax, (int64_t)w.dense_map, (int64_t)w.rowmax_u, (int64_t)w.colmax_u,
+                         (int64_t)w.umax, (int64_t)w.dense_cnt, (int64_t)w.rowmax_u, (int64_t)w.colmax_u,
                          w.splits_s, w.units_s, (int64_t)w.total};
   for (int i = 0; i < 40; ++i) out[i] = v[i];
   return FM_OK;
@@ -176,14 +182,15 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   // one dispatch: clear the per-call counters, split both images into float16 planes
   hipError_t e = launch_prep(feat0, feat1, C, w, base, st);
   if (e != hipSuccess) return (int)e;
-  // max pass: row / column / unit maxima of the hi x hi product (atomicMax: no partials, no reduction kernel)
-  e = launch_corr(0, w, base, inv_ct, thr, st);
+  // max pass: row / column / unit maxima of the int8 screening product (atomicMax: no partials, no reduction kernel)
+  e = launch_max_i8(w, base, st);
   if (e != hipSuccess) return (int)e;
   // sparse sum kernel: stabilisers, live units, exact terms of the few significant entries, candidates;
   // flags the units with too many significant entries (flat similarity) for the dense kernel
   e = launch_sum_sparse(feat0, feat1, C, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
-  // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): exits at once when nothing is flagged
+  // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
+  // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
   e = launch_corr(1, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
   // The common path goes straight to the assignment (k_cand_conf folds the softmax denominators of its
@@ -231,6 +238,7 @@ extern "C" int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C,
   if (mode < 0 || mode > 2) return FM_E_UNSUPPORTED;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) return (int)launch_max_i8(w, (char*)workspace, st);
   return (int)launch_corr(mode, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st);
 }
 
@@ -252,7 +260,7 @@ extern "C" int fm_debug_reset_counters(void* workspace, int N, int L, int S, int
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  hipError_t e = hipMemsetAsync((char*)workspace + w.cand_count, 0, (size_t)w.N * w.Lp * 4, (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync((char*)workspace + w.cand_count, 0, w.colbest - w.cand_count, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   return (int)hipMemsetAsync((char*)workspace + w.scalars, 0, sizeof(Scalars), (hipStream_t)stream);
 }

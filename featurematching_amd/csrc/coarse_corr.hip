@@ -69,10 +69,11 @@ struct CorrArgs {
   float* rowpart; float* colpart;
   unsigned* rowmax_u; unsigned* colmax_u;   // MODE 0: row / column maxima of the f16 product (ord_encode, atomicMax)
   float* umax;            // [N][Lp/32][Sp/32] unit maxima of the raw f16 product (written by MODE 0)
-  const float* dense_map; // MODE 1: [N][Lp/32][Sp/32] 1.0 = unit left to this kernel by the sparse sum kernel
-  const int* dense_units; // MODE 1: number of such units (0: nothing to do)
+  const int* dense_cnt;   // [N] units per sample the sparse sum kernel left to the dense one (> 0: MODE 1 redoes the sample)
+  const int* dense_units; // their total (0: MODE 1 has nothing to do)
   const float* emarg;     // [N] log2-domain bound of |f16 product - exact product| * k
   int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
+  int* cand_count_b; int* cand_j_b; float* cand_x_b;   // the dense kernel's candidate set (samples it redid)
   float* conf;            // MODE 3: dense [N,L,S] output
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, slots;
   int pgroup;             // panels per XCD-locality group of the workgroup order
@@ -199,22 +200,12 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const int t0 = split * a.tiles_per_split;
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
-  if (MODE == 1) {
-    // Does the sparse sum kernel leave anything to this workgroup's block (8 row blocks x 2 units per tile)?
-    // Usually not: then its partial sums are zero and nothing is loaded.
-    const int nu = 2 * (t1 - t0);
-    bool any = false;
-    for (int idx = tid; idx < 8 * nu; idx += 512) {
-      const int rb = idx / nu, u = idx - rb * nu;
-      any = any || a.dense_map[((long)b * (a.Lp / 32) + panel * 8 + rb) * (a.Sp / 32) + 2 * t0 + u] != 0.f;
-    }
-    if (!__syncthreads_or((int)any)) {
-      if (tid < kPanelRows) a.rowpart[((long)b * a.splits + split) * a.Lp + panel * kPanelRows + tid] = 0.f;
-      float* co = a.colpart + ((long)b * a.panels + panel) * a.Sp;
-      for (int c = t0 * kTileCols + tid; c < t1 * kTileCols; c += 512) co[c] = 0.f;
-      return;
-    }
-  }
+  if (MODE == 1 && a.dense_cnt[b] == 0) return;      // uniform: this sample was handled by the sparse sum kernel
+  // candidate set of this sample: the dense kernel's own for the samples it redoes
+  const bool dense_sample = MODE == 1 || (MODE == 2 && a.dense_cnt[b] != 0);
+  int* const cand_count = dense_sample ? a.cand_count_b : a.cand_count;
+  int* const cand_j = dense_sample ? a.cand_j_b : a.cand_j;
+  float* const cand_x = dense_sample ? a.cand_x_b : a.cand_x;
   const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};   // fragment-major
   // Small per-workgroup tables live in their OWN static LDS objects, not in the dynamic tile ring: hipcc
   // orders every LDS access it can see against outstanding LDS-DMA writes it cannot tell apart from it -
@@ -258,7 +249,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     // wave 0 brings the 64 column stabilisers, wave 1 the 16 unit maxima of (wave, unit) = (lane/2, lane%2).
     if (MODE && wv == 0) glds4(a.nmc + (long)b * a.Sp + t * kTileCols + lane, meta + (buf & 1) * META);
     if (SPARSE && wv == 1 && lane < 16)
-      glds4((MODE == 1 ? a.dense_map : a.umax) + ((long)b * (a.Lp / 32) + panel * 8 + (lane >> 1)) * (a.Sp / 32) + 2 * t + (lane & 1),
+      glds4(a.umax + ((long)b * (a.Lp / 32) + panel * 8 + (lane >> 1)) * (a.Sp / 32) + 2 * t + (lane & 1),
             meta + (buf & 1) * META + 64);
   };
 #pragma unroll
@@ -291,7 +282,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     const float nv = lane < 32 ? a.nmr[(long)b * a.Lp + wrow0 + lane] : -INFINITY;
     if (lane < 32) nmr_lds[lane] = nv;
     // padded rows (>= L) never contribute: keep them out of the wave's largest stabiliser
-    if (MODE == 2) { wmax_nmr = wave_max64(wrow0 + lane < a.L ? nv : -INFINITY); emarg = a.emarg[b]; }
+    if (SPARSE) { wmax_nmr = wave_max64(wrow0 + lane < a.L ? nv : -INFINITY); emarg = a.emarg[b]; }
   }
   const bool row_edge = (wrow0 + 32 > a.L);     // wave-uniform: some of this wave's rows are padding
 
@@ -369,8 +360,8 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   };
 
   auto record_candidate = [&](long grow, int col, float x) {
-    const int pos = atomicAdd(&a.cand_count[grow], 1);
-    if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = col; a.cand_x[grow * a.slots + pos] = x; }
+    const int pos = atomicAdd(&cand_count[grow], 1);
+    if (pos < a.slots) { cand_j[grow * a.slots + pos] = col; cand_x[grow * a.slots + pos] = x; }
     else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
   };
 
@@ -532,9 +523,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nmc_u), "+v"(um));
     }
     bool skip = false;
-    if (MODE == 1) {        // only the units the sparse sum kernel flagged (um = 1.0 / 0.0)
-      skip = __builtin_amdgcn_readfirstlane((int)(um == 0.f));
-    } else if (MODE == 2) {
+    if (SPARSE) {
       const float top = __builtin_fmaf(um, a.k, emarg);             // >= k * (exact product), log2 domain
       const float cmax = wave_max64(t * kTileCols + (u & 1) * 32 + r < a.S ? nmc_u : -INFINITY);
       skip = __builtin_amdgcn_readfirstlane((int)((top + wmax_nmr < -kSkipLog2) && (top + cmax < -kSkipLog2)));
@@ -597,12 +586,12 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       q_key = qkey[lane];
       q_x = qx[lane];
       q_row = (long)b * a.Lp + wrow0 + (q_key & 31);
-      q_pos = atomicAdd(&a.cand_count[q_row], 1);
+      q_pos = atomicAdd(&cand_count[q_row], 1);
     }
   }
   auto commit_candidates = [&]() {
     if (SPARSE && q_pos >= 0) {
-      if (q_pos < a.slots) { a.cand_j[q_row * a.slots + q_pos] = q_key >> 5; a.cand_x[q_row * a.slots + q_pos] = q_x; }
+      if (q_pos < a.slots) { cand_j[q_row * a.slots + q_pos] = q_key >> 5; cand_x[q_row * a.slots + q_pos] = q_x; }
       else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
     }
   };
@@ -661,7 +650,9 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.rowpart = (float*)(base + w.rowB);
   a.colpart = (float*)(base + w.colB);
   a.rowmax_u = (unsigned*)(base + w.rowmax_u); a.colmax_u = (unsigned*)(base + w.colmax_u);
-  a.dense_map = (const float*)(base + w.dense_map);
+  a.dense_cnt = (const int*)(base + w.dense_cnt);
+  a.cand_count_b = (int*)(base + w.cand_count_b); a.cand_j_b = (int*)(base + w.cand_j_b);
+  a.cand_x_b = (float*)(base + w.cand_conf_b);
   a.dense_units = &((const Scalars*)(base + w.scalars))->dense_units;
   a.umax = (float*)(base + w.umax); a.emarg = (const float*)(base + w.emarg);
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
@@ -687,7 +678,7 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
 #define FM_CORR_CASE(CC)                                                     \
   case CC: return mode == 3 ? launch_corr_t<CC, 3>(a, blocks, st)            \
                  : mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)          \
-                 : (mode ? launch_corr_t<CC, 1>(a, blocks, st) : launch_corr_t<CC, 0>(a, blocks, st));
+                 : (mode ? launch_corr_t<CC, 1>(a, blocks, st) : hipErrorInvalidValue);
   switch (w.C) {
     FM_CORR_CASE(64)
     FM_CORR_CASE(128)

@@ -1,0 +1,283 @@
+// Coarse stage, the max pass on the int8 screening planes.
+//
+// First sweep of network/utils/coarse_matching_new.py:64-68 (all-pairs correlation): it only has to tell the
+// sum kernels WHERE the mass of the dual softmax is - per-row and per-column maxima (stabilisers) and the
+// maximum of every 32 x 32 unit (which units are alive) - so it runs on the int8 planes of k_prep_split:
+// v_mfma_i32_32x32x32_i8 does twice the k per instruction of the f16 form, the planes have half the bytes
+// (prologue, LDS-DMA, LDS reads all halve), and the quantisation error is bounded rigorously (fm_device.h).
+//   screening product  x~_ij = sigma_i * sigma_j * (q_i . q_j)   (exact integer dot, one step per descriptor)
+// Maxima are published with an order-preserving atomicMax (exact, order independent): no partial arrays and no
+// reduction kernel.
+//
+// Structure (as the dense sum kernel k_corr): one workgroup = 8 waves = a 256-row panel of image 0 x a range of
+// 64-column tiles of image 1; each wave keeps its 32 rows as A fragments in 32 VGPRs for the whole sweep; image-1
+// tiles (16 KiB at C = 256) stream through a 4-deep LDS ring by LDS-DMA (global_load_lds_dwordx4, 1 KiB fragment
+// block per instruction), handed over by counted vmcnt + raw s_barrier; B fragments are read ahead through
+// inline-asm ds_read_b128 + counted lgkmcnt.  The LDS footprint (64 KiB) and ~100 VGPRs leave room for two
+// workgroups per CU.
+#include "fm_device.h"
+
+namespace fm {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct MaxArgs {
+  const signed char* q0; const signed char* q1;
+  const float* sig0; const float* sig1;
+  unsigned* rowmax_u; unsigned* colmax_u; float* umax;
+  int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, pgroup;
+};
+
+__device__ __forceinline__ int xcd_remap_m(int bid, int n) {
+  const int q = n >> 3, rem = n & 7, x = bid & 7, y = bid >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + y;
+}
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_mov_m(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                               CTRL, 0xf, BANK, false));
+}
+// max over the 32 lanes that share lane>>5, result in every lane of the half; DPP only
+__device__ __forceinline__ float half_max32(float v) {
+  v = fmaxf(v, dpp_mov_m<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov_m<0x4E, 0xf>(v, v));
+  { float t = dpp_mov_m<0x104, 0x5>(v, v); t = dpp_mov_m<0x114, 0xA>(t, v); v = fmaxf(v, t); }
+  v = fmaxf(v, dpp_mov_m<0x128, 0xf>(v, v));
+  { float p = v, q = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q)); v = fmaxf(p, q); }
+  return v;
+}
+__device__ __forceinline__ float halves_max(float v) {
+  float p = v, q = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  return fmaxf(p, q);
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
+  constexpr int KS8 = C / 32;                       // k-steps of 32 channels
+  constexpr int TILE_BYTES = kTileCols * C;         // 64 columns x C bytes
+  constexpr int NBUF = 4;
+  constexpr int PIECES = 2 * KS8;                   // 1 KiB fragment blocks per tile: [column block 0/1][k-step]
+  constexpr int PER_WAVE = PIECES >= 8 ? PIECES / 8 : 1;   // (C = 64: the 8 waves bring the 4 blocks twice - harmless)
+  constexpr int PF = KS8 < 4 ? KS8 : 4;             // B-fragment read-ahead
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float s_colred[2 * 8 * 64];            // per tile parity: the 8 waves' column maxima of 64 columns
+  __shared__ float s_meta[NBUF * 64];               // per ring slot: the quantisation steps of the tile's 64 columns
+  __shared__ __attribute__((aligned(16))) float s_sigA[8][32];   // ... of the 8 waves' rows
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  // workgroup order: sample, groups of a.pgroup panels, split-major inside a group, through the bijective XCD
+  // remap - one XCD's share is a compact (panels x splits) block (speed only)
+  int kk = xcd_remap_m(blockIdx.x, gridDim.x);
+  const int per_sample = a.panels * a.splits;
+  const int b = kk / per_sample;
+  kk -= b * per_sample;
+  const int gsz = a.pgroup * a.splits;
+  const int pg = kk / gsz;
+  kk -= pg * gsz;
+  const int pcount = min(a.pgroup, a.panels - pg * a.pgroup);
+  const int split = kk / pcount;
+  const int panel = pg * a.pgroup + (kk - split * pcount);
+  const int t0 = split * a.tiles_per_split;
+  const int t1 = min(t0 + a.tiles_per_split, a.tiles);
+  const int nunits = a.Sp / 32;
+
+  // the steps of this wave's 32 rows: through LDS into the accumulator's row order (rows 8q + 4h + 0..3 in
+  // registers 4q..4q+3), BEFORE the first LDS-DMA is issued (afterwards hipcc would drain the ring in front of
+  // every LDS access it can see)
+  const int wrow0 = panel * kPanelRows + wv * 32;
+  if (lane < 32) s_sigA[wv][lane] = a.sig0[(long)b * a.Lp + wrow0 + lane];
+  __builtin_amdgcn_wave_barrier();
+  float sgA[16];
+  {
+    const int h_ = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(&s_sigA[wv][8 * q + 4 * h_]);
+      sgA[4 * q] = v.x; sgA[4 * q + 1] = v.y; sgA[4 * q + 2] = v.z; sgA[4 * q + 3] = v.w;
+    }
+  }
+  const signed char* plane1 = a.q1 + (long)b * a.Sp * C;
+  auto stage = [&](int t, int buf) {
+#pragma unroll
+    for (int n = 0; n < PER_WAVE; ++n) {
+      const int blk = (wv * PER_WAVE + n) % PIECES;                 // (cb, ks)
+      const signed char* src = plane1 + ((long)(2 * t) * KS8 + blk) * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + buf * TILE_BYTES + blk * 1024),
+                                       16, 0, 0);
+    }
+    // the tile's 64 column steps travel the same way (4-byte LDS-DMA: no register carries a global load across
+    // the sweep - hipcc would order every such load against the tile prefetch with vmcnt(0))
+    if (wv == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.sig1 + (long)b * a.Sp + t * kTileCols + lane),
+                                       (__attribute__((address_space(3))) void*)(s_meta + buf * 64), 4, 0, 0);
+  };
+#pragma unroll
+  for (int d = 0; d < NBUF - 1; ++d)
+    if (t0 + d < t1) stage(t0 + d, d);
+
+  // this wave's 32 rows as A fragments: one contiguous 1 KiB block per k-step of the fragment-major plane
+  v4i aq[KS8];
+  {
+    const signed char* src = a.q0 + (((long)b * a.Lp + wrow0) / 32 * KS8 * 64 + lane) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
+  }
+  const bool row_edge = (wrow0 + 32 > a.L);
+
+  float rstat[16];               // running maxima of (q_i . q_j) * sigma_j over the columns seen so far
+#pragma unroll
+  for (int g = 0; g < 16; ++g) rstat[g] = -INFINITY;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned colred_a = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_colred;
+  const unsigned meta_a = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_meta;
+  v16i acc;
+  auto mfma_unit = [&](int u) {
+    const unsigned base = lds0 + (((u >> 1) - t0) % NBUF) * TILE_BYTES + (u & 1) * (KS8 * 1024) + lane * 16;
+    constexpr int RING = PF + 1;
+    v4i bq[RING];
+    auto issue = [&](int ks) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(bq[ks % RING]) : "v"(base + (unsigned)(ks * 1024)));
+    };
+#pragma unroll
+    for (int ks = 0; ks < PF && ks < KS8; ++ks) issue(ks);
+#pragma unroll
+    for (int ks = 0; ks < KS8; ++ks) {
+      if (ks + PF < KS8) issue(ks + PF);
+      const int ahead = (KS8 - 1 - ks) < PF ? (KS8 - 1 - ks) : PF;     // k-steps issued beyond ks
+      if (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[ks % RING]));
+      else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[ks % RING]));
+      else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bq[ks % RING]));
+      else if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bq[ks % RING]));
+      else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[ks % RING]));
+      static_assert(PF <= 4, "lgkmcnt ladder above covers at most 4 reads in flight");
+      if (ks == 0) {
+        v16i z;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) z[g] = 0;
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks % RING], z, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks % RING], acc, 0, 0, 0);
+      }
+    }
+  };
+
+  auto tile_barrier = [&](int tiles_after) {
+    if (tiles_after <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (tiles_after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * PER_WAVE) : "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  tile_barrier(min(NBUF - 2, t1 - t0 - 1));     // first tile landed
+  // name the registers loaded before the loop: hipcc then waits for them here and not (with vmcnt(0), i.e. also
+  // for the tile prefetch) at their first use inside the loop
+#pragma unroll
+  for (int ks = 0; ks < KS8; ++ks) asm volatile("" ::"v"(aq[ks]));
+#pragma unroll
+  for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(sgA[g]));
+
+  for (int u = 2 * t0; u < 2 * t1; ++u) {
+    const int t = u >> 1, par = (t - t0) & 1;
+    if ((u & 1) == 0 && t + NBUF - 1 < t1) stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF);   // refill the slot of tile t-1
+    float sB;                  // this lane's column step (inline asm: see k_corr on compiler-visible LDS accesses)
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sB) : "v"(meta_a + (((t - t0) % NBUF) * 64 + (u & 1) * 32 + r) * 4));
+    mfma_unit(u);
+    // ---- epilogue: rows in registers, columns on lanes ----
+    const int ucol0 = u * 32;
+    float cstat = -INFINITY;
+    const bool cpad = ucol0 + r >= a.S;       // padded columns (zero descriptors, step 0) never count
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float rv = (float)acc[g] * sB;
+      if (cpad) rv = -INFINITY;
+      float cv = rv * sgA[g];
+      // padded rows (>= L) hold zero descriptors: keep their zeros out of the column maxima
+      if (row_edge && wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) cv = -INFINITY;
+      rstat[g] = fmaxf(rstat[g], rv);
+      cstat = fmaxf(cstat, cv);
+    }
+    cstat = halves_max(cstat);
+    const float um = halves_max(half_max32(cstat));                  // unit maximum (both halves already merged)
+    if (lane == 0) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * nunits + u] = um;
+    if (h == 0) {
+      const unsigned ad = colred_a + (((par * 8 + wv) * 64 + (u & 1) * 32 + r) * 4);
+      asm volatile("ds_write_b32 %0, %1" ::"v"(ad), "v"(cstat) : "memory");
+    }
+    if (u & 1) {
+      // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
+      tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1));
+      if (wv == (t & 7)) {
+        // every wave's column maxima of tile t are in LDS (their writes precede the barrier): this wave folds them
+        float pv[8];
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8)
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(pv[w8]) : "v"(colred_a + (par * 8 * 64 + lane) * 4), "i"(w8 * 256));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
+                     "+v"(pv[6]), "+v"(pv[7]));
+        float cv = pv[0];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) cv = fmaxf(cv, pv[w8]);
+        if (t * kTileCols + lane < a.S && cv > -INFINITY)
+          __hip_atomic_fetch_max(a.colmax_u + (long)b * a.Sp + t * kTileCols + lane, ord_encode(cv), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+
+  // ---- row maxima of this workgroup's column range ----
+#pragma unroll
+  for (int g = 0; g < 16; ++g) rstat[g] = half_max32(rstat[g]) * sgA[g];
+  if (r == 0) {
+    unsigned* out = a.rowmax_u + (long)b * a.Lp + wrow0 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+      if (wrow0 + 4 * h + (g & 3) + 8 * (g >> 2) < a.L && rstat[g] > -INFINITY)
+        __hip_atomic_fetch_max(out + (g & 3) + 8 * (g >> 2), ord_encode(rstat[g]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st) {
+  MaxArgs a;
+  a.q0 = (const signed char*)(base + w.q0); a.q1 = (const signed char*)(base + w.q1);
+  a.sig0 = (const float*)(base + w.sig0); a.sig1 = (const float*)(base + w.sig1);
+  a.rowmax_u = (unsigned*)(base + w.rowmax_u); a.colmax_u = (unsigned*)(base + w.colmax_u);
+  a.umax = (float*)(base + w.umax);
+  a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
+  a.splits = w.splits0; a.tiles_per_split = (w.tiles + a.splits - 1) / a.splits;
+  {
+    // one XCD runs ~blocks/8 workgroups: make its block of (panels x splits) as square as the bytes are
+    const int blocks_all = w.N * a.splits * w.panels;
+    const float share = fmaxf(1.f, (float)blocks_all / 8.f);
+    int pgr = (int)lroundf(sqrtf(share * (float)(a.tiles_per_split * kTileCols) / (float)kPanelRows));
+    a.pgroup = pgr < 1 ? 1 : (pgr > w.panels ? w.panels : pgr);
+    if (a.splits == 1) a.pgroup = w.panels;
+  }
+  const int blocks = w.N * a.splits * w.panels;
+  hipError_t e = hipSuccess;
+#define FM_MAX_CASE(CC)                                                                        \
+  case CC: {                                                                                   \
+    static unsigned long long lds_set = 0;                                                     \
+    e = ensure_dynamic_lds(&k_max_i8<CC>, 4 * kTileCols * CC, &lds_set);                       \
+    if (e != hipSuccess) return e;                                                             \
+    hipLaunchKernelGGL(k_max_i8<CC>, dim3(blocks), dim3(512), 4 * kTileCols * CC, st, a);      \
+    break;                                                                                     \
+  }
+  switch (w.C) {
+    FM_MAX_CASE(64)
+    FM_MAX_CASE(128)
+    FM_MAX_CASE(256)
+    default: return hipErrorInvalidValue;
+  }
+#undef FM_MAX_CASE
+  return hipGetLastError();
+}
+
+}  // namespace fm

@@ -1,5 +1,6 @@
 // Coarse stage, kernels around the correlation sweeps:
-//   k_prep_split  : float32 descriptors -> two float16 planes (hi, lo = x - hi) + row norms
+//   k_prep_split  : float32 descriptors -> int8 screening plane + block scales + L1 norms, and two float16
+//                   planes (hi, lo = x - hi)
 //   k_reduce_sums : partial sums of the sum kernels -> softmax denominators of every row / column
 //                   (exact screening and dense conf_matrix only)
 //
@@ -7,8 +8,8 @@
 // (sim = (f0/sqrt(C)) . (f1/sqrt(C)) / T, softmax over dim 1 and dim 2).  The float16
 // pair (hi, lo) carries 22 mantissa bits, so hi*hi + hi*lo + lo*hi on the f16 matrix
 // cores reproduces the float32 product to ~2^-22 relative while running at the f16
-// MFMA rate; the single-plane product (hi*hi) is only used to bound the row/column
-// maxima, with the rigorous margin of fm_device.h.
+// MFMA rate (dense sum kernel).  Screening (row / column / unit maxima, which units and entries matter) runs on
+// the int8 plane at twice that rate and half the bytes, with the rigorous quantisation margin of fm_device.h.
 #include "fm_internal.h"
 
 namespace fm {
@@ -18,7 +19,11 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 struct PrepArgs {
   const float* src0; const float* src1;
   _Float16* hi0; _Float16* lo0; _Float16* hi1; _Float16* lo1;
-  float* norm0; float* norm1; float* bmax0; float* bmax1;
+  signed char* q0; signed char* q1;   // int8 screening planes (fragment-major for v_mfma_i32_32x32x32_i8)
+  float* sig0; float* sig1;           // quantisation step of every descriptor (row)
+  float* bsig0; float* bsig1;         // largest step per 32-row block
+  float* l1_0; float* l1_1;           // L1 norm of every descriptor
+  float* bl1_0; float* bl1_1;         // largest L1 norm per 32-row block (+inf: the block holds a bad value)
   uint4* zero; int zero_vec;          // per-call counters to clear (uint4 units)
   int L, S, Lp, Sp, c_in, blocks0;    // blocks0 = workgroups that convert image 0
 };
@@ -31,18 +36,25 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 // One dispatch prepares both images and clears the per-call counters.
 // C = padded channel count of the planes (64/128/256); c_in <= C = channels of the source rows,
 // the planes are zero beyond c_in (a dot product does not change under zero padding).
-//   Both images' planes are FRAGMENT-major, one workgroup per 32-row block: element (row, k) lives at
+//   All planes are FRAGMENT-major, one workgroup per 32-row block.
+//   float16 planes (hi, lo = x - hi; the dense sum kernel's float32-equivalent product): element (row, k) lives at
 //     (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8   with chunk q = k/8 = h*KSTEPS + ks,
-//   i.e. the 64 lanes (h, row%32) of an MFMA operand fragment are one contiguous 1 KiB block per
-//   (32-row block, k-step).  Image 0 (the register-resident A operand of the sweeps) is read that way
-//   straight into registers; image 1 blocks are copied 1 KiB at a time into LDS by LDS-DMA (lane-linear
-//   image: the ds_read_b128 of lane l at l*16 is bank-conflict free with no swizzle), or fetched directly
-//   by the block-sparse path.
-// A workgroup that sees a non-finite / out-of-range value reports +inf as its block norm; k_sum_sparse
+//   i.e. the 64 lanes (h, row%32) of a v_mfma_f32_32x32x16_f16 operand fragment are one contiguous 1 KiB block
+//   per (32-row block, k-step).
+//   int8 plane (the screening product of the max pass and the sparse sum kernel): q = rint(x / sigma) with one
+//   step sigma = max_k|x_k| / 127 per DESCRIPTOR - identical descriptors get identical codes, steps and error
+//   margins wherever they sit, which keeps exact conf ties exact (coarse_matching_new.py:105-106 keeps all tied
+//   entries); element (row, k) lives at
+//     (((row/32 * KS8 + ks) * 2 + h) * 32 + row%32) * 16 + k%16   with 16-channel chunk k/16 = h*KS8 + ks,
+//   the 64 lanes of a v_mfma_i32_32x32x32_i8 operand fragment again one contiguous 1 KiB block per k-step.
+//   The quantisation error is bounded rigorously from sigma and the descriptors' L1 norms (fm_device.h).
+// A workgroup that sees a non-finite / out-of-range value reports +inf as its block L1 maximum; k_sum_sparse
 // turns that into FM_DEV_RANGE (the flag word itself is cleared by this kernel, so it cannot be set here).
 template <int C>
 __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   constexpr int KSTEPS = C / 16;
+  constexpr int KS8 = C / 32;
+  constexpr int NCH = C / 8 / 8;          // 8-channel chunks per thread
   const int tid = threadIdx.x;
   // ---- clear this workgroup's slice of the per-call counters ----
   {
@@ -51,64 +63,92 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
     for (int k = lo_ + tid; k < hi_; k += 256) a.zero[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   __shared__ float sm[8][33];
-  float bmax = 0.f;
+  // ---------------- one 32-row block of image 0 or image 1 ----------------
+  const bool img1 = (int)blockIdx.x >= a.blocks0;
+  const long rb = img1 ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;   // row block over N*Lp/32 (N*Sp/32)
+  const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
+  _Float16* const hi = img1 ? a.hi1 : a.hi0;
+  _Float16* const lo = img1 ? a.lo1 : a.lo0;
+  signed char* const qp = img1 ? a.q1 : a.q0;
+  const int b = (int)(rb * 32 / rows_pad);
+  const int r = tid & 31;
+  const int local = (int)(rb * 32 - (long)b * rows_pad) + r;
+  const float* row = (img1 ? a.src1 : a.src0) + ((long)b * rows + local) * a.c_in;
+  float x[NCH][8];
+  float s1 = 0.f, amax = 0.f;
   bool bad = false;
-  {
-    // ---------------- one 32-row block of image 0 or image 1, fragment-major ----------------
-    const bool img1 = (int)blockIdx.x >= a.blocks0;
-    const long rb = img1 ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;   // row block over N*Lp/32 (N*Sp/32)
-    const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
-    _Float16* const hi = img1 ? a.hi1 : a.hi0;
-    _Float16* const lo = img1 ? a.lo1 : a.lo0;
-    const int b = (int)(rb * 32 / rows_pad);
-    const int r = tid & 31;
-    const int local = (int)(rb * 32 - (long)b * rows_pad) + r;
-    const float* row = (img1 ? a.src1 : a.src0) + ((long)b * rows + local) * a.c_in;
-    float ss = 0.f;
 #pragma unroll
-    for (int n = 0; n < C / 8 / 8; ++n) {             // C/8 chunks of 8 channels, 8 per pass
-      const int q = n * 8 + (tid >> 5);
-      const int h = q / KSTEPS, ks = q - h * KSTEPS;
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-      if (local < rows) {
-        if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
-        if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
-      }
-      bad = bad || bad_value(v0) || bad_value(v1);
-      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-      half8 hh, ll;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        hh[e] = (_Float16)x[e];
-        ll[e] = (_Float16)(x[e] - (float)hh[e]);
-        ss += x[e] * x[e];
-      }
-      const long off = (((rb * KSTEPS + ks) * 2 + h) * 32 + r) * 8;
-      *reinterpret_cast<half8*>(hi + off) = hh;
-      *reinterpret_cast<half8*>(lo + off) = ll;
+  for (int n = 0; n < NCH; ++n) {             // C/8 chunks of 8 channels, 8 per pass
+    const int q = n * 8 + (tid >> 5);
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (local < rows) {
+      if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
+      if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
     }
-    sm[tid >> 5][r] = ss;
-    __syncthreads();
-    if (tid < 32) {
-      float t = 0.f;
+    bad = bad || bad_value(v0) || bad_value(v1);
+    x[n][0] = v0.x; x[n][1] = v0.y; x[n][2] = v0.z; x[n][3] = v0.w;
+    x[n][4] = v1.x; x[n][5] = v1.y; x[n][6] = v1.z; x[n][7] = v1.w;
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    half8 hh, ll;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) t += sm[g][tid];
-      const float nrm = sqrtf(t);
-      (img1 ? a.norm1 : a.norm0)[rb * 32 + tid] = nrm;
-      bmax = nrm;
+    for (int e = 0; e < 8; ++e) {
+      hh[e] = (_Float16)x[n][e];
+      ll[e] = (_Float16)(x[n][e] - (float)hh[e]);
+      s1 += fabsf(x[n][e]);
+      amax = fmaxf(amax, fabsf(x[n][e]));
     }
+    const int h = q / KSTEPS, ks = q - h * KSTEPS;
+    const long off = (((rb * KSTEPS + ks) * 2 + h) * 32 + r) * 8;
+    *reinterpret_cast<half8*>(hi + off) = hh;
+    *reinterpret_cast<half8*>(lo + off) = ll;
   }
-  if (__any(bad)) bmax = INFINITY;
+  // per-row maximum of |x| -> quantisation step; per-row L1 norms (a row's channels sit in 8 threads)
+  __shared__ float sm2[8][33];
+  sm[tid >> 5][r] = s1;
+  sm2[tid >> 5][r] = amax;
+  __syncthreads();
+  amax = sm2[0][r];
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, m));
-  __shared__ float wmax[4];
-  if ((tid & 63) == 0) wmax[tid >> 6] = bmax;
+  for (int g = 1; g < 8; ++g) amax = fmaxf(amax, sm2[g][r]);
+  // (an all-zero row - padding - gets sigma = 0: it must not raise the image's largest step)
+  const float sigma = amax * (1.0f / 127.0f);
+  const float inv_sigma = amax > 0.f ? 1.0f / sigma : 0.f;
+#pragma unroll
+  for (int n = 0; n < NCH; ++n) {
+    const int q = n * 8 + (tid >> 5);          // 8-channel chunk; 16-channel chunk q/2, byte half q&1
+    int w0 = 0, w1 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int v = (int)fminf(fmaxf(rintf(x[n][e] * inv_sigma), -127.f), 127.f);
+      const int u = (int)fminf(fmaxf(rintf(x[n][4 + e] * inv_sigma), -127.f), 127.f);
+      w0 |= (v & 0xff) << (8 * e);
+      w1 |= (u & 0xff) << (8 * e);
+    }
+    const int q16 = q >> 1;
+    const int h = q16 / KS8, ks = q16 - h * KS8;
+    const long off = (((rb * KS8 + ks) * 2 + h) * 32 + r) * 16 + (q & 1) * 8;
+    *reinterpret_cast<int2*>(qp + off) = make_int2(w0, w1);
+  }
+  float bl1 = 0.f, bsg = 0.f;
+  if (tid < 32) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += sm[g][tid];
+    (img1 ? a.l1_1 : a.l1_0)[rb * 32 + tid] = t;
+    (img1 ? a.sig1 : a.sig0)[rb * 32 + tid] = sigma;
+    bl1 = t;
+    bsg = sigma;
+  }
+  if (__any(bad)) bl1 = INFINITY;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { bl1 = fmaxf(bl1, __shfl_xor(bl1, m)); bsg = fmaxf(bsg, __shfl_xor(bsg, m)); }
+  __shared__ float wred[4];
+  if ((tid & 63) == 0) wred[tid >> 6] = bl1;
   __syncthreads();
   if (tid == 0) {
-    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    if ((int)blockIdx.x < a.blocks0) a.bmax0[blockIdx.x] = m;
-    else a.bmax1[(int)blockIdx.x - a.blocks0] = m;     // one entry per 32-row block for both images
+    const float m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    (img1 ? a.bl1_1 : a.bl1_0)[rb] = m;
+    (img1 ? a.bsig1 : a.bsig0)[rb] = bsg;          // wave 0 holds the 32 rows' steps
   }
 }
 
@@ -118,8 +158,11 @@ hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const C
   a.src0 = feat0; a.src1 = feat1;
   a.hi0 = (_Float16*)(base + w.hi0); a.lo0 = (_Float16*)(base + w.lo0);
   a.hi1 = (_Float16*)(base + w.hi1); a.lo1 = (_Float16*)(base + w.lo1);
-  a.norm0 = (float*)(base + w.norm0); a.norm1 = (float*)(base + w.norm1);
-  a.bmax0 = (float*)(base + w.bmax0); a.bmax1 = (float*)(base + w.bmax1);
+  a.q0 = (signed char*)(base + w.q0); a.q1 = (signed char*)(base + w.q1);
+  a.sig0 = (float*)(base + w.sig0); a.sig1 = (float*)(base + w.sig1);
+  a.bsig0 = (float*)(base + w.bsig0); a.bsig1 = (float*)(base + w.bsig1);
+  a.l1_0 = (float*)(base + w.l1_0); a.l1_1 = (float*)(base + w.l1_1);
+  a.bl1_0 = (float*)(base + w.bl1_0); a.bl1_1 = (float*)(base + w.bl1_1);
   a.zero = (uint4*)(base + w.zero_begin); a.zero_vec = (int)((w.zero_end - w.zero_begin) / 16);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.c_in = c_in;
   a.blocks0 = (int)((long)w.N * w.Lp / 32);
@@ -136,7 +179,7 @@ hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const C
 // Softmax denominators of EVERY row and column (only the exact screening pass and the dense conf_matrix need
 // them; the common path folds the denominators of its candidates in k_select).
 // grid (chunks, N, 2): z = 0 rows of image 0 (sum over j), z = 1 columns (over i).
-// The partial sums come from the sparse sum kernel (partS) and, when it flagged units, from the dense one
+// The partial sums come from the sparse sum kernel (partS) or, for the samples it redid, from the dense one
 // (partB); out = their sum in a fixed order (deterministic), nm2 = nm - log2(out) the log-softmax offset.
 // Workgroup = 16 consecutive entries x 16 part-groups: every thread folds ~nparts/16 partials (all
 // loads independent and in flight together), then the 16 groups are folded through LDS in a fixed order.
@@ -146,17 +189,18 @@ __global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ r
                                                      int rpartsS, int rpartsB, int cparts,
                                                      const float* __restrict__ nm_r, const float* __restrict__ nm_c,
                                                      float* __restrict__ nm2_r, float* __restrict__ nm2_c,
-                                                     int* __restrict__ cand_count, const Scalars* __restrict__ scal) {
+                                                     int* __restrict__ cand_count, int* __restrict__ cand_count_b,
+                                                     const int* __restrict__ dense_cnt, const Scalars* __restrict__ scal) {
   const int side = blockIdx.z;
   const int b = blockIdx.y;
   const int len = side ? Sp : Lp;
   if ((int)blockIdx.x * 16 >= len) return;
-  const bool dense = scal->dense_units > 0;
+  const bool dense = dense_cnt[b] > 0;       // the dense sum kernel redid this sample
   const int cx = threadIdx.x & 15, pg = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + cx;       // len is a multiple of 64
   __shared__ float fold[16][17];
   float acc = 0.f;
-  {
+  if (!dense) {
     const int nparts = side ? cparts : rpartsS;
     const float* part = (side ? colS : rowS) + (long)b * nparts * len;
 #pragma unroll 4
@@ -180,7 +224,7 @@ __global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ r
   const long gi = (long)b * len + idx;
   (side ? nm2_c : nm2_r)[gi] = (side ? nm_c : nm_r)[gi] - __log2f(v);
   // the sum kernels overflowed some row's candidate slots: the exact screening sweep refills the lists from scratch
-  if (side == 0 && (scal->flags & FM_INT_SCREEN_OVERFLOW)) cand_count[gi] = 0;
+  if (side == 0 && (scal->flags & FM_INT_SCREEN_OVERFLOW)) (dense ? cand_count_b : cand_count)[gi] = 0;
 }
 
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st) {
@@ -191,7 +235,8 @@ hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, 
                      (const float*)(base + w.rowB), (const float*)(base + w.colB), (float*)(base + w.rsum),
                      (float*)(base + w.csum), w.Lp, w.Sp, w.splits_s, w.splits, w.panels,
                      (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
-                     (float*)(base + w.nmc2), (int*)(base + w.cand_count), (const Scalars*)(base + w.scalars));
+                     (float*)(base + w.nmc2), (int*)(base + w.cand_count), (int*)(base + w.cand_count_b),
+                     (const int*)(base + w.dense_cnt), (const Scalars*)(base + w.scalars));
   return hipGetLastError();
 }
 

@@ -16,8 +16,10 @@ struct SelArgs {
   const float* rowS; const float* colS;   // partial sums of the sparse sum kernel: rows [N][splits_s][Lp], columns [N][panels][Sp]
   const float* rowB; const float* colB;   // ... of the dense sum kernel (valid when it had units): rows [N][splits][Lp]
   int exact;                              // exact screening ran: its overflow is then FM_DEV_CANDIDATES already
-  const int* cand_count; const int* cand_j;
-  float* cand_conf; float* rowbest; unsigned* colbest;
+  const int* cand_count; const int* cand_j; float* cand_conf;          // the sparse sum kernel's candidates
+  const int* cand_count_b; const int* cand_j_b; float* cand_conf_b;    // the dense one's (samples with dense_cnt > 0)
+  const int* dense_cnt;
+  float* rowbest; unsigned* colbest;
   int* blocktot; Scalars* scal;
   int N, L, S, C, Lp, Sp, splits, splits_s, panels, slots;
   int h0c, w0c, h1c, w1c, border;
@@ -37,12 +39,17 @@ __global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
   const int b = (int)(grow / a.Lp);
   const int i = (int)(grow - (long)b * a.Lp);
   float conf = 0.f;
-  const int cnt = (b < a.N && i < a.L) ? min(a.cand_count[grow], a.slots) : 0;
+  // a sample is handled by ONE sum kernel: the dense one redid it if the sparse one flagged any of its units
+  const bool dense = b < a.N && a.dense_cnt[b] > 0;
+  const int* cand_count = dense ? a.cand_count_b : a.cand_count;
+  const int* cand_j = dense ? a.cand_j_b : a.cand_j;
+  float* cand_conf = dense ? a.cand_conf_b : a.cand_conf;
+  const int cnt = (b < a.N && i < a.L) ? min(cand_count[grow], a.slots) : 0;
   if (slot < cnt) {
-    const int j = a.cand_j[grow * a.slots + slot];
-    // the accumulator value pass B produced for this entry: the same number that entered the row
+    const int j = cand_j[grow * a.slots + slot];
+    // the dot product the sum kernel produced for this entry: the same number that entered the row
     // and column sums, so numerator and denominator are consistent (as in the reference's softmax)
-    const float x = a.cand_conf[grow * a.slots + slot];
+    const float x = cand_conf[grow * a.slots + slot];
     // softmax denominators of this row and this column, folded from pass B's partials in a fixed order
     // (all loads independent: one round trip; no separate reduction kernel on the common path)
     float rs = 0.f, cs = 0.f;
@@ -57,16 +64,17 @@ __global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
       }
       return t;
     };
-    rs = fold(a.rowS + (long)b * a.splits_s * a.Lp + i, a.splits_s, a.Lp);
-    cs = fold(a.colS + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
-    if (a.scal->dense_units > 0) {      // the dense sum kernel had units of its own
-      rs += fold(a.rowB + (long)b * a.splits * a.Lp + i, a.splits, a.Lp);
-      cs += fold(a.colB + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
+    if (dense) {
+      rs = fold(a.rowB + (long)b * a.splits * a.Lp + i, a.splits, a.Lp);
+      cs = fold(a.colB + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
+    } else {
+      rs = fold(a.rowS + (long)b * a.splits_s * a.Lp + i, a.splits_s, a.Lp);
+      cs = fold(a.colS + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
     }
     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmr[grow])) / rs;
     const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmc[(long)b * a.Sp + j])) / cs;
     conf = pr * pc;
-    a.cand_conf[grow * a.slots + slot] = conf;
+    cand_conf[grow * a.slots + slot] = conf;
     atomicMax(&a.colbest[(long)b * a.Sp + j], __float_as_uint(conf));
   }
   float best = conf;
@@ -97,13 +105,17 @@ __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
   const int slot = (int)(gid - grow * a.slots);
   const int b = (int)(grow / a.Lp);
   const int i = (int)(grow - (long)b * a.Lp);
-  const int cnt = (b < a.N && i < a.L) ? min(a.cand_count[grow], a.slots) : 0;
+  const bool dense = b < a.N && a.dense_cnt[b] > 0;
+  const int* cand_count = dense ? a.cand_count_b : a.cand_count;
+  const int* cand_j = dense ? a.cand_j_b : a.cand_j;
+  const float* cand_conf = dense ? a.cand_conf_b : a.cand_conf;
+  const int cnt = (b < a.N && i < a.L) ? min(cand_count[grow], a.slots) : 0;
   bool keep = false;
   int j = 0x7fffffff;
   float conf = 0.f;
   if (slot < cnt) {
-    j = a.cand_j[grow * a.slots + slot];
-    conf = a.cand_conf[grow * a.slots + slot];
+    j = cand_j[grow * a.slots + slot];
+    conf = cand_conf[grow * a.slots + slot];
     keep = conf > a.thr && conf == a.rowbest[grow] &&
            __float_as_uint(conf) == a.colbest[(long)b * a.Sp + j] &&
            interior(i, a.h0c, a.w0c, a.border) && interior(j, a.h1c, a.w1c, a.border);
@@ -199,6 +211,8 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   a.rowB = (const float*)(base + w.rowB); a.colB = (const float*)(base + w.colB);
   a.cand_count = (const int*)(base + w.cand_count); a.cand_j = (const int*)(base + w.cand_j);
   a.cand_conf = (float*)(base + w.cand_conf); a.rowbest = (float*)(base + w.rowbest);
+  a.cand_count_b = (const int*)(base + w.cand_count_b); a.cand_j_b = (const int*)(base + w.cand_j_b);
+  a.cand_conf_b = (float*)(base + w.cand_conf_b); a.dense_cnt = (const int*)(base + w.dense_cnt);
   a.colbest = (unsigned*)(base + w.colbest);
   a.blocktot = (int*)(base + w.blocktot);
   a.scal = (Scalars*)(base + w.scalars);

@@ -2,8 +2,9 @@
 // that matter, without barriers inside the sweep.
 //
 // Reproduces network/utils/coarse_matching_new.py:64-68 (correlation + dual softmax) for every entry whose
-// term is not negligible.  After the max pass (k_corr<C,0>: row / column maxima and the maximum of every
-// 32 x 32 unit of the float16 hi x hi product) each entry s_ij falls in one of three classes:
+// term is not negligible.  After the max pass (k_max_i8: row / column maxima and the maximum of every
+// 32 x 32 unit of the int8 screening product x~, error bounded by fm_device.h) each entry s_ij falls in one of
+// three classes:
 //   * negligible : k x~_ij + margin lies more than 2^32 below BOTH its row's and its column's stabiliser: it adds
 //                  < 2^-32 to sums that are >= e^-2E ~ 1 (<= S 2^-32 ~ 1e-6 relative in total, inside the 1e-5
 //                  parity bar) and cannot be a candidate.  Never touched again.  With dual-softmax-trained
@@ -12,41 +13,47 @@
 //                  caller's rows (one wave, 4 channels per lane, fixed butterfly) and enters
 //                  sum_j exp2(k x - m^_i), sum_i exp2(k x - c^_j) and, when both terms pass log2 thr, the
 //                  candidate list - the same number in numerator and denominator of conf, as in the reference.
-//   * significant, many per unit (flat similarity: untrained network, repetitive texture) : the unit is FLAGGED
-//                  for the dense sum kernel (k_corr<C,1>: float32-equivalent hi/lo product on the matrix cores for
-//                  all 1024 entries), which runs next and exits at once when nothing is flagged.
+//   * significant, many per unit (flat similarity: untrained network, repetitive texture) : the unit's SAMPLE is
+//                  flagged for the dense sum kernel (k_corr<C,1>: float32-equivalent hi/lo product on the matrix
+//                  cores for all 1024 entries of every live unit), which runs next, redoes that sample and exits at
+//                  once when no sample is flagged.  A sample is handled by ONE of the two kernels: their float32
+//                  products agree to ~1e-7 but not bit for bit, and coarse_matching_new.py:105-106 keeps exactly
+//                  tied entries (conf == row max == column max), so identical descriptors must see one arithmetic.
 //
 // Structure: a workgroup = 8 INDEPENDENT waves = 8 row blocks (32 rows) x one range of <= 16 column units; no
 // LDS tile ring and no barrier in the sweep - with ~1 unit in 5 alive, lock-stepping 8 waves through shared
 // tiles cost the old sum sweep 19k of its 55k cycles in barrier waits at 640x480.  A wave keeps its 32 rows as
-// hi A-fragments in 64 VGPRs (no lo plane: half the prologue bytes), decides from the unit maxima which of its
-// units are alive, and for each of them loads the hi B-fragments straight into registers (16 x 1 KiB contiguous
-// blocks of the fragment-major plane, the next unit's issued behind the MFMA chain), runs 16 MFMAs, screens the
+// int8 A-fragments in 32 VGPRs, decides from the unit maxima which of its units are alive, and for each of them
+// loads the int8 B-fragments straight into registers (8 x 1 KiB contiguous blocks of the fragment-major plane at
+// C = 256 - the sweep is bound by these L2 -> CU bytes, which is why it runs on the int8 planes - with the next
+// unit's in flight behind the current chain), runs 8 v_mfma_i32_32x32x32_i8, screens the
 // 32 x 32 accumulators against the stabilisers and resolves the significant entries exactly.  All sums are
 // formed in a fixed order: results are bitwise reproducible.
 #include "fm_device.h"
 
 namespace fm {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxExact = 24;         // significant entries of a unit resolved by exact dot products; more -> dense kernel
 constexpr int kSparseQueue = 64;      // candidates a wave parks in LDS (one per lane at the hand-over)
 
 struct SparseArgs {
-  const _Float16* hi0; const _Float16* hi1;
+  const signed char* q0; const signed char* q1;       // int8 screening planes (k_prep_split)
   const float* src0; const float* src1; int c_in;      // the caller's descriptors [N,L,c_in] / [N,S,c_in]
-  const unsigned* rowmax_u; const unsigned* colmax_u;  // max pass: ord_encode'd maxima of the f16 product
-  const float* norm0; const float* norm1; const float* bmax0; const float* bmax1;
+  const unsigned* rowmax_u; const unsigned* colmax_u;  // max pass: ord_encode'd maxima of the screening product
+  const float* sig0; const float* sig1;                // quantisation step per descriptor
+  const float* bsig0; const float* bsig1;              // ... largest per 32-row block
+  const float* l1_0; const float* l1_1; const float* bl1_0; const float* bl1_1;   // L1 norms, their block maxima
   const float* umax;
   float* nmr; float* nmc; float* emarg;                // written here: stabilisers, pair margin
   float* rowS; float* colS;                            // partial sums [N][splits][Lp], [N][panels][Sp]
-  float* dense_map; Scalars* scal;
+  int* dense_cnt; Scalars* scal;                       // [N] units per sample left to the dense kernel
   float* diag;                                         // diagnostic build: stamp buffer
   int* cand_count; int* cand_j; float* cand_x;
   int L, S, Lp, Sp, panels, splits, units_s, slots, pgroup;
-  float k, lt, inv_ct, sqrt_c;
+  float k, lt, inv_ct, cpad;
 };
 
 __device__ __forceinline__ int xcd_remap_s(int bid, int n) {
@@ -74,8 +81,8 @@ __device__ __forceinline__ float wave_reduce64(float v) {
 
 template <int C>
 __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
-  constexpr int KSTEPS = C / 16;
-  constexpr int LIST = kUnitsPerSplit * kMaxExact;      // significant entries a wave can park
+  constexpr int KS8 = C / 32;           // k-steps of v_mfma_i32_32x32x32_i8
+  constexpr int LIST = 256;             // significant entries a wave can park (beyond that a unit goes to the dense kernel)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,11 +113,17 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 #define DIAG_STAMP(i)
 #endif
 
-  __shared__ float s_nmr[8][32];
-  __shared__ float s_nmc[kUnitsPerSplit * 32];
+  __shared__ __attribute__((aligned(16))) float s_nmr[8][32];
+  __shared__ __attribute__((aligned(16))) float s_sgr[8][32];      // the quantisation steps of the 8 waves' rows
   __shared__ float s_cmax[kUnitsPerSplit];
   __shared__ int s_hot[8];
-  __shared__ float s_colacc[8][kUnitsPerSplit * 32];
+  // dynamic LDS, sized for the range: column stabilisers [U*32], column steps [U*32], then the 8 waves' column
+  // accumulators [8][U*32]
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float* s_nmc = s_dyn;
+  float* s_sgc = s_dyn + a.units_s * 32;
+  float* s_colacc = s_dyn + 2 * a.units_s * 32;
+  const int cpitch = a.units_s * 32;
   __shared__ int s_list[8][LIST];              // (unit << 10) | (row in wave << 5) | column in unit
   __shared__ int s_qkey[8][kSparseQueue];
   __shared__ float s_qx[8][kSparseQueue];
@@ -119,53 +132,81 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   // maxima, this wave's row statistics, the range's column statistics, the unit maxima and, speculatively, the
   // wave's A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7; one contiguous 1 KiB block per k-step of the
   // fragment-major plane of k_prep_split) ----
-  float own = 0.f, oth = 0.f;          // largest descriptor norm of image 0 / image 1 (every wave folds them itself)
-  for (int i = lane; i < a.Lp / 32; i += 64) own = fmaxf(own, a.bmax0[(long)b * (a.Lp / 32) + i]);
-  for (int i = lane; i < nunits; i += 64) oth = fmaxf(oth, a.bmax1[(long)b * nunits + i]);
+  float sigA_max, l1A_max, sigB_max, l1B_max;     // image maxima of the block scales / L1 norms (every wave folds them itself)
+  {
+    // eight predicated loads per lane in flight (a plain strided loop waits for every load before the next)
+    auto lane_max = [&](const float* p, int n) {
+      float m = 0.f;
+      for (int base = 0; base < n; base += 512) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = base + q * 64 + lane; v[q] = i < n ? p[i] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = fmaxf(m, v[q]);
+      }
+      return m;
+    };
+    sigA_max = lane_max(a.bsig0 + (long)b * (a.Lp / 32), a.Lp / 32);
+    l1A_max = lane_max(a.bl1_0 + (long)b * (a.Lp / 32), a.Lp / 32);
+    sigB_max = lane_max(a.bsig1 + (long)b * nunits, nunits);
+    l1B_max = lane_max(a.bl1_1 + (long)b * nunits, nunits);
+  }
   const long gi = (long)b * a.Lp + wrow0 + r;
   const unsigned rmax_u = a.rowmax_u[gi];
-  const float rnorm = a.norm0[gi];
+  const float rl1 = a.l1_0[gi];
+  const float rsig = a.sig0[gi];
+  const float sA = a.bsig0[(long)b * (a.Lp / 32) + rb];          // largest step of this wave's rows
+  const float bl1A = a.bl1_0[(long)b * (a.Lp / 32) + rb];
+  // (the first 512 columns of the range here; a longer range - large batches only - fetches the rest below)
   unsigned cmax_u = 0u;
-  float cnorm = 0.f;
-  const long gj = (long)b * a.Sp + u0 * 32 + tid;
-  if (tid < U * 32) { cmax_u = a.colmax_u[gj]; cnorm = a.norm1[gj]; }
-  float um = -INFINITY;
-  if (lane < U) um = a.umax[((long)b * (a.Lp / 32) + rb) * nunits + u0 + lane];
-  half8 ahi[KSTEPS];
-  if (wrow0 < a.L) {
-    const long off = (((long)b * a.Lp + wrow0) / 32 * KSTEPS * 64 + lane) * 8;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) ahi[ks] = *reinterpret_cast<const half8*>(a.hi0 + off + ks * 512);
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ahi[ks][e] = (_Float16)0.f;
+  float cl1 = 0.f, csig = 0.f;
+  if (tid < U * 32) {
+    cmax_u = a.colmax_u[(long)b * a.Sp + u0 * 32 + tid]; cl1 = a.l1_1[(long)b * a.Sp + u0 * 32 + tid];
+    csig = a.sig1[(long)b * a.Sp + u0 * 32 + tid];
   }
-  for (int c = lane; c < U * 32; c += 64) s_colacc[wv][c] = 0.f;
+  float um = -INFINITY, sB_lane = 0.f, bl1B_lane = 0.f;     // lane u: unit u0 + u of this wave's row block
+  if (lane < U) {
+    um = a.umax[((long)b * (a.Lp / 32) + rb) * nunits + u0 + lane];
+    sB_lane = a.bsig1[(long)b * nunits + u0 + lane];               // largest step of the unit's columns
+    bl1B_lane = a.bl1_1[(long)b * nunits + u0 + lane];
+  }
+  v4i aq[KS8];
+  {
+    const signed char* src = a.q0 + (((long)b * a.Lp + wrow0) / 32 * KS8 * 64 + lane) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
+  }
+  for (int c = lane; c < U * 32; c += 64) s_colacc[wv * cpitch + c] = 0.f;
 
-  own = wave_reduce64<false>(own);
-  oth = wave_reduce64<false>(oth);
+  sigA_max = wave_reduce64<false>(sigA_max);
+  l1A_max = wave_reduce64<false>(l1A_max);
+  sigB_max = wave_reduce64<false>(sigB_max);
+  l1B_max = wave_reduce64<false>(l1B_max);
   DIAG_STAMP(1)
-  const float emarg = pair_margin_log2(own, oth, a.inv_ct, a.sqrt_c);
   if (panel == 0 && split == 0 && tid == 0) {
+    const float emarg = margin_log2(q8_margin_raw(sigA_max, l1A_max, sigB_max, l1B_max, a.cpad), a.inv_ct);
     a.emarg[b] = emarg;
-    // a prep workgroup that met NaN/Inf/|x| >= 32768 reported +inf
-    if (!(own < INFINITY) || !(oth < INFINITY)) atomicOr(&a.scal->flags, (unsigned)FM_DEV_RANGE);
+    // a prep workgroup that met NaN/Inf/|x| >= 32768 reported +inf; descriptors so large that the screening margin
+    // alone could overflow exp2 (similarities of several thousand) are out of range as well
+    if (!(l1A_max < INFINITY) || !(l1B_max < INFINITY) || !(emarg < 60.f)) atomicOr(&a.scal->flags, (unsigned)FM_DEV_RANGE);
   }
 
   // ---- stabilisers: this wave's 32 rows, the workgroup's column range ----
   // lanes 0..31 (and their mirror 32..63): -stabiliser*log2e of row wrow0 + r
-  const float nm_lane = neg_stabiliser_log2(ord_decode(rmax_u), rnorm, oth, a.inv_ct, a.sqrt_c);
+  const float nm_lane = neg_stabiliser_log2(ord_decode(rmax_u), q8_margin_raw(rsig, rl1, sigB_max, l1B_max, a.cpad), a.inv_ct);
   if (h == 0) {
     s_nmr[wv][r] = nm_lane;
+    s_sgr[wv][r] = rsig;
     if (split == 0) a.nmr[gi] = nm_lane;
   }
   // padded rows (>= L) never contribute: keep them out of the wave's largest stabiliser
   const float wmax_nmr = wave_reduce64<false>(wrow0 + r < a.L ? nm_lane : -INFINITY);
-  if (tid < U * 32) {
-    const float nm = neg_stabiliser_log2(ord_decode(cmax_u), cnorm, own, a.inv_ct, a.sqrt_c);
-    s_nmc[tid] = nm;
+  for (int c = tid; c < U * 32; c += 512) {
+    const long gj = (long)b * a.Sp + u0 * 32 + c;
+    if (c >= 512) { cmax_u = a.colmax_u[gj]; cl1 = a.l1_1[gj]; csig = a.sig1[gj]; }
+    const float nm = neg_stabiliser_log2(ord_decode(cmax_u), q8_margin_raw(csig, cl1, sigA_max, l1A_max, a.cpad), a.inv_ct);
+    s_nmc[c] = nm;
+    s_sgc[c] = csig;
     if (panel == 0) a.nmc[gj] = nm;
   }
   __syncthreads();
@@ -176,18 +217,20 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   __syncthreads();
 
   // ---- which of this wave's units are alive (same bound as the dense kernel's block-sparse skip) ----
+  // lane u: log2-domain bound of k * |screening product - exact product| over unit u of this wave's row block
+  const float emu_lane = margin_log2(q8_margin_raw(sA, bl1A, sB_lane, bl1B_lane, a.cpad), a.inv_ct);
   bool hot = false;
   if (lane < U && wrow0 < a.L) {
-    const float top = __builtin_fmaf(um, a.k, emarg);             // >= k * (exact product), log2 domain
+    const float top = __builtin_fmaf(um, a.k, emu_lane);          // >= k * (exact product), log2 domain
     hot = !((top + wmax_nmr < -kSkipLog2) && (top + s_cmax[lane] < -kSkipLog2));
   }
-  unsigned mask = (unsigned)__ballot(hot);          // wave-uniform
-  if (lane == 0) s_hot[wv] = __builtin_popcount(mask);
+  unsigned long long mask = __ballot(hot);          // wave-uniform
+  if (lane == 0) s_hot[wv] = __builtin_popcountll(mask);
   __syncthreads();
   int tot = 0;
 #pragma unroll
   for (int w8 = 0; w8 < 8; ++w8) tot += s_hot[w8];
-  unsigned dmask = 0;            // units left to the dense kernel
+  unsigned long long dmask = 0;  // units left to the dense kernel
   if (tot * 2 > 8 * U) {         // more than half of the block is alive: flat similarity, a matrix-core job
     dmask = mask;
     mask = 0;
@@ -196,84 +239,101 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   int nlist = 0;                 // parked significant entries (wave-uniform)
   DIAG_STAMP(2)
 #ifdef FM_DIAG_CLOCK
-  const int diag_units = __builtin_popcount(mask);
+  const int diag_units = __builtin_popcountll(mask);
   dg[3] = dg[2];
 #endif
   if (mask) {
-    // this lane's 16 row stabilisers (rows 8q + 4h + 0..3 of the wave's 32) with the pair margin folded in
-    float nmr_e[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) nmr_e[g] = s_nmr[wv][(g & 3) + 8 * (g >> 2) + 4 * h] + emarg;
     const bool row_edge = (wrow0 + 32 > a.L);
 
-    half8 bfr[KSTEPS];
-    auto load_b = [&](int ul) {
-      const _Float16* src = a.hi1 + (((long)b * nunits + u0 + ul) * KSTEPS * 64 + lane) * 8;
+    // B fragments of two units: while one feeds the MFMA chain the next one's 8 KiB are already in flight
+    v4i bq0[KS8], bq1[KS8];
+    auto load_b = [&](v4i (&bq)[KS8], int ul) {
+      const signed char* src = a.q1 + (((long)b * nunits + u0 + ul) * KS8 * 64 + lane) * 16;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) bfr[ks] = *reinterpret_cast<const half8*>(src + ks * 512);
+      for (int ks = 0; ks < KS8; ++ks) bq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
     };
-    load_b(__builtin_ctz(mask));
+    auto unit = [&](const v4i (&bq)[KS8], int ul) {
+      const int ucol0 = (u0 + ul) * 32;
+      v16i acc;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[g] = 0;
+#pragma unroll
+      for (int ks = 0; ks < KS8; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks], acc, 0, 0, 0);
+      // this unit's margin (lane ul holds it)
+      const float emu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emu_lane), ul));
+      const float ksj = a.k * s_sgc[ul * 32 + r];      // this lane's column: integer dot * sigma_i * ksj = k x~
+      const float sig_thr = -kSkipLog2 - emu;          // the margin turns k x~ into an upper bound of k x
+      float xf[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) xf[g] = (float)acc[g] * ksj;
+      if (row_edge || ucol0 + 32 > a.S) {              // padded rows (>= L) / columns (>= S) never count
+        const bool cok = ucol0 + r < a.S;
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) xf[g] = -INFINITY;
+      }
+      // significance: k x~ + margin within 2^32 of the row's or the column's stabiliser.  One compare per
+      // accumulator register writes the wave's mask straight to scalar registers; the (rare) significant
+      // entries are parked at once, in (register, lane) order, and taken back if the unit turns out to have
+      // too many of them (flat similarity: the dense kernel's job).
+      const float nmc_l = s_nmc[ul * 32 + r];
+      const int nlist0 = nlist;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {      // this lane's rows 8q + 4h + 0..3 of the wave's 32: one 16-byte LDS read
+        const float4 nm4 = *reinterpret_cast<const float4*>(&s_nmr[wv][8 * q + 4 * h]);
+        const float4 sg4 = *reinterpret_cast<const float4*>(&s_sgr[wv][8 * q + 4 * h]);
+        const float nm[4] = {nm4.x, nm4.y, nm4.z, nm4.w};
+        const float sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float tr = __builtin_fmaf(xf[4 * q + e], sg[e], nm[e]);
+          const float tc = __builtin_fmaf(xf[4 * q + e], sg[e], nmc_l);
+          unsigned long long m = __ballot(fmaxf(tr, tc) > sig_thr);
+          while (m) {                    // wave-uniform, usually not entered
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int rl = e + 8 * q + 4 * (l >> 5);
+            if (lane == 0 && nlist < LIST) s_list[wv][nlist] = (ul << 10) | (rl << 5) | (l & 31);
+            ++nlist;
+          }
+        }
+      }
+      if (nlist - nlist0 > kMaxExact || nlist > LIST) { nlist = nlist0; dmask |= 1ull << ul; }
+    };
+    load_b(bq0, __builtin_ctzll(mask));
 #ifdef FM_DIAG_CLOCK
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DIAG_STAMP(3)
 #endif
+    // The prefetch is UNCONDITIONAL (with no unit left it re-reads the current one): behind a branch hipcc has to
+    // assume the shorter path at the join and waits vmcnt(0) in front of the MFMA chain - i.e. for the prefetch it
+    // has just issued (measured: 2.5k cycles per unit instead of ~1k).
     while (mask) {
-      const int ul = __builtin_ctz(mask);
+      const int ua = __builtin_ctzll(mask);
       mask &= mask - 1;
-      const int ucol0 = (u0 + ul) * 32;
-      // The accumulator starts at 0, or at -inf for padded rows (>= L) / padded columns (>= S): such entries
-      // stay -inf through the chain and fail the significance test.
-      f32x16 acc;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-      if (row_edge || ucol0 + 32 > a.S) {
-        const float cb = (ucol0 + r < a.S) ? 0.f : -INFINITY;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[g] = (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h < a.L) ? cb : -INFINITY;
-      }
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bfr[ks], acc, 0, 0, 0);
-      if (mask) load_b(__builtin_ctz(mask));        // next unit's fragments fly behind the epilogue
-
-      // significance: k x~ + margin within 2^32 of the row's or the column's stabiliser
-      const float nmc_e = s_nmc[ul * 32 + r] + emarg;
-      unsigned lm = 0;           // bit g: accumulator register g of this lane is significant
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const float v = __builtin_fmaf(acc[g], a.k, fmaxf(nmr_e[g], nmc_e));
-        lm |= (v > -kSkipLog2) ? (1u << g) : 0u;
-      }
-      unsigned long long any = __ballot(lm != 0);
-      if (!any) continue;
-      const int nsig = (int)wave_reduce64<true>((float)__builtin_popcount(lm));      // <= 1024: exact in float
-      if (nsig > kMaxExact) { dmask |= 1u << ul; continue; }
-      // park the entries (fixed order: lane, then register); they are resolved after the sweep, several at a time
-      while (any) {
-        const int l = __builtin_ctzll(any);
-        any &= any - 1;
-        unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)lm, l);
-        while (bits) {
-          const int g = __builtin_ctz(bits);
-          bits &= bits - 1;
-          const int rl = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-          if (lane == 0) s_list[wv][nlist] = (ul << 10) | (rl << 5) | (l & 31);
-          ++nlist;
-        }
-      }
+      load_b(bq1, mask ? __builtin_ctzll(mask) : ua);
+      unit(bq0, ua);
+      if (!mask) break;
+      const int ub = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      load_b(bq0, mask ? __builtin_ctzll(mask) : ub);
+      unit(bq1, ub);
     }
   }
 
-  // ---- the parked entries: exact float32 dot products of the caller's descriptors, four entries (eight row
+  // ---- the parked entries: exact float32 dot products of the caller's descriptors, eight entries (sixteen row
   // loads per lane) in flight; sums in list order (deterministic) ----
   float racc = 0.f;              // lanes 0..31: sum_j exp2(k x - m^) of row wrow0 + lane over this range
   int qn = 0;                    // parked candidates (wave-uniform)
   DIAG_STAMP(4)
-  for (int e0 = 0; e0 < nlist; e0 += 4) {
-    int key[4];
-    float4 av[4], bv[4];
+  constexpr int EB = 8;          // entries per batch: 16 row loads per lane in flight
+  for (int e0 = 0; e0 < nlist; e0 += EB) {
+    int key[EB];
+    float4 av[EB], bv[EB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      key[q] = __builtin_amdgcn_readfirstlane(s_list[wv][min(e0 + q, nlist - 1)]);
+    for (int q = 0; q < EB; ++q) {
+      if (e0 + q >= nlist) break;                 // wave-uniform
+      key[q] = __builtin_amdgcn_readfirstlane(s_list[wv][e0 + q]);
       const int rl = (key[q] >> 5) & 31, col = (u0 + (key[q] >> 10)) * 32 + (key[q] & 31);
       const float4* rp = reinterpret_cast<const float4*>(a.src0 + ((long)b * a.L + wrow0 + rl) * a.c_in);
       const float4* cp = reinterpret_cast<const float4*>(a.src1 + ((long)b * a.S + col) * a.c_in);
@@ -281,9 +341,10 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
       av[q] = in ? rp[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
       bv[q] = in ? cp[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float x[4];
+    float x[EB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < EB; ++q) {
+      if (e0 + q >= nlist) break;
       float p = av[q].x * bv[q].x;
       p = __builtin_fmaf(av[q].y, bv[q].y, p);
       p = __builtin_fmaf(av[q].z, bv[q].z, p);
@@ -291,7 +352,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
       x[q] = wave_reduce64<true>(p);          // the exact float32 dot product, same bits in every lane
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < EB; ++q) {
       if (e0 + q >= nlist) break;
       const int ul = key[q] >> 10, rl = (key[q] >> 5) & 31, cl = key[q] & 31;
       const float nr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm_lane), rl));
@@ -299,7 +360,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
       const float rr = __builtin_fmaf(x[q], a.k, nr);
       const float cc = __builtin_fmaf(x[q], a.k, nc);
       racc += (lane == rl) ? __builtin_amdgcn_exp2f(rr) : 0.f;
-      if (lane == 0) s_colacc[wv][ul * 32 + cl] += __builtin_amdgcn_exp2f(cc);
+      if (lane == 0) s_colacc[wv * cpitch + ul * 32 + cl] += __builtin_amdgcn_exp2f(cc);
       if (rr > a.lt && cc > a.lt) {                     // wave-uniform: a candidate (superset of conf > thr)
         const int col = (u0 + ul) * 32 + cl;
         if (qn < kSparseQueue) {
@@ -318,7 +379,6 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   DIAG_STAMP(5)
   // ---- results of this wave: row partial, dense flags, candidates ----
   if (lane < 32) a.rowS[((long)b * a.splits + split) * a.Lp + wrow0 + lane] = racc;
-  if (lane < U) a.dense_map[((long)b * (a.Lp / 32) + rb) * nunits + u0 + lane] = ((dmask >> lane) & 1u) ? 1.f : 0.f;
   {
     const int nq = min(qn, kSparseQueue);
     if (lane < nq) {
@@ -331,20 +391,20 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   }
   // ---- the workgroup's dense-unit count (one atomic per workgroup) and its column partial: the 8 waves'
   // accumulators folded in a fixed order ----
-  if (lane == 0) s_hot[wv] = __builtin_popcount(dmask);
+  if (lane == 0) s_hot[wv] = __builtin_popcountll(dmask);
   __syncthreads();
   if (tid == 0) {
     int nd = 0;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) nd += s_hot[w8];
-    if (nd) atomicAdd(&a.scal->dense_units, nd);
+    if (nd) { atomicAdd(&a.dense_cnt[b], nd); atomicAdd(&a.scal->dense_units, nd); }
   }
   float* co = a.colS + ((long)b * a.panels + panel) * a.Sp + u0 * 32;
-  if (tid < U * 32) {
-    float s = s_colacc[0][tid];
+  for (int c = tid; c < U * 32; c += 512) {
+    float s = s_colacc[c];
 #pragma unroll
-    for (int w8 = 1; w8 < 8; ++w8) s += s_colacc[w8][tid];
-    co[tid] = s;
+    for (int w8 = 1; w8 < 8; ++w8) s += s_colacc[w8 * cpitch + c];
+    co[c] = s;
   }
 #ifdef FM_DIAG_CLOCK
   DIAG_STAMP(6)
@@ -362,15 +422,17 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 hipError_t launch_sum_sparse(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
                              float inv_ct, float thr, hipStream_t st) {
   SparseArgs a;
-  a.hi0 = (const _Float16*)(base + w.hi0); a.hi1 = (const _Float16*)(base + w.hi1);
+  a.q0 = (const signed char*)(base + w.q0); a.q1 = (const signed char*)(base + w.q1);
   a.src0 = feat0; a.src1 = feat1; a.c_in = c_in;
   a.rowmax_u = (const unsigned*)(base + w.rowmax_u); a.colmax_u = (const unsigned*)(base + w.colmax_u);
-  a.norm0 = (const float*)(base + w.norm0); a.norm1 = (const float*)(base + w.norm1);
-  a.bmax0 = (const float*)(base + w.bmax0); a.bmax1 = (const float*)(base + w.bmax1);
+  a.sig0 = (const float*)(base + w.sig0); a.sig1 = (const float*)(base + w.sig1);
+  a.bsig0 = (const float*)(base + w.bsig0); a.bsig1 = (const float*)(base + w.bsig1);
+  a.l1_0 = (const float*)(base + w.l1_0); a.l1_1 = (const float*)(base + w.l1_1);
+  a.bl1_0 = (const float*)(base + w.bl1_0); a.bl1_1 = (const float*)(base + w.bl1_1);
   a.umax = (const float*)(base + w.umax);
   a.nmr = (float*)(base + w.nmr); a.nmc = (float*)(base + w.nmc); a.emarg = (float*)(base + w.emarg);
   a.rowS = (float*)(base + w.rowS); a.colS = (float*)(base + w.colS);
-  a.dense_map = (float*)(base + w.dense_map); a.scal = (Scalars*)(base + w.scalars);
+  a.dense_cnt = (int*)(base + w.dense_cnt); a.scal = (Scalars*)(base + w.scalars);
   a.diag = (float*)(base + w.rowB);
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j); a.cand_x = (float*)(base + w.cand_conf);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.splits = w.splits_s; a.units_s = w.units_s;
@@ -381,14 +443,25 @@ hipError_t launch_sum_sparse(const float* feat0, const float* feat1, int c_in, c
     int pgr = (int)lroundf(sqrtf(share * (float)(a.units_s * 32) / (float)kPanelRows));
     a.pgroup = pgr < 1 ? 1 : (pgr > w.panels ? w.panels : pgr);
   }
-  a.k = inv_ct * kLog2e; a.lt = log2f(thr); a.inv_ct = inv_ct; a.sqrt_c = sqrtf((float)w.C);
+  a.k = inv_ct * kLog2e; a.lt = log2f(thr); a.inv_ct = inv_ct; a.cpad = (float)w.C;
   const int blocks = w.N * a.splits * w.panels;
+  const int smem = a.units_s * 32 * 10 * 4;      // column stabilisers + steps + 8 waves' column accumulators
+  hipError_t e = hipSuccess;
+#define FM_SPARSE_CASE(CC)                                                                   \
+  case CC: {                                                                                 \
+    static unsigned long long lds_set = 0;                                                   \
+    e = ensure_dynamic_lds(&k_sum_sparse<CC>, kUnitsPerSplit * 32 * 10 * 4, &lds_set);        \
+    if (e != hipSuccess) return e;                                                           \
+    hipLaunchKernelGGL(k_sum_sparse<CC>, dim3(blocks), dim3(512), smem, st, a);              \
+    break;                                                                                   \
+  }
   switch (w.C) {
-    case 64: hipLaunchKernelGGL(k_sum_sparse<64>, dim3(blocks), dim3(512), 0, st, a); break;
-    case 128: hipLaunchKernelGGL(k_sum_sparse<128>, dim3(blocks), dim3(512), 0, st, a); break;
-    case 256: hipLaunchKernelGGL(k_sum_sparse<256>, dim3(blocks), dim3(512), 0, st, a); break;
+    FM_SPARSE_CASE(64)
+    FM_SPARSE_CASE(128)
+    FM_SPARSE_CASE(256)
     default: return hipErrorInvalidValue;
   }
+#undef FM_SPARSE_CASE
   return hipGetLastError();
 }
 

@@ -16,31 +16,33 @@ __device__ __forceinline__ float ord_decode(unsigned c) {      // c == 0 (nothin
   return __uint_as_float((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c);
 }
 
-// Error of the single-plane (float16 hi x hi) product against the exact one, in similarity units:
-//   |fl16(a).fl16(b) - a.b| <= 2^-10 (1+2^-12) |a||b| for normal halves, + 2^-25 per operand below the half
-//   normal range  =>  E = (2^-10 * 1.01 * |a| * max|b| + 2^-24 sqrt(C) (|a| + max|b|)) / (C T)  (+ 1e-6 slack).
-// `nrm` = |a_i| (this row / column), `om` = largest descriptor norm of the OTHER image.
-__device__ __forceinline__ float f16_product_margin(float nrm, float om, float inv_ct, float sqrt_c) {
+// Error of the int8 screening product against the exact one (raw dot-product units).  With a = sigma_a q_a + da,
+// |da_k| <= sigma_a / 2 (k_prep_split: q = rint(a / sigma), sigma = block max / 127) and likewise for b:
+//   a.b - sigma_a sigma_b (q_a.q_b) = da.b + (a - da).db
+//   |...| <= (sigma_a / 2) ||b||_1 + (sigma_b / 2) (||a||_1 + C sigma_a / 2).
+// The factor 1.0001 covers the float roundings of x / sigma, of sigma_a sigma_b and of the scaled accumulator
+// (each ~1e-7 relative against terms of the same form).  Pass block / image maxima of sigma and of the L1 norms to
+// bound a whole row, unit or pair.
+__device__ __forceinline__ float q8_margin_raw(float sig_a, float l1_a, float sig_b, float l1_b, float cpad) {
 #pragma clang fp contract(off)
-  return (9.8633e-4f * nrm * om + 5.9605e-8f * sqrt_c * (nrm + om)) * inv_ct + 1e-6f;
+  return (0.5f * sig_a * l1_b + 0.5f * sig_b * (l1_a + 0.5f * cpad * sig_a)) * 1.0001f;
 }
 
-// -stabiliser * log2(e) of a row / column whose largest f16 product is `raw` (network/utils/
-// coarse_matching_new.py:64-68: sim = raw / (C T)).  The stabiliser is the LOWER bound m^ = max~ - E of the
-// true maximum: every s - m^ <= 2E (no overflow in exp2) and conf > thr => softmax > thr => s - m^ > ln thr,
-// the screening test of the sum kernels.
-__device__ __forceinline__ float neg_stabiliser_log2(float raw, float nrm, float om, float inv_ct, float sqrt_c) {
+// -stabiliser * log2(e) of a row / column whose largest screening product is `raw`, E = its margin in raw units
+// (network/utils/coarse_matching_new.py:64-68: sim = raw / (C T)).  The stabiliser is the LOWER bound
+// m^ = (max~ - E) / (C T) of the true maximum: every s - m^ <= 2E/(C T) (no overflow in exp2) and
+// conf > thr => softmax > thr => s - m^ > ln thr, the screening test of the sum kernels.
+__device__ __forceinline__ float neg_stabiliser_log2(float raw, float margin_raw, float inv_ct) {
 #pragma clang fp contract(off)
-  const float e = f16_product_margin(nrm, om, inv_ct, sqrt_c);
-  const float mhat = raw * inv_ct - e;
+  const float mhat = (raw - margin_raw) * inv_ct - 1e-6f;
   return -mhat * kLog2e;
 }
 
-// log2-domain bound of k * |f16 product - exact product| over the whole pair (own / om = largest norms of the
-// two images): turns an f16 product into an upper bound of the exact similarity.
-__device__ __forceinline__ float pair_margin_log2(float own, float om, float inv_ct, float sqrt_c) {
+// log2-domain bound of k * |screening product - exact product| from a raw margin: turns a screening product into
+// an upper bound of the exact similarity.
+__device__ __forceinline__ float margin_log2(float margin_raw, float inv_ct) {
 #pragma clang fp contract(off)
-  return f16_product_margin(own, om, inv_ct, sqrt_c) * kLog2e + 1e-3f;
+  return margin_raw * inv_ct * kLog2e + 1e-3f;
 }
 
 }  // namespace fm

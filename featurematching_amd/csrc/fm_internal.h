@@ -13,7 +13,7 @@ constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup o
 constexpr int kColParts = 1;         // column partials per 256-row panel (the 8 waves' partials are folded in LDS)
 constexpr int kTieCap = 1023;        // listed tie losers per image; beyond it the gathers scan the match list
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
-constexpr int kUnitsPerSplit = 16; // 32-column units one workgroup of the sparse sum kernel covers at most
+constexpr int kUnitsPerSplit = 64; // 32-column units one workgroup of the sparse sum kernel covers at most (64-bit live mask)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kSkipLog2 = 32.f;    // terms more than 2^32 below every stabiliser are negligible (see coarse_sum_sparse.hip)
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
@@ -31,7 +31,10 @@ struct CoarseWs {
   int splits0;                                // column splits of the max pass (its own grid size)
   int splits_s, units_s;                      // sparse sum kernel: column splits and 32-column units per split
   // zeroed on every call (contiguous, starts at the base)
-  size_t zero_begin, cand_count, colbest, scalars, zero_end;
+  size_t zero_begin, cand_count, cand_count_b, colbest, dense_cnt, scalars, zero_end;
+                                              // cand_count / cand_count_b: candidates per row found by the sparse /
+                                              // the dense sum kernel; dense_cnt [N]: units of a sample the sparse
+                                              // kernel left to the dense one (> 0: the dense kernel redoes the sample)
   size_t cell0, cell1;                        // (zeroed) match index + 1 of every image-0 / image-1 cell
   size_t ties0, ties1;                        // (zeroed) [0] = count, [1..kTieCap] = matches that lost their cell to an
                                               // exactly tied match (the cell-ordered gathers pick them up)
@@ -41,7 +44,9 @@ struct CoarseWs {
   // float16 planes
   size_t hi0, lo0, hi1, lo1;
   // per-row / per-column statistics
-  size_t norm0, norm1, bmax0, bmax1;          // descriptor norms, largest norm per 32-row prep block
+  size_t q0, q1;                              // int8 screening planes
+  size_t sig0, sig1, bsig0, bsig1;            // quantisation step per descriptor, largest step per 32-row block
+  size_t l1_0, l1_1, bl1_0, bl1_1;            // L1 norm per descriptor, largest L1 norm per 32-row block
   size_t emarg;                               // [N] log2-domain bound of k * |f16 product - exact product|
   size_t rowS, colS;                          // partial sum-exp of the sparse sum kernel: rows [N][splits_s][Lp],
                                               // columns [N][panels][Sp]
@@ -51,8 +56,8 @@ struct CoarseWs {
   size_t rsum, csum;                          // softmax denominators per row / column
   size_t nmr2, nmc2;                          // nmr - log2(rsum), nmc - log2(csum): log-softmax offsets
   size_t umax;                                // unit maxima [N][Lp/32][Sp/32] of the max pass
-  size_t dense_map;                           // [N][Lp/32][Sp/32] float 0/1: unit left to the dense sum kernel
-  size_t cand_j, cand_conf, rowbest;          // candidate columns, exact conf, best conf per row
+  size_t cand_j, cand_conf, rowbest;          // candidate columns, exact conf, best conf per row (sparse kernel's set)
+  size_t cand_j_b, cand_conf_b;               // ... the dense kernel's set (used for the samples it redid)
   size_t total;
 };
 
@@ -69,6 +74,7 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
 hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
                        hipStream_t st);
+hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st);
 hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st,
                        float* conf = nullptr);
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);

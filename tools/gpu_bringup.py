@@ -19,9 +19,9 @@ sys.path.insert(0, ROOT)
 from featurematching_amd import _lib, ops, synth  # noqa: E402
 from oracle import matcher_ref as orc  # noqa: E402  (checker only)
 
-NAMES = ["cand_count", "colbest", "scalars", "blocktot", "hi0", "lo0", "hi1", "lo1", "norm0", "norm1", "bmax0",
-         "bmax1", "rowS", "colS", "rowB", "colB", "nmr", "nmc", "rsum", "csum", "cand_j", "cand_conf", "rowbest",
-         "umax", "dense_map", "rowmax_u", "colmax_u", "splits_s", "units_s", "total"]
+NAMES = ["cand_count", "colbest", "scalars", "blocktot", "hi0", "lo0", "hi1", "lo1", "q0", "q1", "sig0",
+         "sig1", "rowS", "colS", "rowB", "colB", "nmr", "nmc", "rsum", "csum", "cand_j", "cand_conf", "rowbest",
+         "umax", "dense_cnt", "rowmax_u", "colmax_u", "splits_s", "units_s", "total"]
 
 
 def layout(n, l, s, c, slots):
@@ -76,10 +76,19 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     print(f"   planes: hi err {e_hi:.2e}  hi+lo recon err {rec:.2e}/{rec1:.2e}  pad max {pad}")
     ok &= e_hi == 0 and rec < 1e-5 and pad == 0
 
-    norm0 = view(ws, base, lay["norm0"], n * Lp, torch.float32).reshape(n, Lp)
-    ok_n = np.allclose(norm0[:, :l], np.linalg.norm(f0, axis=2), rtol=1e-5)
-    print("   norms ok:", ok_n)
-    ok &= ok_n
+    def unfrag8(a, rows_pad):           # int8 planes: [rowblock][ks][h][r][16]
+        ks8 = cp // 32
+        a = a.reshape(n * rows_pad // 32, ks8, 2, 32, 16).transpose(0, 3, 2, 1, 4)      # rb, r, h, ks, e
+        return a.reshape(n, rows_pad, cp)[:, :, :c]
+
+    q0 = unfrag8(view(ws, base, lay["q0"], n * Lp * cp, torch.int8), Lp).astype(np.float64)
+    q1 = unfrag8(view(ws, base, lay["q1"], n * Sp * cp, torch.int8), Sp).astype(np.float64)
+    sig0 = view(ws, base, lay["sig0"], n * Lp, torch.float32).reshape(n, Lp)
+    sig1 = view(ws, base, lay["sig1"], n * Sp, torch.float32).reshape(n, Sp)
+    eq0 = (np.abs(q0[:, :l] * sig0[:, :l, None] - f0) / np.maximum(sig0[:, :l, None], 1e-30)).max()
+    eq1 = (np.abs(q1[:, :s] * sig1[:, :s, None] - f1) / np.maximum(sig1[:, :s, None], 1e-30)).max()
+    print(f"   int8 planes: |x - sigma q| / sigma max {eq0:.4f} / {eq1:.4f} (must be <= 0.5); |q| max {np.abs(q0).max():.0f}")
+    ok &= eq0 <= 0.5001 and eq1 <= 0.5001
 
     def ord_decode(u):                  # fm_device.h: order-preserving uint code -> float (0 = nothing recorded)
         u = u.astype(np.uint32)
@@ -96,16 +105,25 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     rsum = view(ws, base, lay["rowS"], n * splits_s * Lp, torch.float32).reshape(n, splits_s, Lp).sum(1)
     csum = view(ws, base, lay["colS"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
     scal = view(ws, base, lay["scalars"], 3, torch.int32)
-    dmap = view(ws, base, lay["dense_map"], n * (Lp // 32) * (Sp // 32), torch.float32)
-    print(f"   scalars: flags={scal[0]} dense_units={scal[1]} (dense_map sum {int(dmap.sum())}); sparse splits {splits_s} x {lay['units_s']} units")
-    if scal[1] > 0:                     # the dense sum kernel had units of its own
-        rsum = rsum + view(ws, base, lay["rowB"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).sum(1)
-        csum = csum + view(ws, base, lay["colB"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
-    ccount = view(ws, base, lay["cand_count"], n * Lp, torch.int32).reshape(n, Lp)
-    cand_j = view(ws, base, lay["cand_j"], n * Lp * slots, torch.int32).reshape(n, Lp, slots)
+    dcnt = view(ws, base, lay["dense_cnt"], n, torch.int32)
+    print(f"   scalars: flags={scal[0]} dense_units={scal[1]} per sample {dcnt.tolist()}; sparse splits {splits_s} x {lay['units_s']} units")
+    rB = view(ws, base, lay["rowB"], n * splits * Lp, torch.float32).reshape(n, splits, Lp).sum(1)
+    cB = view(ws, base, lay["colB"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
+    for bb in range(n):                 # the dense sum kernel redid the samples with flagged units
+        if dcnt[bb] > 0:
+            rsum[bb], csum[bb] = rB[bb], cB[bb]
+    ccount = view(ws, base, lay["cand_count"], n * Lp, torch.int32).reshape(n, Lp).copy()
+    cand_j = view(ws, base, lay["cand_j"], n * Lp * slots, torch.int32).reshape(n, Lp, slots).copy()
+    o_b = lay["cand_j"] + (lay["rowbest"] - lay["cand_conf"]) + n * Lp * 4        # cand_j_b follows rowbest
+    o_b = (o_b + 255) // 256 * 256
+    cnt_b = view(ws, base, lay["cand_count"] + (n * Lp * 4 + 255) // 256 * 256, n * Lp, torch.int32).reshape(n, Lp)
+    cj_b = view(ws, base, lay["rowbest"] + (n * Lp * 4 + 255) // 256 * 256, n * Lp * slots, torch.int32).reshape(n, Lp, slots)
+    for bb in range(n):
+        if dcnt[bb] > 0:
+            ccount[bb], cand_j[bb] = cnt_b[bb], cj_b[bb]
     log2e = 1.4426950408889634
     for b in range(n):
-        dot_hi = hi0[b, :l].astype(np.float64) @ hi1[b, :s].astype(np.float64).T
+        dot_hi = (q0[b, :l] * sig0[b, :l, None]) @ (q1[b, :s] * sig1[b, :s, None]).T      # the screening product
         dot = f0[b].astype(np.float64) @ f1[b].astype(np.float64).T
         sim = dot * inv_ct
         ea = np.abs(rowA[b, :l] - dot_hi.max(1)).max() / max(1.0, np.abs(dot_hi).max())
