@@ -4,9 +4,10 @@ Every pair is independent in all three stages, so ranks take cont
 pairs and nothing is exchanged on the data path.  The only collective is the gather of the
 resulting match lists: one all-gather of the per-rank counts and one all-gather of records padded
 to the largest count - the pad-to-largest scheme of the reference's utils/comm.py:113-176, but
-with raw float32 records over RCCL (backend "nccl" on ROCm) instead of pickles over gloo.
+with raw 24-byte records over RCCL (backend "nccl" on ROCm) instead of pickles over gloo.
 
-Record = [pair_id, x0, y0, x1, y1, conf] float32 (pair ids are exact in float32 up to 2**24).
+Record (little-endian, 24 bytes) = {int32 pair_id, float32 x0, y0, x1, y1, conf}; a list of
+records is an int32 tensor [M, 6] whose columns 1..5 hold the float bits.
 """
 from __future__ import annotations
 
@@ -27,13 +28,15 @@ def shard_range(num_pairs: int, rank: int, world: int) -> Tuple[int, int]:
 
 def pack_records(b_ids: torch.Tensor, kpts0: torch.Tensor, kpts1: torch.Tensor, conf: torch.Tensor,
                  pair_offset: int = 0) -> torch.Tensor:
-    """[M, 6] float32 records; local batch ids become global pair ids."""
+    """[M, 6] int32 records {pair_id, bits(x0, y0, x1, y1, conf)}; local batch ids become global pair ids."""
     m = b_ids.shape[0]
-    rec = torch.empty(m, RECORD, dtype=torch.float32, device=conf.device)
-    rec[:, 0] = (b_ids + pair_offset).to(torch.float32)
-    rec[:, 1:3] = kpts0[:, :2]
-    rec[:, 3:5] = kpts1[:, :2]
-    rec[:, 5] = conf
+    rec = torch.empty(m, RECORD, dtype=torch.int32, device=conf.device)
+    rec[:, 0] = (b_ids + pair_offset).to(torch.int32)
+    f = rec[:, 1:].view(torch.float32) if m else rec[:, 1:]
+    if m:
+        f[:, 0:2] = kpts0[:, :2].float()
+        f[:, 2:4] = kpts1[:, :2].float()
+        f[:, 4] = conf.float()
     return rec
 
 
@@ -51,7 +54,7 @@ def gather_match_lists(records: torch.Tensor, group=None) -> torch.Tensor:
     dist.all_gather(counts, count, group=group)
     counts = [int(c.item()) for c in counts]
     cap = max(counts)
-    padded = torch.zeros(cap, RECORD, dtype=torch.float32, device=dev)
+    padded = torch.zeros(cap, RECORD, dtype=torch.int32, device=dev)
     padded[:records.shape[0]] = records
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
@@ -60,4 +63,5 @@ def gather_match_lists(records: torch.Tensor, group=None) -> torch.Tensor:
 
 def unpack_records(rec: torch.Tensor):
     """-> (pair_ids int64 [M], kpts0 [M,2], kpts1 [M,2], conf [M])"""
-    return rec[:, 0].round().to(torch.int64), rec[:, 1:3], rec[:, 3:5], rec[:, 5]
+    f = rec[:, 1:].contiguous().view(torch.float32)
+    return rec[:, 0].to(torch.int64), f[:, 0:2], f[:, 2:4], f[:, 4]

@@ -58,6 +58,42 @@ def test_gather_equals_single_process(tmp_path, world, num_pairs):
     assert np.all(np.diff(ids.numpy()) >= 0)             # rank-major == pair order
 
 
+def _recorded():
+    """Match lists the HIP path produced on an MI355X for 4 pairs of config #1 (tools/record_hip_matches.py)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hip_matches_cfg1x4.npz"))
+    return (torch.as_tensor(z["b_ids"]).long(), torch.as_tensor(z["kpts0"]), torch.as_tensor(z["kpts1"]),
+            torch.as_tensor(z["mconf"]))
+
+
+def _worker_recorded(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, k0, k1, c = _recorded()
+    lo, hi = fdist.shard_range(4, rank, world)
+    mine = (b >= lo) & (b < hi)                       # this rank's block of pairs, local batch ids from 0
+    rec = fdist.pack_records(b[mine] - lo, k0[mine], k1[mine], c[mine], pair_offset=lo)
+    torch.save(fdist.gather_match_lists(rec), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_of_recorded_hip_outputs(tmp_path):
+    """cfg#4's exchange on real outputs: two ranks each hold the HIP match lists of their two pairs; after
+    pack -> all-gather -> unpack every rank holds the single-process list, bit for bit and in pair order."""
+    port = _free_port()
+    mp.spawn(_worker_recorded, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    b, k0, k1, c = _recorded()
+    assert b.shape[0] > 100 and sorted(set(b.tolist())) == [0, 1, 2, 3]
+    ref = fdist.pack_records(b, k0, k1, c, 0)
+    assert ref.dtype == torch.int32 and ref.shape[1] * 4 == 24          # 24-byte records, int32 pair id
+    for r in range(2):
+        got = torch.load(os.path.join(tmp_path, f"rank{r}.pt"))
+        assert torch.equal(got, ref), f"rank {r}"
+        ids, g0, g1, gc = fdist.unpack_records(got)
+        assert torch.equal(ids, b) and torch.equal(g0, k0) and torch.equal(g1, k1) and torch.equal(gc, c)
+
+
 def test_shard_ranges_partition_the_batch():
     for n in (1, 7, 64, 512):
         for w in (1, 2, 3, 8):
