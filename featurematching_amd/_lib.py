@@ -10,8 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FMATCH_LIB lets the tuning tools load an experimental build (same ABI) of the library
-LIB_PATH = os.environ.get("FMATCH_LIB") or os.path.join(_HERE, "lib", "libfmatch_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libfmatch_hip.so")
 
 FM_OK = 0
 FM_E_CAPACITY = -5
@@ -56,22 +55,27 @@ class FMatchError(RuntimeError):
         super().__init__(f"{where}: {msg} (status {status})")
 
 
-def load():
-    """Load (once) and return the ctypes handle.  torch must already be imported by the
-    caller so that the HIP runtime the library binds to is the one torch uses."""
+def load(path=None):
+    """Load (once) and return the ctypes handle of featurematching_amd/lib/libfmatch_hip.so.  `path` is for the
+    tuning tools under tools/ only: they may load an experimental build of the same ABI BEFORE anything else has
+    loaded the library (no environment variable can redirect the product's loader).  torch must already be imported
+    by the caller so that the HIP runtime the library binds to is the one torch uses."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        lib_path = path or LIB_PATH
+        if not os.path.exists(lib_path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP library is the product and has no fallback. "
+                f"{lib_path} is missing: the HIP library is the product and has no fallback. "
                 "Build it with `make -C featurematching_amd/csrc` (hipcc, --offload-arch=gfx950).")
         import torch  # noqa: F401  (loads torch's libamdhip64 first; same soname is then reused)
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(lib_path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+    elif path is not None and os.path.abspath(path) != os.path.abspath(getattr(_lib, '_name', '')):
+        raise RuntimeError("the library is already loaded; load an experimental build before any other use")
     return _lib
 
 

@@ -121,12 +121,24 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     return out
 
 
+# Shapes / thresholds whose candidate screening overflowed once start later calls with the exact screening pass
+# switched on (flat similarity rows - an untrained network, a tiny thr - would otherwise pay for the coarse stage
+# twice on every forward).
+_NEEDS_EXACT_SCREENING = set()
+
+
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
-                 scale0=None, scale1=None, conf_matrix: bool = False) -> dict:
+                 scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None) -> dict:
     """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
     N*min(L,S)), with the exact screening pass, then with more candidate slots when the device reports
-    the corresponding overflow."""
-    kw = dict(cap=None, cand_slots=None, exact_screening=False)
+    the corresponding overflow.  exact_screening=None: on when conf_matrix is requested (that path already runs
+    the denominator reduction the exact screening needs, and it is the training / untrained-network mode in which
+    flat rows occur) or when this shape needed it before."""
+    lib = _lib.load()
+    key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
+    if exact_screening is None:
+        exact_screening = bool(conf_matrix) or key in _NEEDS_EXACT_SCREENING
+    kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening))
     for _ in range(6):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
                                  scale0, scale1, conf_matrix=conf_matrix, **kw)
@@ -138,10 +150,10 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
                 continue
             if e.status == _lib.FM_E_CANDIDATES and not kw['exact_screening']:
                 kw['exact_screening'] = True
+                _NEEDS_EXACT_SCREENING.add(key)
                 continue
-            if e.status == _lib.FM_E_CANDIDATES and (kw['cand_slots'] or 8) < 64:
-                base = kw['cand_slots'] or _lib.load().fm_default_cand_slots(float(thr))
-                kw['cand_slots'] = min(64, base * 2)
+            if e.status == _lib.FM_E_CANDIDATES and kw['cand_slots'] < 64:
+                kw['cand_slots'] = min(64, kw['cand_slots'] * 2)
                 continue
             raise
         out = buf.sliced(m)

@@ -1,0 +1,158 @@
+/*
+ * Host-side driver for the C ABI of libfmatch_hip.so (include/fmatch.h): a plain C caller, as the reference's
+ * maintainer would write one behind net.forward (network/net.py:75-83).  It dlopens the library, resolves every
+ * entry point the header declares and walks the argument checks - every status < 0 in fm_status that is decided on
+ * the host - without enqueueing any device work (it runs on a machine without a GPU).  Built with
+ * -fsanitize=address against a library whose host objects are instrumented too (make -C featurematching_amd/csrc
+ * asan): a stray read or write in the validation / workspace-layout code aborts the run.
+ *
+ *     abi_driver /path/to/libfmatch_hip_asan.so
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fmatch.h"
+
+static int checks = 0, failures = 0;
+#define EXPECT(expr, want)                                                                  \
+  do {                                                                                      \
+    const int got_ = (expr);                                                                \
+    ++checks;                                                                               \
+    if (got_ != (want)) { ++failures; fprintf(stderr, "%s:%d: %s = %d, want %d\n", __FILE__, __LINE__, #expr, got_, (int)(want)); } \
+  } while (0)
+
+#define RESOLVE(name) do { *(void**)(&p_##name) = dlsym(h, #name); if (!p_##name) { fprintf(stderr, "missing symbol %s\n", #name); return 2; } } while (0)
+
+static __typeof__(fm_version)* p_fm_version;
+static __typeof__(fm_strerror)* p_fm_strerror;
+static __typeof__(fm_default_cand_slots)* p_fm_default_cand_slots;
+static __typeof__(fm_coarse_workspace_bytes)* p_fm_coarse_workspace_bytes;
+static __typeof__(fm_coarse_match)* p_fm_coarse_match;
+static __typeof__(fm_debug_coarse_layout)* p_fm_debug_coarse_layout;
+static __typeof__(fm_debug_launch_corr)* p_fm_debug_launch_corr;
+static __typeof__(fm_debug_launch_sum_sparse)* p_fm_debug_launch_sum_sparse;
+static __typeof__(fm_debug_reset_counters)* p_fm_debug_reset_counters;
+static __typeof__(fm_read_count)* p_fm_read_count;
+static __typeof__(fm_gather_windows)* p_fm_gather_windows;
+static __typeof__(fm_coarse_cell_maps)* p_fm_coarse_cell_maps;
+static __typeof__(fm_gather_windows_cells)* p_fm_gather_windows_cells;
+static __typeof__(fm_merge_pack_weights)* p_fm_merge_pack_weights;
+static __typeof__(fm_gather_merge_windows)* p_fm_gather_merge_windows;
+static __typeof__(fm_gather_windows_pair)* p_fm_gather_windows_pair;
+static __typeof__(fm_fine_match)* p_fm_fine_match;
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s libfmatch_hip.so\n", argv[0]); return 2; }
+  void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+  if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+  RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes);
+  RESOLVE(fm_coarse_match); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
+  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
+  RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
+  RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
+  RESOLVE(fm_fine_match);
+
+  EXPECT(p_fm_version(), FM_VERSION);
+  for (int s = FM_E_RANGE; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
+  EXPECT(strcmp(p_fm_strerror(-99), "unknown fmatch status"), 0);
+  EXPECT(p_fm_default_cand_slots(0.2f), 8);
+  EXPECT(p_fm_default_cand_slots(0.0f), 64);
+
+  /* workspace query: every shape / configuration refusal */
+  size_t bytes = 0;
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, &bytes), FM_OK);
+  EXPECT(bytes > 10u * 1000 * 1000 && bytes < 80u * 1000 * 1000, 1);
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, NULL), FM_E_NULL);
+  EXPECT(p_fm_coarse_workspace_bytes(0, 4800, 4800, 256, 8, &bytes), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_workspace_bytes(1, -1, 4800, 256, 8, &bytes), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 0, 256, 8, &bytes), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 258, 8, &bytes), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 512, 8, &bytes), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 256, 2, &bytes), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 256, 12, &bytes), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 256, 128, &bytes), FM_E_UNSUPPORTED);
+  /* ragged / small / large shapes walk the layout arithmetic under the sanitizer */
+  for (int n = 1; n <= 64; n *= 4)
+    for (int l = 1; l <= 16384; l = l * 3 + 5)
+      for (int c = 4; c <= 256; c += 84) EXPECT(p_fm_coarse_workspace_bytes(n, l, 2 * l + 1, c, 8, &bytes), FM_OK);
+  int64_t lay[40];
+  EXPECT(p_fm_debug_coarse_layout(1, 4800, 4800, 256, 8, lay, 40), FM_OK);
+  EXPECT(lay[39] > 0 && lay[4] == 4864 && lay[5] == 4800, 1);
+  EXPECT(p_fm_debug_coarse_layout(1, 4800, 4800, 256, 8, lay, 39), FM_E_SHAPE);
+  EXPECT(p_fm_debug_coarse_layout(1, 4800, 4800, 256, 8, NULL, 40), FM_E_NULL);
+  EXPECT(p_fm_debug_coarse_layout(0, 4800, 4800, 256, 8, lay, 40), FM_E_SHAPE);
+  EXPECT(p_fm_debug_coarse_layout(1, 4800, 4800, 256, 3, lay, 40), FM_E_UNSUPPORTED);
+
+  /* coarse stage: refused before any device work */
+  void* one = (void*)(uintptr_t)256;     /* a non-NULL, 256-byte aligned address that is never dereferenced */
+  void* odd = (void*)(uintptr_t)264;
+  int32_t* cnt = (int32_t*)one;
+  EXPECT(p_fm_coarse_match(NULL, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_NULL);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, NULL, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_NULL);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, NULL, NULL, NULL), FM_E_NULL);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, NULL, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_NULL);
+  EXPECT(p_fm_coarse_match(one, one, 1, 63, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 7, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, -1, cnt, NULL, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 62, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.0f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 1.0f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.0f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 5, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 16, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, odd, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
+  int32_t m = 0;
+  EXPECT(p_fm_read_count(NULL, 4, &m, NULL), FM_E_NULL);
+  EXPECT(p_fm_read_count(cnt, 4, NULL, NULL), FM_E_NULL);
+  int32_t *c0, *c1, *t0, *t1; int q0, q1;
+  EXPECT(p_fm_coarse_cell_maps(NULL, 1, 64, 64, 64, 8, &c0, &q0, &t0, &c1, &q1, &t1), FM_E_NULL);
+  EXPECT(p_fm_coarse_cell_maps(one, 1, 64, 64, 64, 8, &c0, &q0, &t0, &c1, NULL, &t1), FM_E_NULL);
+  EXPECT(p_fm_coarse_cell_maps(one, 0, 64, 64, 64, 8, &c0, &q0, &t0, &c1, &q1, &t1), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_cell_maps(one, 1, 64, 64, 64, 6, &c0, &q0, &t0, &c1, &q1, &t1), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_cell_maps(one, 1, 64, 64, 64, 8, &c0, &q0, &t0, &c1, &q1, &t1), FM_OK);
+  EXPECT(q0 == 256 && q1 == 64 && c0 != NULL && t1 != NULL, 1);
+  EXPECT(p_fm_debug_launch_corr(NULL, 1, 64, 64, 64, 8, 0.1f, 0.2f, 1, NULL), FM_E_NULL);
+  EXPECT(p_fm_debug_launch_corr(one, 1, 64, 64, 64, 8, 0.1f, 0.2f, 9, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_debug_launch_corr(one, 0, 64, 64, 64, 8, 0.1f, 0.2f, 1, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_debug_launch_sum_sparse(one, NULL, one, 1, 64, 64, 64, 8, 0.1f, 0.2f, NULL), FM_E_NULL);
+  EXPECT(p_fm_debug_launch_sum_sparse(one, one, one, 1, 64, 64, 64, 16 + 1, 0.1f, 0.2f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_debug_reset_counters(NULL, 1, 64, 64, 64, 8, NULL), FM_E_NULL);
+  EXPECT(p_fm_debug_reset_counters(one, 1, 64, 0, 64, 8, NULL), FM_E_SHAPE);
+
+  /* window crop / fine stage */
+  float* f = (float*)one; int64_t* ids = (int64_t*)one;
+  EXPECT(p_fm_gather_windows(NULL, 1, 64, 8, 8, 0, 7, 4, 2, 2, NULL, NULL, NULL, 0, NULL, NULL), FM_OK);          /* M == 0 */
+  EXPECT(p_fm_gather_windows(NULL, 1, 64, 8, 8, 0, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_gather_windows(f, 1, 64, 8, 8, 0, 7, 4, 2, 2, ids, ids, NULL, -4, f, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_gather_windows(f, 1, 64, 0, 8, 0, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_gather_windows(f, 1, 64, 8, 8, 2, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_UNSUPPORTED);      /* layout */
+  EXPECT(p_fm_gather_windows(f, 1, 64, 8, 8, 0, 17, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_UNSUPPORTED);     /* W > 15 */
+  EXPECT(p_fm_gather_windows(f, 1, 62, 8, 8, 1, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_UNSUPPORTED);      /* NHWC, Cf % 4 */
+  int32_t* map = (int32_t*)one;
+  EXPECT(p_fm_gather_windows_cells(NULL, 1, 64, 8, 8, 7, 4, 2, 2, 2, NULL, 4, NULL, NULL, NULL, NULL, 0, NULL, NULL), FM_OK);
+  EXPECT(p_fm_gather_windows_cells(f, 1, 64, 8, 8, 7, 4, 2, 2, 2, NULL, 4, map, ids, ids, NULL, 3, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_gather_windows_cells(f, 1, 64, 8, 8, 7, 4, 2, 2, 2, map, 3, map, ids, ids, NULL, 3, f, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_gather_windows_cells(f, 1, 32, 8, 8, 7, 4, 2, 2, 2, map, 4, map, ids, ids, NULL, 3, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_gather_windows_cells(f, 1, 64, 8, 8, 6, 4, 2, 2, 2, map, 4, map, ids, ids, NULL, 3, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_merge_pack_weights(NULL, 64, one, NULL), FM_E_NULL);
+  EXPECT(p_fm_merge_pack_weights(f, 32, one, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_gather_merge_windows(NULL, 1, 64, 8, 8, 7, 4, 2, 2, 2, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL, NULL), FM_OK);
+  EXPECT(p_fm_gather_merge_windows(f, 1, 64, 8, 8, 7, 4, 2, 2, 2, NULL, 0, NULL, NULL, f, ids, ids, NULL, 3, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_gather_merge_windows(f, 1, 64, 8, 8, 7, 4, 2, 2, 2, map, 4, NULL, one, f, ids, ids, NULL, 3, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_gather_merge_windows(f, 1, 64, 8, 8, 9, 4, 2, 2, 2, NULL, 0, NULL, one, f, ids, ids, NULL, 3, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_gather_windows_pair(f, f, 1, 64, 8, 8, 8, 8, 7, 4, 2, 2, 2, 2, 2, map, 4, map, map, 4, map, NULL, NULL, NULL, ids, ids, ids, NULL, 0, f, f, NULL), FM_OK);
+  EXPECT(p_fm_gather_windows_pair(f, NULL, 1, 64, 8, 8, 8, 8, 7, 4, 2, 2, 2, 2, 2, map, 4, map, map, 4, map, NULL, NULL, NULL, ids, ids, ids, NULL, 3, f, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_gather_windows_pair(f, f, 1, 64, 8, 8, 8, 8, 7, 4, 2, 2, 2, 2, 2, map, 3, map, map, 4, map, NULL, NULL, NULL, ids, ids, ids, NULL, 3, f, f, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_gather_windows_pair(f, f, 1, 32, 8, 8, 8, 8, 7, 4, 2, 2, 2, 2, 2, map, 4, map, map, 4, map, NULL, NULL, NULL, ids, ids, ids, NULL, 3, f, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_fine_match(NULL, NULL, 0, NULL, 49, 64, NULL, NULL, NULL, NULL, 2.f, NULL, NULL, NULL), FM_OK);
+  EXPECT(p_fm_fine_match(NULL, f, 3, NULL, 49, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_fine_match(f, f, -3, NULL, 49, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_fine_match(f, f, 3, NULL, 36, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_fine_match(f, f, 3, NULL, 49, 32, f, f, f, f, 2.f, f, f, NULL), FM_E_UNSUPPORTED);
+
+  printf("abi_driver: %d checks, %d failures\n", checks, failures);
+  return failures ? 1 : 0;
+}

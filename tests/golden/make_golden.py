@@ -215,10 +215,77 @@ def kat_cases():
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **cases)
 
 
+def kat_cases_round2():
+    """Round-2 known-answer cases (kats_r2.npz): a per-sample scale0/scale1 case with many matches, and a pair
+    of cases whose only difference is ONE float32 ulp of one descriptor's scale, chosen by bisection on the
+    REFERENCE's own output so that one entry's conf lands just below / just above thr (:99 `conf > thr`)."""
+    cases = {}
+
+    def add(name, f0, f1, hw0_i, hw1_i, hw0_c, hw1_c, cfg=None, scale0=None, scale1=None, extra=None):
+        data = ref_coarse(f0, f1, hw0_i, hw1_i, hw0_c, hw1_c, cfg, scale0, scale1)
+        d = pack_coarse(data)
+        d.update(f0=f0.astype(np.float32), f1=f1.astype(np.float32),
+                 hw=np.array([*hw0_i, *hw1_i, *hw0_c, *hw1_c], np.int64),
+                 cfg=np.array([(cfg or {}).get('thr', 0.2), (cfg or {}).get('border_rm', 2),
+                               (cfg or {}).get('dsmax_temperature', 0.1)], np.float64))
+        if scale0 is not None:
+            d.update(scale0=np.asarray(scale0, np.float32), scale1=np.asarray(scale1, np.float32))
+        d.update(extra or {})
+        for k, v in d.items():
+            cases[f"{name}/{k}"] = v
+        print(f"kat {name}: M={d['i_ids'].shape[0]}")
+        return data
+
+    # per-sample scales, rectangular maps, L != S, M >= 50
+    f0 = 3.0 * synth.normal(21, 1, (2, 12 * 16, 64))
+    f1 = np.concatenate([f0[:, synth.permutation(21, 3, 192)], 3.0 * synth.normal(21, 7, (2, 18, 64))], 1)
+    f1 += 0.3 * synth.normal(21, 2, f1.shape)
+    s0 = np.array([[1.0, 1.5], [2.0, 0.5]], np.float32); s1 = np.array([[0.75, 1.25], [1.0, 3.0]], np.float32)
+    add("scale_big", f0, f1, (96, 128), (120, 112), (12, 16), (15, 14), scale0=s0, scale1=s1)
+
+    # conf straddling thr by one ulp of a descriptor scale
+    f0, f1 = synth.coarse_descriptors(22, 1, 100, 32, "borderline")
+    hw_i, hw_c = (80, 80), (10, 10)
+    base = ref_coarse(f0, f1, hw_i, hw_i, hw_c, hw_c)
+    ii, jj, cc = base['i_ids'].numpy(), base['j_ids'].numpy(), base['mconf'].numpy()
+    pick = int(np.argsort(cc)[len(cc) // 3])             # a mid-confidence interior match
+    i_s, j_s = int(ii[pick]), int(jj[pick])
+    orig = f1[0, j_s].copy()
+
+    def present(alpha):
+        g1 = f1.copy()
+        g1[0, j_s] = (np.float32(alpha) * orig).astype(np.float32)
+        d = ref_coarse(f0, g1, hw_i, hw_i, hw_c, hw_c)
+        hit = (d['i_ids'].numpy() == i_s) & (d['j_ids'].numpy() == j_s)
+        return bool(hit.any()), g1, d
+
+    lo, hi = np.float32(0.0), np.float32(1.0)            # alpha = 0 kills the match, alpha = 1 keeps it
+    assert not present(lo)[0] and present(hi)[0]
+    while np.nextafter(lo, np.float32(2.0), dtype=np.float32) < hi:
+        mid = np.float32((np.float64(lo) + np.float64(hi)) / 2)
+        if present(mid)[0]:
+            hi = mid
+        else:
+            lo = mid
+    _, g_lo, _ = present(lo)
+    _, g_hi, d_hi = present(hi)
+    hit = (d_hi['i_ids'].numpy() == i_s) & (d_hi['j_ids'].numpy() == j_s)
+    conf_hi = float(d_hi['mconf'].numpy()[hit][0])
+    print(f"thr straddle: entry ({i_s},{j_s}) alpha {lo!r} -> absent, {hi!r} -> present with conf {conf_hi!r}")
+    meta = dict(straddle=np.array([i_s, j_s], np.int64), straddle_conf=np.float64(conf_hi))
+    add("thr_below", f0, g_lo, hw_i, hw_i, hw_c, hw_c, extra=meta)
+    add("thr_above", f0, g_hi, hw_i, hw_i, hw_c, hw_c, extra=meta)
+    np.savez_compressed(os.path.join(HERE, "kats_r2.npz"), **cases)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":       # only the round-2 cases (the others are unchanged)
+        kat_cases_round2()
+        sys.exit(0)
     kat_cases()
+    kat_cases_round2()
     full_case("cfg1_peaky", "cfg1", "peaky")
     full_case("cfg1_borderline", "cfg1", "borderline")
     full_case("cfg2_peaky", "cfg2", "peaky")

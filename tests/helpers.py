@@ -12,8 +12,8 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
-def load_kats():
-    z = np.load(os.path.join(GOLDEN, "kats.npz"))
+def load_kats(name="kats"):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
     cases = {}
     for k in z.files:
         case, key = k.split("/", 1)

@@ -50,6 +50,8 @@ def test_workspace_query_and_argument_checks():
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 512, 8, C.byref(n)) == -3     # C > 256
     assert lib.fm_coarse_workspace_bytes(1, 64, 64, 32, 8, C.byref(n)) == 0           # zero-padded to 64
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 7, C.byref(n)) == -3     # slots not a power of 2
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 2, C.byref(n)) == -3     # fewer than 4 slots
+    assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 128, C.byref(n)) == -3   # more than 64
     assert lib.fm_coarse_workspace_bytes(0, 4800, 4800, 256, 8, C.byref(n)) == -2
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, None) == -1
     # NULL / shape checks return before any device work
@@ -79,6 +81,25 @@ def test_workspace_query_and_argument_checks():
     assert lib.fm_merge_pack_weights(one, 32, one, null) == -3
 
 
+def test_debug_entry_points_validate_their_shapes():
+    """The diagnostic entry points make the same N/L/S/C/slots checks as the product ones (a zero N used to reach
+    an integer division on the host)."""
+    lib = _lib.load()
+    one = C.c_void_p(256)
+    arr = (C.c_int64 * 40)()
+    assert lib.fm_debug_coarse_layout(0, 64, 64, 64, 8, arr, 40) == -2
+    assert lib.fm_debug_coarse_layout(1, 64, 64, 66, 8, arr, 40) == -3
+    assert lib.fm_debug_coarse_layout(1, 64, 64, 64, 3, arr, 40) == -3
+    assert lib.fm_debug_coarse_layout(1, 64, 64, 64, 8, arr, 39) == -2
+    assert lib.fm_debug_reset_counters(one, 0, 64, 64, 64, 8, None) == -2
+    assert lib.fm_debug_reset_counters(one, 1, 64, 64, 64, 5, None) == -3
+    assert lib.fm_debug_reset_counters(None, 1, 64, 64, 64, 8, None) == -1
+    assert lib.fm_debug_launch_corr(one, 1, 0, 64, 64, 8, 0.1, 0.2, 1, None) == -2
+    assert lib.fm_debug_launch_corr(one, 1, 64, 64, 64, 8, 0.1, 0.2, 7, None) == -3
+    assert lib.fm_debug_launch_sum_sparse(one, one, one, 1, 64, -1, 64, 8, 0.1, 0.2, None) == -2
+    assert lib.fm_debug_launch_sum_sparse(one, None, one, 1, 64, 64, 64, 8, 0.1, 0.2, None) == -1
+
+
 def test_layout_query_is_consistent():
     lib = _lib.load()
     arr = (C.c_int64 * 40)()
@@ -100,3 +121,21 @@ def test_ops_refuse_cpu_tensors():
     from featurematching_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.coarse_match(torch.zeros(1, 64, 64), torch.zeros(1, 64, 64), (8, 8), (8, 8), 8.0)
+
+
+def test_c_driver_under_address_sanitizer():
+    """tests/c/abi_driver.c - a plain C caller of the ABI - against a build of the library whose HOST code is
+    instrumented with AddressSanitizer (make asan; the device code is untouched, GPU ASan is not available on the
+    pool): every host-decided status < 0 of fmatch.h and the workspace-layout arithmetic over ragged shapes."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "featurematching_amd", "csrc")
+    if not (shutil.which("make") and os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc toolchain on this machine")
+    subprocess.run(["make", "-C", csrc, "asan", "-j6"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+    r = subprocess.run([os.path.join(ROOT, "build", "asan", "abi_driver"),
+                        os.path.join(ROOT, "build", "asan", "libfmatch_hip_asan.so")],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failures" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr

@@ -58,8 +58,14 @@ def test_full_path_against_reference_fixture(name, dist):
     inp = case_inputs(g['meta'], dist)
     out = _run_coarse(inp['f0'], inp['f1'], inp['hw_i'], inp['hw_c'], inp['hw_c'])
     ndiff = _assert_coarse(out, g)
-    if ndiff:
-        pytest.skip(f"{ndiff} guard-band flips: fine outputs not comparable index by index")
+    assert ndiff <= 4, f"{ndiff} guard-band flips"
+    # crop and fine outputs are compared on the matches both sides hold (all of them unless a guard-band flip)
+    gk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))}
+    rk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(g['b_ids'], g['i_ids'], g['j_ids']))}
+    common = [k for k in gk if k in rk]
+    gi = np.array([gk[k] for k in common])
+    ri = np.array([rk[k] for k in common])
+    assert len(common) >= len(rk) - 4
     ff0 = torch.as_tensor(inp['ff0'], device=DEV)
     ff1 = torch.as_tensor(inp['ff1'], device=DEV)
     wc = inp['hw_c'][1]
@@ -67,16 +73,16 @@ def test_full_path_against_reference_fixture(name, dist):
     win1 = ops.gather_windows(ff1, out['b_ids'], out['j_ids'], 7, 4, wc)
     pos = torch.arange(1, 50, dtype=torch.float64, device=DEV).view(1, 49, 1)
     ch = torch.arange(1, 65, dtype=torch.float64, device=DEV).view(1, 1, -1)
-    np.testing.assert_allclose((win0.double() * pos * ch).sum((1, 2)).cpu().numpy(), g['win0_sum'], rtol=1e-12, atol=1e-9)
-    np.testing.assert_allclose((win1.double() * pos * ch).sum((1, 2)).cpu().numpy(), g['win1_sum'], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose((win0.double() * pos * ch).sum((1, 2)).cpu().numpy()[gi], g['win0_sum'][ri], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose((win1.double() * pos * ch).sum((1, 2)).cpu().numpy()[gi], g['win1_sum'][ri], rtol=1e-12, atol=1e-9)
     w0, b0, w1, b1 = inp['mix']
     mix0 = torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=DEV)
     mix1 = torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=DEV)
     k0, k1 = ops.fine_match(win0, win1, mix0, mix1, out['mkpts0_c'], out['mkpts1_c'], inp['hw_i'][0] / inp['hw_f'][0])
-    assert np.abs(k0.cpu().numpy()[:, :2] - g['mkpts0_f'][:, :2]).max() <= FINE_TOL_PX
-    assert np.abs(k1.cpu().numpy()[:, :2] - g['mkpts1_f'][:, :2]).max() <= FINE_TOL_PX
-    np.testing.assert_allclose(k0.cpu().numpy()[:, 2], g['mkpts0_f'][:, 2], atol=1e-4)
-    np.testing.assert_allclose(k1.cpu().numpy()[:, 2], g['mkpts1_f'][:, 2], atol=1e-4)
+    assert np.abs(k0.cpu().numpy()[gi, :2] - g['mkpts0_f'][ri, :2]).max() <= FINE_TOL_PX
+    assert np.abs(k1.cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= FINE_TOL_PX
+    np.testing.assert_allclose(k0.cpu().numpy()[gi, 2], g['mkpts0_f'][ri, 2], atol=1e-4)
+    np.testing.assert_allclose(k1.cpu().numpy()[gi, 2], g['mkpts1_f'][ri, 2], atol=1e-4)
 
 
 def test_cfg5_coarse_against_reference_fixture():
@@ -106,6 +112,29 @@ def test_kats_against_reference_fixture():
             k0, k1 = ops.fine_match(win0, win1, mix0, mix1, out['mkpts0_c'], out['mkpts1_c'], hw[0] / (hw[4] * 4))
             assert np.abs(k0.cpu().numpy() - k['mkpts0_f']).max() <= FINE_TOL_PX, name
             assert np.abs(k1.cpu().numpy() - k['mkpts1_f']).max() <= FINE_TOL_PX, name
+
+
+def test_round2_kats_against_reference_fixture():
+    """Per-sample scales with M >= 50 (keypoints bit-exact), and the constructed thr straddle: two inputs one ulp
+    of one descriptor's scale apart, whose reference outputs differ by exactly the entry with conf = thr +- few ulp.
+    The HIP path may place that ONE entry on either side (its conf is within 1e-6 of thr); nothing else may move."""
+    cases = load_kats("kats_r2")
+    k = cases["scale_big"]
+    hw = [int(v) for v in k['hw']]
+    out = _run_coarse(k['f0'], k['f1'], hw[0:2], hw[4:6], hw[6:8], 0.2, 2, 0.1, k['scale0'], k['scale1'])
+    assert _assert_coarse(out, k) == 0 and out['i_ids'].shape[0] >= 50
+    for name in ("thr_below", "thr_above"):
+        k = cases[name]
+        hw = [int(v) for v in k['hw']]
+        i_s, j_s = [int(v) for v in k['straddle']]
+        out = _np(_run_coarse(k['f0'], k['f1'], hw[0:2], hw[4:6], hw[6:8]))
+        only_g, only_r, err = compare_match_sets(out, k)
+        moved = {key for key, _ in only_g + only_r}
+        assert moved <= {(0, i_s, j_s)}, (name, moved)       # a flip happens only at the constructed entry
+        assert err <= CONF_TOL
+        got = {(int(i), int(j)): float(c) for i, j, c in zip(out['i_ids'], out['j_ids'], out['mconf'])}
+        if (i_s, j_s) in got:
+            assert abs(got[(i_s, j_s)] - 0.2) < 2e-6
 
 
 # ------------------------------------------------------------------ oracle on fresh inputs
@@ -157,6 +186,28 @@ def test_flat_rows_take_the_exact_screening_pass():
     assert e.value.status == _lib.FM_E_CANDIDATES
     buf = ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0, exact_screening=True)
     assert buf.read_count() == ref['i_ids'].shape[0]
+
+
+def test_flat_rows_with_conf_matrix_run_the_coarse_stage_once(monkeypatch):
+    """Training-shaped call (conf_matrix requested) on flat rows: the exact screening is on from the first call, so
+    the coarse stage is enqueued once - not once to overflow and once more to recover."""
+    f0, f1 = synth.coarse_descriptors(43, 2, 30 * 40, 128, "peaky")
+    f0[:, ::2] *= 1e-4
+    f1[:, ::2] *= 1e-4
+    ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
+    calls = []
+    real = ops.coarse_match_async
+    monkeypatch.setattr(ops, "coarse_match_async", lambda *a, **k: (calls.append(k.get("exact_screening")), real(*a, **k))[1])
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    out = ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0, conf_matrix=True)
+    assert calls == [True]
+    _assert_coarse(out, ref)
+    # and a shape that overflowed once starts with the exact screening the next time
+    calls.clear()
+    ops._NEEDS_EXACT_SCREENING.clear()
+    ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
+    ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
+    assert calls == [False, True, True]
 
 
 def test_non_finite_input_is_reported():
@@ -267,6 +318,39 @@ def test_properties_at_cfg2_size():
     fwd = set(zip(s0['i_ids'].tolist(), s0['j_ids'].tolist()))
     bwd = set(zip(t['j_ids'].tolist(), t['i_ids'].tolist()))
     assert len(fwd ^ bwd) <= 2                            # conf differs in the last bits only
+
+
+def test_properties_at_cfg3_size():
+    """BASELINE config #3 at its size (batch of 64 pairs of 640x480, C = 256): the launch geometry of a batch that
+    fills the chip by itself (one column split in the max pass, 64-unit ranges in the sparse sum kernel).  Inputs
+    are generated on the device (same statistics as the 'peaky' distribution); checked: bitwise determinism,
+    torch.where order, border exclusion, and batch == the single pairs run alone."""
+    sh = synth.config_shapes(synth.CONFIGS['cfg2'])
+    n, l, c = 64, sh['l'], 256
+    g = torch.Generator(device=DEV).manual_seed(123)
+    f0 = 4.0 * torch.randn(n, l, c, device=DEV, generator=g)
+    f1 = torch.empty_like(f0)
+    for b in range(n):
+        f1[b] = f0[b, torch.randperm(l, device=DEV, generator=g)]
+    f1 += 0.4 * torch.randn(n, l, c, device=DEV, generator=g)
+    hw_c = (sh['hc'], sh['wc'])
+    run = lambda a0, a1: _np(ops.coarse_match(a0, a1, hw_c, hw_c, 8.0))
+    a = run(f0, f1)
+    b2 = run(f0, f1)
+    for k in a:                                           # deterministic, bit for bit
+        assert np.array_equal(a[k], b2[k]), k
+    key = a['b_ids'] * (1 << 40) + a['i_ids'] * (1 << 20) + a['j_ids']
+    assert np.all(np.diff(key) > 0)                       # torch.where order, no duplicates
+    assert set(np.unique(a['b_ids']).tolist()) == set(range(n))
+    assert a['mconf'].min() > 0.2 and a['i_ids'].shape[0] > 0.7 * n * 56 * 76
+    for ids in (a['i_ids'], a['j_ids']):                  # border cells never match
+        y, x = ids // sh['wc'], ids % sh['wc']
+        assert y.min() >= 2 and y.max() < sh['hc'] - 2 and x.min() >= 2 and x.max() < sh['wc'] - 2
+    for b in (0, 31, 63):                                 # a sample of the batch == that pair run alone
+        s = run(f0[b:b + 1], f1[b:b + 1])
+        sel = a['b_ids'] == b
+        assert np.array_equal(a['i_ids'][sel], s['i_ids']) and np.array_equal(a['j_ids'][sel], s['j_ids'])
+        assert np.array_equal(a['mconf'][sel], s['mconf']) and np.array_equal(a['mkpts1_c'][sel], s['mkpts1_c'])
 
 
 # ------------------------------------------------------------------ match(img0, img1) facade

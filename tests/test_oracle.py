@@ -63,6 +63,23 @@ def test_kats_match_reference():
             np.testing.assert_allclose(k1.numpy(), k['mkpts1_f'], rtol=0, atol=2e-5)
 
 
+def test_round2_kats_match_reference():
+    """kats_r2.npz: per-sample scales with many matches; one entry's conf one descriptor-scale ulp below / above thr."""
+    cases = load_kats("kats_r2")
+    assert set(cases) == {"scale_big", "thr_below", "thr_above"}
+    for name, k in cases.items():
+        hw = [int(v) for v in k['hw']]
+        out = orc.coarse_match(k['f0'], k['f1'], hw[0:2], hw[4:6], hw[6:8], 0.2, 2, 0.1, k.get('scale0'), k.get('scale1'))
+        _check_coarse(out, k)
+    assert cases["scale_big"]['i_ids'].shape[0] >= 50
+    lo, hi = cases["thr_below"], cases["thr_above"]
+    i_s, j_s = [int(v) for v in hi['straddle']]
+    pairs = lambda c: set(zip(c['i_ids'].tolist(), c['j_ids'].tolist()))
+    assert pairs(hi) - pairs(lo) == {(i_s, j_s)} and not (pairs(lo) - pairs(hi))
+    assert 0.2 < float(hi['straddle_conf']) < 0.2 + 1e-6
+    assert np.count_nonzero(lo['f1'] != hi['f1']) <= 32          # one descriptor, one ulp of its scale
+
+
 def test_kat_properties():
     cases = load_kats()
     tie = cases['tie']

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build an experimental variant of the library:  tools/build_variant.sh NAME "-DFM_PF_SUM=3 ..."
-# -> build/variants/libfmatch_NAME.so   (load it with FMATCH_LIB=build/variants/libfmatch_NAME.so)
+# -> build/variants/libfmatch_NAME.so   (run it with: python tools/bench_variant.py build/variants/libfmatch_NAME.so ...)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
