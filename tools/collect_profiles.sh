@@ -8,7 +8,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
 rm -rf $O && mkdir -p $O
-COMMON="--steps 200 --warmup 20 --skip-cpu"
+COMMON="--steps 200 --warmup 20 --skip-cpu --quick"
 # (1) the default command (hipGraph replay, 4 streams): per-kernel time under the bench's own concurrency
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -- python bench.py $COMMON > $O/default.json 2> $O/default.err
 echo "default done"
@@ -16,7 +16,7 @@ echo "default done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python bench.py $COMMON --streams 1 --pairs 1 --no-graph > $O/serial.json 2> $O/serial.err
 echo "serial done"
 # (3) memory-side traffic per launch, one counter per pass
-PM="--steps 20 --warmup 5 --skip-cpu --streams 1 --pairs 1 --no-graph"
+PM="--steps 20 --warmup 5 --skip-cpu --quick --streams 1 --pairs 1 --no-graph"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python bench.py $PM > $O/fetch.json 2> $O/fetch.err
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py $PM > $O/write.json 2> $O/write.err
@@ -25,9 +25,9 @@ echo "write done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python bench.py $PM > $O/sq.json 2> $O/sq.err
 echo "sq done"
 # (5) the batch-of-64 workload (cfg3) and the 1024x1024 pair (cfg5): kernel time
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python bench.py --workload cfg3 --steps 20 --warmup 3 --skip-cpu > $O/cfg3.json 2> $O/cfg3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python bench.py --workload cfg3 --steps 20 --warmup 3 --skip-cpu --quick > $O/cfg3.json 2> $O/cfg3.err
 echo "cfg3 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- python bench.py --workload cfg5 --steps 50 --warmup 5 --skip-cpu > $O/cfg5.json 2> $O/cfg5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- python bench.py --workload cfg5 --steps 50 --warmup 5 --skip-cpu --quick > $O/cfg5.json 2> $O/cfg5.err
 echo "cfg5 done"
 # keep what is merged back small: stats + counter tables only (traces of 200 steps are large)
 find $O -name '*kernel_trace.csv' -size +8M -delete
