@@ -26,6 +26,7 @@ struct MaxArgs {
   const signed char* q0; const signed char* q1;
   const float* sig0; const float* sig1;
   unsigned* rowmax_u; unsigned* colmax_u; float* umax;
+  float* diag;            // diagnostic build: stamp buffer
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, pgroup;
 };
 
@@ -64,12 +65,20 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float s_colred[2 * 8 * 64];            // per tile parity: the 8 waves' column maxima of 64 columns
   __shared__ float s_meta[NBUF * 64];               // per ring slot: the quantisation steps of the tile's 64 columns
-  __shared__ __attribute__((aligned(16))) float s_sigA[8][32];   // ... of the 8 waves' rows
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
+#ifdef FM_DIAG_CLOCK       // diagnostic build only: shader-clock stamps per phase of every wave (tools/diag_max.py)
+  const unsigned long long dg0 = __builtin_amdgcn_s_memtime();
+  unsigned long long dg_pro = 0, dg_mfma = 0, dg_epi = 0, dg_bar = 0, dg_stage = 0;
+#define DG_T0 const unsigned long long dg_t = __builtin_amdgcn_s_memtime();
+#define DG_ADD(x) x += __builtin_amdgcn_s_memtime() - dg_t;
+#else
+#define DG_T0
+#define DG_ADD(x)
+#endif
 
   // workgroup order: sample, groups of a.pgroup panels, split-major inside a group, through the bijective XCD
   // remap - one XCD's share is a compact (panels x splits) block (speed only)
@@ -87,21 +96,7 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
   const int nunits = a.Sp / 32;
 
-  // the steps of this wave's 32 rows: through LDS into the accumulator's row order (rows 8q + 4h + 0..3 in
-  // registers 4q..4q+3), BEFORE the first LDS-DMA is issued (afterwards hipcc would drain the ring in front of
-  // every LDS access it can see)
   const int wrow0 = panel * kPanelRows + wv * 32;
-  if (lane < 32) s_sigA[wv][lane] = a.sig0[(long)b * a.Lp + wrow0 + lane];
-  __builtin_amdgcn_wave_barrier();
-  float sgA[16];
-  {
-    const int h_ = lane >> 5;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(&s_sigA[wv][8 * q + 4 * h_]);
-      sgA[4 * q] = v.x; sgA[4 * q + 1] = v.y; sgA[4 * q + 2] = v.z; sgA[4 * q + 3] = v.w;
-    }
-  }
   const signed char* plane1 = a.q1 + (long)b * a.Sp * C;
   auto stage = [&](int t, int buf) {
 #pragma unroll
@@ -129,7 +124,20 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
   }
-  const bool row_edge = (wrow0 + 32 > a.L);
+  // the quantisation steps of this lane's 16 accumulator rows (rows 8q + 4h + 0..3 in registers 4q..4q+3): four
+  // 16-byte loads, in flight together with the A fragments and the first tiles.  Padded rows (>= L: zero
+  // descriptors) get NaN: their products then drop out of every maximum (v_max ignores NaN), no masks needed.
+  float sgA[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(a.sig0 + (long)b * a.Lp + wrow0 + 8 * q + 4 * h);
+    sgA[4 * q] = v.x; sgA[4 * q + 1] = v.y; sgA[4 * q + 2] = v.z; sgA[4 * q + 3] = v.w;
+  }
+  if (wrow0 + 32 > a.L) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+      if (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) sgA[g] = __builtin_nanf("");
+  }
 
   float rstat[16];               // running maxima of (q_i . q_j) * sigma_j over the columns seen so far
 #pragma unroll
@@ -182,37 +190,43 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   for (int ks = 0; ks < KS8; ++ks) asm volatile("" ::"v"(aq[ks]));
 #pragma unroll
   for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(sgA[g]));
+#ifdef FM_DIAG_CLOCK
+  dg_pro = __builtin_amdgcn_s_memtime() - dg0;
+#endif
 
   for (int u = 2 * t0; u < 2 * t1; ++u) {
     const int t = u >> 1, par = (t - t0) & 1;
-    if ((u & 1) == 0 && t + NBUF - 1 < t1) stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF);   // refill the slot of tile t-1
+    if ((u & 1) == 0 && t + NBUF - 1 < t1) { DG_T0 stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF); DG_ADD(dg_stage) }   // refill the slot of tile t-1
     float sB;                  // this lane's column step (inline asm: see k_corr on compiler-visible LDS accesses)
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sB) : "v"(meta_a + (((t - t0) % NBUF) * 64 + (u & 1) * 32 + r) * 4));
-    mfma_unit(u);
+    { DG_T0 mfma_unit(u); asm volatile("" ::"v"(acc)); DG_ADD(dg_mfma) }
+#ifdef FM_DIAG_CLOCK
+    const unsigned long long dg_e0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: rows in registers, columns on lanes ----
     const int ucol0 = u * 32;
+    // padded columns (>= S: zero descriptors) get a NaN step: their products drop out of every maximum
+    if (ucol0 + r >= a.S) sB = __builtin_nanf("");
     float cstat = -INFINITY;
-    const bool cpad = ucol0 + r >= a.S;       // padded columns (zero descriptors, step 0) never count
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      float rv = (float)acc[g] * sB;
-      if (cpad) rv = -INFINITY;
-      float cv = rv * sgA[g];
-      // padded rows (>= L) hold zero descriptors: keep their zeros out of the column maxima
-      if (row_edge && wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) cv = -INFINITY;
+      const float rv = (float)acc[g] * sB;
       rstat[g] = fmaxf(rstat[g], rv);
-      cstat = fmaxf(cstat, cv);
+      cstat = fmaxf(cstat, rv * sgA[g]);
     }
     cstat = halves_max(cstat);
-    const float um = halves_max(half_max32(cstat));                  // unit maximum (both halves already merged)
+    const float um = half_max32(cstat);                              // unit maximum (the halves are merged already)
     if (lane == 0) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * nunits + u] = um;
     if (h == 0) {
       const unsigned ad = colred_a + (((par * 8 + wv) * 64 + (u & 1) * 32 + r) * 4);
       asm volatile("ds_write_b32 %0, %1" ::"v"(ad), "v"(cstat) : "memory");
     }
+#ifdef FM_DIAG_CLOCK
+    dg_epi += __builtin_amdgcn_s_memtime() - dg_e0;
+#endif
     if (u & 1) {
       // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
-      tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1));
+      { DG_T0 tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1)); DG_ADD(dg_bar) }
       if (wv == (t & 7)) {
         // every wave's column maxima of tile t are in LDS (their writes precede the barrier): this wave folds them
         float pv[8];
@@ -231,6 +245,9 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
     }
   }
 
+#ifdef FM_DIAG_CLOCK
+  const unsigned long long dg_tail0 = __builtin_amdgcn_s_memtime();
+#endif
   // ---- row maxima of this workgroup's column range ----
 #pragma unroll
   for (int g = 0; g < 16; ++g) rstat[g] = half_max32(rstat[g]) * sgA[g];
@@ -242,6 +259,16 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
         __hip_atomic_fetch_max(out + (g & 3) + 8 * (g >> 2), ord_encode(rstat[g]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
   }
+#ifdef FM_DIAG_CLOCK
+  if (lane < 8) {
+    const float vals[8] = {(float)(__builtin_amdgcn_s_memtime() - dg0), (float)dg_pro, (float)dg_mfma, (float)dg_epi,
+                           (float)dg_bar, (float)dg_stage, (float)(2 * (t1 - t0)), (float)(__builtin_amdgcn_s_memtime() - dg_tail0)};
+    float vv = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vv = lane == q ? vals[q] : vv;
+    a.diag[((long)blockIdx.x * 8 + wv) * 8 + lane] = vv;
+  }
+#endif
 }
 
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st) {
@@ -250,6 +277,7 @@ hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st) {
   a.sig0 = (const float*)(base + w.sig0); a.sig1 = (const float*)(base + w.sig1);
   a.rowmax_u = (unsigned*)(base + w.rowmax_u); a.colmax_u = (unsigned*)(base + w.colmax_u);
   a.umax = (float*)(base + w.umax);
+  a.diag = (float*)(base + w.rowB);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
   a.splits = w.splits0; a.tiles_per_split = (w.tiles + a.splits - 1) / a.splits;
   {
