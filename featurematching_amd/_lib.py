@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfmatch_hip.so")
 
 FM_OK = 0
+FM_F32, FM_F16, FM_BF16 = 0, 1, 2     # enum fm_dtype
 FM_E_CAPACITY = -5
 FM_E_CANDIDATES = -6
 FM_E_RANGE = -7
@@ -31,6 +32,8 @@ SIGNATURES = {
     "fm_coarse_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "fm_coarse_match": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
                              _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "fm_coarse_match_dtype": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
+                                   _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
     "fm_debug_launch_corr": (_i, [_p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "fm_debug_launch_sum_sparse": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),

@@ -168,7 +168,19 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
                                int cand_slots, int exact_screening, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
                                float* mkpts0_c, float* mkpts1_c, float* mconf, int cap, int32_t* d_count,
                                float* conf_matrix, void* stream) {
+  return fm_coarse_match_dtype(feat0, feat1, FM_F32, N, L, S, C, h0c, w0c, h1c, w1c, temperature, thr, border_rm, scale_px,
+                               scale0, scale1, workspace, workspace_bytes, cand_slots, exact_screening, b_ids, i_ids,
+                               j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, conf_matrix, stream);
+}
+
+extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                                     int h0c, int w0c, int h1c, int w1c, float temperature, float thr, int border_rm,
+                                     float scale_px, const float* scale0, const float* scale1, void* workspace,
+                                     size_t workspace_bytes, int cand_slots, int exact_screening, int64_t* b_ids,
+                                     int64_t* i_ids, int64_t* j_ids, float* mkpts0_c, float* mkpts1_c, float* mconf,
+                                     int cap, int32_t* d_count, float* conf_matrix, void* stream) {
   if (!feat0 || !feat1 || !workspace || !d_count) return FM_E_NULL;
+  if (in_dtype != FM_F32 && in_dtype != FM_F16 && in_dtype != FM_BF16) return FM_E_UNSUPPORTED;
   if (cap > 0 && (!b_ids || !i_ids || !j_ids || !mkpts0_c || !mkpts1_c || !mconf)) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
@@ -180,14 +192,14 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
   const float inv_ct = 1.0f / ((float)C * temperature);
 
   // one dispatch: clear the per-call counters, split both images into float16 planes
-  hipError_t e = launch_prep(feat0, feat1, C, w, base, st);
+  hipError_t e = launch_prep(feat0, feat1, in_dtype, C, w, base, st);
   if (e != hipSuccess) return (int)e;
   // max pass: row / column / unit maxima of the int8 screening product (atomicMax: no partials, no reduction kernel)
   e = launch_max_i8(w, base, st);
   if (e != hipSuccess) return (int)e;
   // sparse sum kernel: stabilisers, live units, exact terms of the few significant entries, candidates;
   // flags the units with too many significant entries (flat similarity) for the dense kernel
-  e = launch_sum_sparse(feat0, feat1, C, w, base, inv_ct, thr, st);
+  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
   // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
   // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
@@ -249,7 +261,7 @@ extern "C" int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, c
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  return (int)launch_sum_sparse(feat0, feat1, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr,
+  return (int)launch_sum_sparse(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr,
                                 (hipStream_t)stream);
 }
 

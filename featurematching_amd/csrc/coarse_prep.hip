@@ -10,14 +10,14 @@
 // cores reproduces the float32 product to ~2^-22 relative while running at the f16
 // MFMA rate (dense sum kernel).  Screening (row / column / unit maxima, which units and entries matter) runs on
 // the int8 plane at twice that rate and half the bytes, with the rigorous quantisation margin of fm_device.h.
-#include "fm_internal.h"
+#include "fm_device.h"
 
 namespace fm {
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 struct PrepArgs {
-  const float* src0; const float* src1;
+  const void* src0; const void* src1; int in_dtype;      // FM_F32 / FM_F16 / FM_BF16 rows [N, rows, c_in]
   _Float16* hi0; _Float16* lo0; _Float16* hi1; _Float16* lo1;
   signed char* q0; signed char* q1;   // int8 screening planes (fragment-major for v_mfma_i32_32x32x32_i8)
   float* sig0; float* sig1;           // quantisation step of every descriptor (row)
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   const int b = (int)(rb * 32 / rows_pad);
   const int r = tid & 31;
   const int local = (int)(rb * 32 - (long)b * rows_pad) + r;
-  const float* row = (img1 ? a.src1 : a.src0) + ((long)b * rows + local) * a.c_in;
+  const long row_off = ((long)b * rows + local) * a.c_in;          // elements
+  const void* const src = img1 ? a.src1 : a.src0;
   float x[NCH][8];
   float s1 = 0.f, amax = 0.f;
   bool bad = false;
@@ -82,8 +83,20 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
     const int q = n * 8 + (tid >> 5);
     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
     if (local < rows) {
-      if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
-      if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
+      if (a.in_dtype == FM_F32) {
+        const float* row = (const float*)src + row_off;
+        if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
+        if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
+      } else {
+        // half-precision rows (what a ROCm backbone under autocast hands over): 4 values per 8-byte load; every
+        // float16 / bfloat16 value is exact in float32, so everything downstream sees the caller's numbers
+        const unsigned short* row = (const unsigned short*)src + row_off;
+        uint2 h0 = make_uint2(0u, 0u), h1 = h0;
+        if (q * 8 < a.c_in) h0 = *reinterpret_cast<const uint2*>(row + q * 8);
+        if (q * 8 + 4 < a.c_in) h1 = *reinterpret_cast<const uint2*>(row + q * 8 + 4);
+        v0 = half4_to_float4(h0, a.in_dtype);
+        v1 = half4_to_float4(h1, a.in_dtype);
+      }
     }
     bad = bad || bad_value(v0) || bad_value(v1);
     x[n][0] = v0.x; x[n][1] = v0.y; x[n][2] = v0.z; x[n][3] = v0.w;
@@ -152,10 +165,10 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   }
 }
 
-hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
+hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                        hipStream_t st) {
   PrepArgs a;
-  a.src0 = feat0; a.src1 = feat1;
+  a.src0 = feat0; a.src1 = feat1; a.in_dtype = in_dtype;
   a.hi0 = (_Float16*)(base + w.hi0); a.lo0 = (_Float16*)(base + w.lo0);
   a.hi1 = (_Float16*)(base + w.hi1); a.lo1 = (_Float16*)(base + w.lo1);
   a.q0 = (signed char*)(base + w.q0); a.q1 = (signed char*)(base + w.q1);

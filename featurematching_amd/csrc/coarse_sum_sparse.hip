@@ -41,7 +41,7 @@ constexpr int kSparseQueue = 64;      // candidates a wave parks in LDS (one per
 
 struct SparseArgs {
   const signed char* q0; const signed char* q1;       // int8 screening planes (k_prep_split)
-  const float* src0; const float* src1; int c_in;      // the caller's descriptors [N,L,c_in] / [N,S,c_in]
+  const void* src0; const void* src1; int c_in, in_dtype;   // the caller's descriptors [N,L,c_in] / [N,S,c_in]
   const unsigned* rowmax_u; const unsigned* colmax_u;  // max pass: ord_encode'd maxima of the screening product
   const float* sig0; const float* sig1;                // quantisation step per descriptor
   const float* bsig0; const float* bsig1;              // ... largest per 32-row block
@@ -335,11 +335,16 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
       if (e0 + q >= nlist) break;                 // wave-uniform
       key[q] = __builtin_amdgcn_readfirstlane(s_list[wv][e0 + q]);
       const int rl = (key[q] >> 5) & 31, col = (u0 + (key[q] >> 10)) * 32 + (key[q] & 31);
-      const float4* rp = reinterpret_cast<const float4*>(a.src0 + ((long)b * a.L + wrow0 + rl) * a.c_in);
-      const float4* cp = reinterpret_cast<const float4*>(a.src1 + ((long)b * a.S + col) * a.c_in);
+      const long ro = ((long)b * a.L + wrow0 + rl) * a.c_in, co = ((long)b * a.S + col) * a.c_in;
       const bool in = lane * 4 < a.c_in;
-      av[q] = in ? rp[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      bv[q] = in ? cp[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[q] = bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in && a.in_dtype == FM_F32) {
+        av[q] = reinterpret_cast<const float4*>((const float*)a.src0 + ro)[lane];
+        bv[q] = reinterpret_cast<const float4*>((const float*)a.src1 + co)[lane];
+      } else if (in) {       // float16 / bfloat16 rows: exact in float32, products of two halves are exact too
+        av[q] = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)a.src0 + ro)[lane], a.in_dtype);
+        bv[q] = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)a.src1 + co)[lane], a.in_dtype);
+      }
     }
     float x[EB];
 #pragma unroll
@@ -419,9 +424,10 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 #endif
 }
 
-hipError_t launch_sum_sparse(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
+hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                              float inv_ct, float thr, hipStream_t st) {
   SparseArgs a;
+  a.in_dtype = in_dtype;
   a.q0 = (const signed char*)(base + w.q0); a.q1 = (const signed char*)(base + w.q1);
   a.src0 = feat0; a.src1 = feat1; a.c_in = c_in;
   a.rowmax_u = (const unsigned*)(base + w.rowmax_u); a.colmax_u = (const unsigned*)(base + w.colmax_u);

@@ -16,6 +16,16 @@ __device__ __forceinline__ float ord_decode(unsigned c) {      // c == 0 (nothin
   return __uint_as_float((c & 0x80000000u) ? (c & 0x7fffffffu) : ~c);
 }
 
+// float16 / bfloat16 bit patterns -> float32 (exact)
+__device__ __forceinline__ float half_bits_to_float(unsigned h, int dtype) {       // low 16 bits of h
+  if (dtype == FM_BF16) return __uint_as_float(h << 16);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+}
+__device__ __forceinline__ float4 half4_to_float4(uint2 p, int dtype) {
+  return make_float4(half_bits_to_float(p.x & 0xffffu, dtype), half_bits_to_float(p.x >> 16, dtype),
+                     half_bits_to_float(p.y & 0xffffu, dtype), half_bits_to_float(p.y >> 16, dtype));
+}
+
 // Error of the int8 screening product against the exact one (raw dot-product units).  With a = sigma_a q_a + da,
 // |da_k| <= sigma_a / 2 (k_prep_split: q = rint(a / sigma), sigma = block max / 127) and likewise for b:
 //   a.b - sigma_a sigma_b (q_a.q_b) = da.b + (a - da).db

@@ -72,7 +72,7 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 };
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
-hipError_t launch_prep(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
+hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                        hipStream_t st);
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st);
 hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st,
@@ -82,7 +82,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1
                          float scale_px, const float* scale0, const float* scale1,
                          int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* k0, float* k1,
                          float* mconf, int cap, int32_t* d_count, int exact_screening, hipStream_t st);
-hipError_t launch_sum_sparse(const float* feat0, const float* feat1, int c_in, const CoarseWs& w, char* base,
+hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                              float inv_ct, float thr, hipStream_t st);
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, device) instead of on every launch: the

@@ -23,6 +23,19 @@ def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_DTYPES = {torch.float32: _lib.FM_F32, torch.float16: _lib.FM_F16, torch.bfloat16: _lib.FM_BF16}
+
+
+def _desc(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Coarse descriptors go to the kernels in the type they come in (float32, float16 or bfloat16: no up-cast
+    pass); anything else is converted to float32."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.dtype not in _DTYPES:
+        t = t.float()
+    return t.contiguous()
+
+
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU: the HIP path has no CPU fallback")
@@ -80,12 +93,16 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
                        conf_matrix: bool = False, exact_screening: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
-    capacity-sized device buffers without synchronising.  exact_screening adds the two kernels that
+    capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
+    (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
+    the up-cast tensors).  exact_screening adds the two kernels that
     re-screen the candidates with exact softmax denominators (needed for nearly flat similarity rows;
     without it such rows report FM_E_CANDIDATES through read_count)."""
     lib = _lib.load()
-    f0 = _f32c(feat_c0, "feat_c0")
-    f1 = _f32c(feat_c1, "feat_c1")
+    f0 = _desc(feat_c0, "feat_c0")
+    f1 = _desc(feat_c1, "feat_c1")
+    if f1.dtype != f0.dtype:
+        f1 = f1.to(f0.dtype)
     n, l, c = f0.shape
     s = f1.shape[1]
     if f1.shape[0] != n or f1.shape[2] != c:
@@ -109,13 +126,13 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
         out.conf_matrix = torch.empty(n, l, s, dtype=torch.float32, device=dev)
     sc0 = None if scale0 is None else _f32c(scale0.to(dev), "scale0")
     sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
-    st = lib.fm_coarse_match(_ptr(f0), _ptr(f1), n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
+    st = lib.fm_coarse_match_dtype(_ptr(f0), _ptr(f1), _DTYPES[f0.dtype], n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
                              int(hw1_c[1]), float(temperature), float(thr), int(border_rm), float(scale_px),
                              _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots, int(bool(exact_screening)),
                              _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids), _ptr(out.mkpts0_c),
                              _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), _ptr(out.conf_matrix),
                              _stream(dev))
-    _lib.check(st, "fm_coarse_match")
+    _lib.check(st, "fm_coarse_match_dtype")
     out._keep = (f0, f1, sc0, sc1)   # inputs must outlive the enqueued kernels
     out._shape = (n, l, s, c, cand_slots)
     return out

@@ -47,6 +47,9 @@ enum fm_status {
   FM_E_RANGE = -7        /* (device status) descriptor not finite or |x| >= 32768 */
 };
 
+/* element type of the coarse descriptors handed to fm_coarse_match_dtype */
+enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
+
 /* device status bits stored in d_count[1] */
 #define FM_DEV_CAPACITY 1
 #define FM_DEV_CANDIDATES 2
@@ -90,6 +93,23 @@ int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S,
                     float* mkpts0_c, float* mkpts1_c, float* mconf,
                     int cap, int32_t* d_count, float* conf_matrix, void* stream);
 
+/*
+ * The same stage for descriptors in float32, float16 or bfloat16 (in_dtype = enum fm_dtype; feat0/feat1 [dev]
+ * [N,L,C] / [N,S,C] of that type, 8-byte aligned rows): what a PyTorch-ROCm backbone under autocast hands over,
+ * without an up-cast pass in between.  Every half-precision value is exact in float32 and so is the product of
+ * two of them, so the result equals fm_coarse_match on the up-cast tensors (the reference's float32 arithmetic on
+ * the same numbers, coarse_matching_new.py:64-66).  fm_coarse_match(...) == fm_coarse_match_dtype(..., FM_F32, ...).
+ * The workspace does not depend on the input type.
+ */
+int fm_coarse_match_dtype(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                          int h0c, int w0c, int h1c, int w1c,
+                          float temperature, float thr, int border_rm, float scale_px,
+                          const float* scale0, const float* scale1,
+                          void* workspace, size_t workspace_bytes, int cand_slots, int exact_screening,
+                          int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                          float* mkpts0_c, float* mkpts1_c, float* mconf,
+                          int cap, int32_t* d_count, float* conf_matrix, void* stream);
+
 /* Diagnostic only: workspace layout of fm_coarse_match (40 values: 10 ints, byte offsets, the sparse
  * sum kernel's split geometry, total; order documented in csrc/api.hip) so tests can inspect
  * intermediate statistics. */
@@ -103,7 +123,7 @@ int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* 
 int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_slots,
                          float temperature, float thr, int mode, void* stream);
 int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
-                               int C, int cand_slots, float temperature, float thr, void* stream);
+                               int C, int cand_slots, float temperature, float thr, void* stream);   /* float32 rows */
 int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream);
 
 /* Copy {M, status} to the host and wait for the stream (the one host sync of the

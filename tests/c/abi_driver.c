@@ -31,6 +31,7 @@ static __typeof__(fm_strerror)* p_fm_strerror;
 static __typeof__(fm_default_cand_slots)* p_fm_default_cand_slots;
 static __typeof__(fm_coarse_workspace_bytes)* p_fm_coarse_workspace_bytes;
 static __typeof__(fm_coarse_match)* p_fm_coarse_match;
+static __typeof__(fm_coarse_match_dtype)* p_fm_coarse_match_dtype;
 static __typeof__(fm_debug_coarse_layout)* p_fm_debug_coarse_layout;
 static __typeof__(fm_debug_launch_corr)* p_fm_debug_launch_corr;
 static __typeof__(fm_debug_launch_sum_sparse)* p_fm_debug_launch_sum_sparse;
@@ -49,7 +50,7 @@ int main(int argc, char** argv) {
   void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes);
-  RESOLVE(fm_coarse_match); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
+  RESOLVE(fm_coarse_match); RESOLVE(fm_coarse_match_dtype); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
   RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
@@ -104,6 +105,8 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 5, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 16, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, odd, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
+  EXPECT(p_fm_coarse_match_dtype(one, one, 7, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_match_dtype(NULL, one, FM_F16, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_NULL);
   int32_t m = 0;
   EXPECT(p_fm_read_count(NULL, 4, &m, NULL), FM_E_NULL);
   EXPECT(p_fm_read_count(cnt, 4, NULL, NULL), FM_E_NULL);

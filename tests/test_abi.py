@@ -59,6 +59,10 @@ def test_workspace_query_and_argument_checks():
     args = [null, null, 1, 64, 64, 64, 8, 8, 8, 8, 0.1, 0.2, 2, 8.0, null, null, null, 0, 8, 0,
             null, null, null, null, null, null, 0, null, null, null]
     assert lib.fm_coarse_match(*args) == -1
+    one_ = C.c_void_p(256)
+    dargs = [one_, one_, 3, 1, 64, 64, 64, 8, 8, 8, 8, 0.1, 0.2, 2, 8.0, null, null, one_, 1 << 30, 8, 0,
+             one_, one_, one_, one_, one_, one_, 64, one_, null, null]
+    assert lib.fm_coarse_match_dtype(*dargs) == -3                 # unknown element type
     assert lib.fm_gather_windows(null, 1, 64, 8, 8, 0, 7, 4, 2, 2, null, null, null, 4, null, null) == -1
     assert lib.fm_gather_windows(null, 1, 64, 8, 8, 0, 7, 4, 2, 2, null, null, null, 0, null, null) == 0   # M == 0
     assert lib.fm_fine_match(null, null, 0, null, 49, 64, null, null, null, null, 2.0, null, null, null) == 0

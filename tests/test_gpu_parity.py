@@ -167,6 +167,22 @@ def test_small_magnitude_descriptors():
     assert ref['i_ids'].shape[0] > 50
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,dist", [((16, 16, 64), "peaky"), ((60, 80, 256), "peaky"), ((30, 40, 128), "borderline")])
+def test_half_precision_descriptors(dtype, shape, dist):
+    """fm_coarse_match_dtype: float16 / bfloat16 descriptors go to the kernels as they are.  Half-precision values
+    and their pairwise products are exact in float32, so the oracle - the reference's float32 arithmetic - run on
+    the up-cast tensors is the answer: identical ids outside the guard band, mconf within 1e-5."""
+    hc, wc, c = shape
+    f0, f1 = synth.coarse_descriptors(91, 2, hc * wc, c, dist)
+    h0 = torch.as_tensor(f0).to(dtype)
+    h1 = torch.as_tensor(f1).to(dtype)
+    ref = orc.coarse_match(h0.float().numpy(), h1.float().numpy(), (hc * 8, wc * 8), (hc, wc), (hc, wc), 0.2, 2, 0.1)
+    out = ops.coarse_match(h0.to(DEV), h1.to(DEV), (hc, wc), (hc, wc), 8.0)
+    _assert_coarse(out, ref)
+    assert ref['i_ids'].shape[0] > 50
+
+
 def test_flat_rows_take_the_exact_screening_pass():
     """Half of the cells of BOTH images carry almost no signal: every (flat row, flat column) entry is
     within ln(thr) of its row and its column maximum, the max-based screening of the sum pass overflows the
