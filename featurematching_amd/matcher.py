@@ -6,7 +6,10 @@ The feature extractor is NOT part of the accelerated path ("CNN
 on PyTorch-ROCm"); `SmallFPN` is a plain torch stand-in with the reference's resolutions (coarse
 1/8 with d_model 256, fine 1/2 with d_model 64) so that the pipeline runs end to end with
 seeded-random weights.  No checkpoint of the reference exists, so there is no parity claim for it.
-The context transformers (network/module/transformer.py) are the first "next" row and are skipped.
+Everything after the backbone follows network/net.py:66-83 step by step - coarse context layers, coarse matching,
+window crop + context merge, fine context layers, fine matching (`Matcher.forward_features`) - and is checked
+against a fixture produced by the reference's own modules (tests: net_tail_small).  The context layers run on
+PyTorch-ROCm (transformer.py); the three matching stages are the HIP kernels.
 """
 from __future__ import annotations
 
@@ -15,10 +18,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .modules import CoarseMatching, FineMatching, FinePreprocess
+from .transformer import LocalFeatureTransformer
 
 DEFAULT_CONFIG = {
     'fine_window_size': 7, 'fine_concat_coarse_feat': True, 'resolution': (8, 2),
-    'coarse': {'d_model': 256}, 'fine': {'d_model': 64},
+    'coarse': {'d_model': 256, 'nhead': 8, 'layer_names': ['self', 'cross'] * 4, 'attention': 'linear'},
+    'fine': {'d_model': 64, 'nhead': 8, 'layer_names': ['self', 'cross'], 'attention': 'linear'},
     'match_coarse': {'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1,
                      'train_coarse_percent': 1.0, 'train_pad_num_gt_min': 200},
 }
@@ -55,8 +60,9 @@ class SmallFPN(nn.Module):
 
 
 class Matcher(nn.Module):
-    """backbone -> CoarseMatching -> FinePreprocess -> FineMatching with the reference's `data`
-    dict protocol (same keys as network/net.py:51-62,89-92)."""
+    """backbone -> coarse context layers -> CoarseMatching -> FinePreprocess -> fine context layers ->
+    FineMatching with the reference's `data` dict protocol and sub-module names (network/net.py:24-32,51-92), so
+    that a reference state dict addresses the same parameters."""
 
     def __init__(self, config=None, backbone: nn.Module = None):
         super().__init__()
@@ -64,8 +70,10 @@ class Matcher(nn.Module):
         cfg.update(config or {})
         self.config = cfg
         self.backbone = backbone or SmallFPN(3, cfg['coarse']['d_model'], cfg['fine']['d_model'])
+        self.coarse = LocalFeatureTransformer(cfg['coarse'])
         self.coarse_matching = CoarseMatching(cfg['match_coarse'])
         self.fine_preprocess = FinePreprocess(cfg)
+        self.fine = LocalFeatureTransformer(cfg['fine'])
         self.fine_matching = FineMatching(cfg['fine'], window=cfg['fine_window_size'])
 
     @torch.no_grad()
@@ -76,11 +84,22 @@ class Matcher(nn.Module):
         (feat_c0, feat_c1), (feat_f0, feat_f1) = feats_c.split(data['bs']), feats_f.split(data['bs'])
         data.update({'hw0_c': feat_c0.shape[2:], 'hw1_c': feat_c1.shape[2:],
                      'hw0_f': feat_f0.shape[2:], 'hw1_f': feat_f1.shape[2:]})
+        return self.forward_features(feat_c0, feat_c1, feat_f0, feat_f1, data)
+
+    @torch.no_grad()
+    def forward_features(self, feat_c0, feat_c1, feat_f0, feat_f1, data):
+        """network/net.py:66-92 on the backbone's maps feat_c* [N,C,hc,wc], feat_f* [N,Cf,Hf,Wf]; `data` holds
+        bs, hw0_i, hw1_i."""
+        data.update({'hw0_c': feat_c0.shape[2:], 'hw1_c': feat_c1.shape[2:],
+                     'hw0_f': feat_f0.shape[2:], 'hw1_f': feat_f1.shape[2:]})
         feat_c0 = feat_c0.flatten(2).transpose(1, 2).contiguous()       # n c h w -> n (h w) c
         feat_c1 = feat_c1.flatten(2).transpose(1, 2).contiguous()
-        self.coarse_matching(feat_c0, feat_c1, data)
-        win0, win1 = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)
-        self.fine_matching(win0, win1, data)
+        feat_c0, feat_c1 = self.coarse(feat_c0, feat_c1)                # :74
+        self.coarse_matching(feat_c0, feat_c1, data)                    # :75
+        win0, win1 = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)     # :78
+        if win0.size(0) != 0:                                           # at least one coarse level predicted
+            win0, win1 = self.fine(win0, win1)                          # :79-80
+        self.fine_matching(win0, win1, data)                            # :83
         data.update({'feat_c0': feat_c0, 'feat_c1': feat_c1, 'feat_f0': feat_f0, 'feat_f1': feat_f1})
         return data
 

@@ -127,3 +127,29 @@ def config_shapes(cfg: dict):
     hc, wc = cfg["h"] // 8, cfg["w"] // 8
     hf, wf = cfg["h"] // 2, cfg["w"] // 2
     return dict(hc=hc, wc=wc, hf=hf, wf=wf, l=hc * wc)
+
+
+def transformer_weights(seed: int, d_model: int, n_layers: int) -> dict:
+    """Seeded weights of a LocalFeatureTransformer (network/module/transformer.py) keyed by its state-dict names,
+    from the portable hash RNG: Linear weights uniform with the xavier bound sqrt(6 / (fan_in + fan_out)) (the
+    reference's own initialisation), LayerNorm affine terms away from (1, 0) so that they are exercised."""
+    out = {}
+    stream = 100
+
+    def lin(name, fan_out, fan_in):
+        nonlocal stream
+        bound = (6.0 / (fan_in + fan_out)) ** 0.5
+        u = uniform(seed, stream, fan_out * fan_in).reshape(fan_out, fan_in)
+        stream += 1
+        out[name] = ((2.0 * u - 1.0) * bound).astype(np.float32)
+
+    for k in range(n_layers):
+        for nme in ("q_proj", "k_proj", "v_proj", "merge"):
+            lin(f"layers.{k}.{nme}.weight", d_model, d_model)
+        lin(f"layers.{k}.mlp.0.weight", 2 * d_model, 2 * d_model)
+        lin(f"layers.{k}.mlp.2.weight", d_model, 2 * d_model)
+        for nme in ("norm1", "norm2"):
+            out[f"layers.{k}.{nme}.weight"] = (1.0 + 0.1 * normal(seed, stream, (d_model,))).astype(np.float32)
+            out[f"layers.{k}.{nme}.bias"] = (0.1 * normal(seed, stream + 1, (d_model,))).astype(np.float32)
+            stream += 2
+    return out

@@ -215,6 +215,80 @@ def kat_cases():
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **cases)
 
 
+NET_TAIL = dict(seed=31, n=2, h=128, w=128, c=256, cf=64, nhead=8, layers_c=['self', 'cross'] * 4,
+                layers_f=['self', 'cross'], gain=1.0, sigma=1.6)
+
+
+def net_tail_inputs(meta=NET_TAIL):
+    """Seeded inputs of the net_tail fixture (feature maps as a backbone would hand them over + all weights), from
+    the portable hash RNG: shared with the tests, which regenerate them instead of storing them."""
+    seed, n = meta['seed'], meta['n']
+    hc, wc, hf, wf = meta['h'] // 8, meta['w'] // 8, meta['h'] // 2, meta['w'] // 2
+    l = hc * wc
+    f0 = np.empty((n, l, meta['c']), np.float32)
+    f1 = np.empty_like(f0)
+    for b in range(n):
+        z0 = synth.normal(seed + b, 1, (l, meta['c']))
+        z1 = synth.normal(seed + b, 2, (l, meta['c']))
+        perm = synth.permutation(seed + b, 3, l)
+        f0[b] = z0
+        f1[b, perm] = z0 + meta['sigma'] / meta['gain'] * z1
+    to_map = lambda f: np.ascontiguousarray(f.reshape(n, hc, wc, meta['c']).transpose(0, 3, 1, 2))
+    ff0, ff1 = synth.fine_maps(seed, n, meta['cf'], hf, wf)
+    w_coarse = synth.transformer_weights(seed + 100, meta['c'], len(meta['layers_c']))
+    w_fine = synth.transformer_weights(seed + 200, meta['cf'], len(meta['layers_f']))
+    u = lambda st, shape, bound: ((2.0 * synth.uniform(seed + 300, st, int(np.prod(shape))).reshape(shape) - 1.0) * bound).astype(np.float32)
+    w_prep = {"down_proj.weight": u(1, (meta['cf'], meta['c']), (6.0 / (meta['cf'] + meta['c'])) ** 0.5),
+              "down_proj.bias": u(2, (meta['cf'],), 0.05),
+              "merge_feat.weight": u(3, (meta['cf'], 2 * meta['cf']), (6.0 / (3 * meta['cf'])) ** 0.5),
+              "merge_feat.bias": u(4, (meta['cf'],), 0.05)}
+    mix = synth.mix_weights(seed, 49)
+    return dict(feat_c0=to_map(f0), feat_c1=to_map(f1), feat_f0=ff0, feat_f1=ff1, w_coarse=w_coarse, w_fine=w_fine,
+                w_prep=w_prep, mix=mix, hw_i=(meta['h'], meta['w']))
+
+
+def net_tail_case(name="net_tail_small"):
+    """Everything network/net.py:66-83 does after the backbone, run with the REFERENCE's own modules (coarse /
+    fine LocalFeatureTransformer, CoarseMatching, FinePreprocess with its context merge, FineMatching) on seeded
+    feature maps and weights: the row-a8 fixture."""
+    from network.module.transformer import LocalFeatureTransformer
+    meta = NET_TAIL
+    inp = net_tail_inputs(meta)
+    sd = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}
+    coarse = LocalFeatureTransformer(dict(d_model=meta['c'], nhead=meta['nhead'], layer_names=meta['layers_c'], attention='linear')).eval()
+    fine = LocalFeatureTransformer(dict(d_model=meta['cf'], nhead=meta['nhead'], layer_names=meta['layers_f'], attention='linear')).eval()
+    coarse.load_state_dict(sd(inp['w_coarse']))
+    fine.load_state_dict(sd(inp['w_fine']))
+    fp = FinePreprocess({'fine_concat_coarse_feat': True, 'fine_window_size': 7, 'coarse': {'d_model': meta['c']},
+                         'fine': {'d_model': meta['cf']}}).eval()
+    fp.load_state_dict(sd(inp['w_prep']))
+    cm = CoarseMatching(dict(COARSE_CFG)).eval()
+    fm = FineMatching({'d_model': meta['cf']}).eval()
+    w0, b0, w1, b1 = inp['mix']
+    with torch.no_grad():
+        fm.mix_feat_0.weight.copy_(torch.as_tensor(w0).view(1, -1)); fm.mix_feat_0.bias.fill_(float(b0))
+        fm.mix_feat_1.weight.copy_(torch.as_tensor(w1).view(1, -1)); fm.mix_feat_1.bias.fill_(float(b1))
+        fc0, fc1 = torch.as_tensor(inp['feat_c0']), torch.as_tensor(inp['feat_c1'])
+        ff0, ff1 = torch.as_tensor(inp['feat_f0']), torch.as_tensor(inp['feat_f1'])
+        data = {'bs': meta['n'], 'hw0_i': inp['hw_i'], 'hw1_i': inp['hw_i'], 'hw0_c': fc0.shape[2:], 'hw1_c': fc1.shape[2:],
+                'hw0_f': ff0.shape[2:], 'hw1_f': ff1.shape[2:]}
+        c0 = fc0.flatten(2).transpose(1, 2)                    # net.py:69-70 'n c h w -> n (h w) c'
+        c1 = fc1.flatten(2).transpose(1, 2)
+        c0, c1 = coarse(c0, c1)                                # :74
+        cm(c0, c1, data)                                       # :75
+        u0, u1 = fp(ff0, ff1, c0, c1, data)                    # :78
+        if u0.size(0) != 0:
+            u0, u1 = fine(u0, u1)                              # :79-80
+        fm(u0, u1, data)                                       # :83
+    d = pack_coarse(data)
+    d.update(mkpts0_f=data['mkpts0_f'].numpy(), mkpts1_f=data['mkpts1_f'].numpy(),
+             c0_sum=c0.double().sum((1, 2)).numpy(), c1_abs=c1.double().abs().sum((1, 2)).numpy(),
+             u0_sum=u0.double().sum((1, 2)).numpy(), u1_sum=u1.double().sum((1, 2)).numpy(),
+             meta=np.array([meta['seed'], meta['n'], meta['h'], meta['w'], meta['c'], meta['cf']], np.int64))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(f"{name}: M={d['i_ids'].shape[0]} conf range [{d['mconf'].min():.3f}, {d['mconf'].max():.3f}]")
+
+
 def kat_cases_round2():
     """Round-2 known-answer cases (kats_r2.npz): a per-sample scale0/scale1 case with many matches, and a pair
     of cases whose only difference is ONE float32 ulp of one descriptor's scale, chosen by bisection on the
@@ -283,9 +357,14 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "r2":       # only the round-2 cases (the others are unchanged)
         kat_cases_round2()
+        net_tail_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "net_tail":
+        net_tail_case()
         sys.exit(0)
     kat_cases()
     kat_cases_round2()
+    net_tail_case()
     full_case("cfg1_peaky", "cfg1", "peaky")
     full_case("cfg1_borderline", "cfg1", "borderline")
     full_case("cfg2_peaky", "cfg2", "peaky")

@@ -43,3 +43,35 @@ def compare_match_sets(got, ref, conf_tol=1e-5):
     only_r = [(k, v) for k, v in rk.items() if k not in gk]
     err = max([abs(gk[k] - rk[k]) for k in gk if k in rk], default=0.0)
     return only_g, only_r, err
+
+
+NET_TAIL = dict(seed=31, n=2, h=128, w=128, c=256, cf=64, nhead=8, layers_c=['self', 'cross'] * 4,
+                layers_f=['self', 'cross'], gain=1.0, sigma=1.6)
+
+
+def net_tail_inputs(meta=NET_TAIL):
+    """Seeded inputs of the net_tail_small fixture (tests/golden/make_golden.py:net_tail_inputs restated: feature
+    maps as a backbone hands them over plus all weights, from the portable hash RNG)."""
+    seed, n = meta['seed'], meta['n']
+    hc, wc, hf, wf = meta['h'] // 8, meta['w'] // 8, meta['h'] // 2, meta['w'] // 2
+    l = hc * wc
+    f0 = np.empty((n, l, meta['c']), np.float32)
+    f1 = np.empty_like(f0)
+    for b in range(n):
+        z0 = synth.normal(seed + b, 1, (l, meta['c']))
+        z1 = synth.normal(seed + b, 2, (l, meta['c']))
+        perm = synth.permutation(seed + b, 3, l)
+        f0[b] = z0
+        f1[b, perm] = z0 + meta['sigma'] / meta['gain'] * z1
+    to_map = lambda f: np.ascontiguousarray(f.reshape(n, hc, wc, meta['c']).transpose(0, 3, 1, 2))
+    ff0, ff1 = synth.fine_maps(seed, n, meta['cf'], hf, wf)
+    w_coarse = synth.transformer_weights(seed + 100, meta['c'], len(meta['layers_c']))
+    w_fine = synth.transformer_weights(seed + 200, meta['cf'], len(meta['layers_f']))
+    u = lambda st, shape, bound: ((2.0 * synth.uniform(seed + 300, st, int(np.prod(shape))).reshape(shape) - 1.0) * bound).astype(np.float32)
+    w_prep = {"down_proj.weight": u(1, (meta['cf'], meta['c']), (6.0 / (meta['cf'] + meta['c'])) ** 0.5),
+              "down_proj.bias": u(2, (meta['cf'],), 0.05),
+              "merge_feat.weight": u(3, (meta['cf'], 2 * meta['cf']), (6.0 / (3 * meta['cf'])) ** 0.5),
+              "merge_feat.bias": u(4, (meta['cf'],), 0.05)}
+    mix = synth.mix_weights(seed, 49)
+    return dict(feat_c0=to_map(f0), feat_c1=to_map(f1), feat_f0=ff0, feat_f1=ff1, w_coarse=w_coarse, w_fine=w_fine,
+                w_prep=w_prep, mix=mix, hw_i=(meta['h'], meta['w']))

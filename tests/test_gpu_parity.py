@@ -14,7 +14,7 @@ import torch
 from featurematching_amd import modules, ops, synth
 from featurematching_amd import _lib
 from oracle import matcher_ref as orc
-from helpers import load_golden, load_kats, case_inputs, compare_match_sets
+from helpers import load_golden, load_kats, case_inputs, compare_match_sets, net_tail_inputs, NET_TAIL
 
 pytestmark = pytest.mark.gpu
 
@@ -367,6 +367,43 @@ def test_properties_at_cfg3_size():
         sel = a['b_ids'] == b
         assert np.array_equal(a['i_ids'][sel], s['i_ids']) and np.array_equal(a['j_ids'][sel], s['j_ids'])
         assert np.array_equal(a['mconf'][sel], s['mconf']) and np.array_equal(a['mkpts1_c'][sel], s['mkpts1_c'])
+
+
+# ------------------------------------------------------------------ row a8: net.forward after the backbone
+def test_matcher_tail_against_reference_fixture():
+    """Matcher.forward_features (network/net.py:66-83: coarse context layers on PyTorch-ROCm -> HIP coarse matching
+    -> HIP window crop fused with the context merge -> fine context layers -> HIP fine matching) against the
+    fixture the REFERENCE's own modules produced for the same seeded feature maps and weights.  The context
+    layers run in float32 on another device than the fixture's, which moves the descriptors by ~1e-6 relative:
+    the conf tolerance of this chain test is 1e-4 (guard band likewise), fine keypoints 2e-3 px."""
+    from featurematching_amd.matcher import Matcher
+    g = load_golden("net_tail_small")
+    inp = net_tail_inputs()
+    m = Matcher().to(DEV).eval()
+    t = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}
+    m.coarse.load_state_dict(t(inp['w_coarse']))
+    m.fine.load_state_dict(t(inp['w_fine']))
+    m.fine_preprocess.load_state_dict(t(inp['w_prep']))
+    w0, b0, w1, b1 = inp['mix']
+    with torch.no_grad():
+        m.fine_matching.mix_feat_0.weight.copy_(torch.as_tensor(w0).view(1, -1)); m.fine_matching.mix_feat_0.bias.fill_(float(b0))
+        m.fine_matching.mix_feat_1.weight.copy_(torch.as_tensor(w1).view(1, -1)); m.fine_matching.mix_feat_1.bias.fill_(float(b1))
+    dev = lambda x: torch.as_tensor(x, device=DEV)
+    data = {'bs': NET_TAIL['n'], 'hw0_i': inp['hw_i'], 'hw1_i': inp['hw_i']}
+    m.forward_features(dev(inp['feat_c0']), dev(inp['feat_c1']), dev(inp['feat_f0']), dev(inp['feat_f1']), data)
+    np.testing.assert_allclose(data['feat_c0'].double().sum((1, 2)).cpu().numpy(), g['c0_sum'], rtol=1e-5)
+    got = _np({k: data[k] for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts0_c', 'mkpts1_c')})
+    only_g, only_r, err = compare_match_sets(got, g)
+    assert all(abs(v - 0.2) < 1e-4 for _, v in only_g + only_r), (only_g, only_r)
+    assert err <= 1e-4, err
+    gk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(got['b_ids'], got['i_ids'], got['j_ids']))}
+    rk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(g['b_ids'], g['i_ids'], g['j_ids']))}
+    common = [k for k in gk if k in rk]
+    gi, ri = np.array([gk[k] for k in common]), np.array([rk[k] for k in common])
+    assert len(common) >= len(rk) - 2 and len(rk) > 80
+    assert np.array_equal(got['mkpts0_c'][gi], g['mkpts0_c'][ri])
+    assert np.abs(data['mkpts0_f'].cpu().numpy()[gi, :2] - g['mkpts0_f'][ri, :2]).max() <= 2e-3
+    assert np.abs(data['mkpts1_f'].cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= 2e-3
 
 
 # ------------------------------------------------------------------ match(img0, img1) facade

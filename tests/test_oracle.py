@@ -5,7 +5,7 @@ import torch
 
 from featurematching_amd import synth
 from oracle import matcher_ref as orc
-from helpers import load_golden, load_kats, case_inputs
+from helpers import load_golden, load_kats, case_inputs, net_tail_inputs, NET_TAIL
 
 
 def _check_coarse(out, g):
@@ -152,3 +152,34 @@ def test_context_merge_matches_reference(name, dist):
         np.testing.assert_allclose(m[:3].numpy(), g[key + '_head'], rtol=0, atol=2e-5)
         s = (m.double() * pos * ch).sum((1, 2)).numpy()
         np.testing.assert_allclose(s, g[key + '_sum'], rtol=0, atol=5e-2)       # sums of ~1e5 weighted terms
+
+
+def test_net_tail_matches_reference():
+    """Row a8: everything network/net.py:66-83 does after the backbone (coarse context layers -> coarse matching ->
+    window crop + context merge -> fine context layers -> fine matching), restated in oracle.net_tail, against the
+    fixture the reference's own modules produced for the same seeded feature maps and weights."""
+    g = load_golden("net_tail_small")
+    inp = net_tail_inputs()
+    out = orc.net_tail(inp['feat_c0'], inp['feat_c1'], inp['feat_f0'], inp['feat_f1'], inp['hw_i'], inp['w_coarse'],
+                       inp['w_fine'], inp['w_prep'], inp['mix'], NET_TAIL['layers_c'], NET_TAIL['layers_f'])
+    _check_coarse(out, g)
+    assert g['i_ids'].shape[0] > 80 and g['mconf'].min() < 0.5 < g['mconf'].max()
+    np.testing.assert_allclose(out['feat_c0'].double().sum((1, 2)).numpy(), g['c0_sum'], rtol=1e-6)
+    np.testing.assert_allclose(out['mkpts0_f'].numpy(), g['mkpts0_f'], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out['mkpts1_f'].numpy(), g['mkpts1_f'], rtol=0, atol=5e-5)
+
+
+def test_transformer_module_loads_reference_state_dict_names():
+    """featurematching_amd.transformer mirrors the reference's parameter names / shapes and its arithmetic: the
+    torch module (the product's PyTorch-ROCm side) and the oracle restatement agree on CPU."""
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    w = synth.transformer_weights(5, 64, 2)
+    tf = LocalFeatureTransformer(dict(d_model=64, nhead=8, layer_names=['self', 'cross'], attention='linear')).eval()
+    missing = tf.load_state_dict({k: torch.as_tensor(v) for k, v in w.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    x0 = torch.as_tensor(synth.normal(6, 1, (3, 49, 64)))
+    x1 = torch.as_tensor(synth.normal(6, 2, (3, 49, 64)))
+    with torch.no_grad():
+        a0, a1 = tf(x0, x1)
+    b0, b1 = orc.local_feature_transformer(x0, x1, w, 8, ['self', 'cross'])
+    assert (a0 - b0).abs().max() < 1e-5 and (a1 - b1).abs().max() < 1e-5
