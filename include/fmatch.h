@@ -208,6 +208,22 @@ int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t
                   const float* mkpts0_c, const float* mkpts1_c, float scale_f,
                   float* out0, float* out1, void* stream);
 
+/*
+ * Match post-processing (the step after the path; utils/metrics.py:33-81): squared symmetric epipolar distance
+ * of every match against a relative pose, and a RANSAC-free inlier score per pair.
+ *   mkpts0/mkpts1 [dev] float32 [m_max, kpt_stride] (x, y in pixels first; kpt_stride = 3 for the fine
+ *   keypoints [M,3], 2 for plain [M,2]); m_bids [dev] int64 [m_max] (data['m_bids']); the number of matches is
+ *   min(*d_count, m_max) when d_count != NULL.  T_0to1 [dev] float32 [N,4,4], K0/K1 [dev] float32 [N,3,3],
+ *   row-major.  E = [t]x R (:65-66), points normalised by their intrinsics (:41-42),
+ *   d = (p1.E p0)^2 (1/((E p0)_x^2 + (E p0)_y^2) + 1/((E^T p1)_x^2 + (E^T p1)_y^2))   (:47-56).
+ * Outputs: epi_errs float32 [m_max] (data['epi_errs']); optional inlier uint8 [m_max] (d < inlier_thr) and
+ * per_pair int32 [N,2] = {matches, inliers} per pair, which the caller zeroes beforehand (the kernel adds).
+ */
+int fm_epipolar_errors(const float* mkpts0, const float* mkpts1, int kpt_stride, const int64_t* m_bids,
+                       const int32_t* d_count, int m_max, int N, const float* T_0to1, const float* K0,
+                       const float* K1, float inlier_thr, float* epi_errs, unsigned char* inlier,
+                       int32_t* per_pair, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

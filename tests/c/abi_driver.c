@@ -44,6 +44,7 @@ static __typeof__(fm_merge_pack_weights)* p_fm_merge_pack_weights;
 static __typeof__(fm_gather_merge_windows)* p_fm_gather_merge_windows;
 static __typeof__(fm_gather_windows_pair)* p_fm_gather_windows_pair;
 static __typeof__(fm_fine_match)* p_fm_fine_match;
+static __typeof__(fm_epipolar_errors)* p_fm_epipolar_errors;
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s libfmatch_hip.so\n", argv[0]); return 2; }
@@ -54,7 +55,7 @@ int main(int argc, char** argv) {
   RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
-  RESOLVE(fm_fine_match);
+  RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
 
   EXPECT(p_fm_version(), FM_VERSION);
   for (int s = FM_E_RANGE; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
@@ -155,6 +156,11 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_fine_match(f, f, -3, NULL, 49, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_SHAPE);
   EXPECT(p_fm_fine_match(f, f, 3, NULL, 36, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_fine_match(f, f, 3, NULL, 49, 32, f, f, f, f, 2.f, f, f, NULL), FM_E_UNSUPPORTED);
+
+  EXPECT(p_fm_epipolar_errors(NULL, NULL, 3, NULL, NULL, 0, 1, NULL, NULL, NULL, 1e-4f, NULL, NULL, NULL, NULL), FM_OK);
+  EXPECT(p_fm_epipolar_errors(f, f, 3, ids, NULL, 5, 1, f, f, NULL, 1e-4f, f, NULL, NULL, NULL), FM_E_NULL);
+  EXPECT(p_fm_epipolar_errors(f, f, 1, ids, NULL, 5, 1, f, f, f, 1e-4f, f, NULL, NULL, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_epipolar_errors(f, f, 3, ids, NULL, 5, 0, f, f, f, 1e-4f, f, NULL, NULL, NULL), FM_E_SHAPE);
 
   printf("abi_driver: %d checks, %d failures\n", checks, failures);
   return failures ? 1 : 0;

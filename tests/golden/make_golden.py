@@ -289,6 +289,57 @@ def net_tail_case(name="net_tail_small"):
     print(f"{name}: M={d['i_ids'].shape[0]} conf range [{d['mconf'].min():.3f}, {d['mconf'].max():.3f}]")
 
 
+def epipolar_inputs(seed=51, n=3, m=240):
+    """Seeded matches / poses / intrinsics of the epi_small fixture (shared with the tests)."""
+    u = lambda st, shape: synth.uniform(seed, st, int(np.prod(shape))).reshape(shape)
+    b = np.sort((u(1, (m,)) * n).astype(np.int64))
+    k0 = np.concatenate([u(2, (m, 2)) * [640, 480], u(3, (m, 1))], 1).astype(np.float32)       # [M,3] like mkpts*_f
+    k1 = (k0 + np.concatenate([synth.normal(seed, 4, (m, 2)) * 6.0, np.zeros((m, 1))], 1)).astype(np.float32)
+    T = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    for i in range(n):
+        w = synth.normal(seed + i, 5, (3,)) * 0.2                      # small rotation (Rodrigues) + translation
+        th = float(np.linalg.norm(w)); kx = w / th
+        Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+        T[i, :3, :3] = (np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx).astype(np.float32)
+        T[i, :3, 3] = synth.normal(seed + i, 6, (3,)).astype(np.float32)
+    K = np.tile(np.array([[500.0, 0, 320], [0, 510, 240], [0, 0, 1]], np.float32), (n, 1, 1))
+    K0 = K + (u(7, (n, 3, 3)) * [[20, 0, 10], [0, 20, 10], [0, 0, 0]]).astype(np.float32)
+    K1 = K + (u(8, (n, 3, 3)) * [[20, 0, 10], [0, 20, 10], [0, 0, 0]]).astype(np.float32)
+    return dict(m_bids=b, mkpts0_f=k0, mkpts1_f=k1, T_0to1=T, K0=K0.astype(np.float32), K1=K1.astype(np.float32))
+
+
+def epipolar_case(name="epi_small"):
+    """utils/metrics.py:60-81 compute_symmetrical_epipolar_errors run from the reference's own file.  Its module
+    imports cv2, loguru and two kornia helpers that are not installed here: cv2 is not touched by this function
+    (empty stand-in); kornia's cross_product_matrix (skew-symmetric matrix of a vector) and
+    convert_points_to_homogeneous (append a 1) are restated - third-party, unpinned by the reference."""
+    cv2 = types.ModuleType("cv2")
+    sys.modules.setdefault("cv2", cv2)
+    epi = types.ModuleType("kornia.geometry.epipolar")
+    numeric = types.ModuleType("kornia.geometry.epipolar.numeric")
+
+    def cross_product_matrix(x):
+        z = torch.zeros_like(x[..., 0])
+        return torch.stack([torch.stack([z, -x[..., 2], x[..., 1]], -1), torch.stack([x[..., 2], z, -x[..., 0]], -1),
+                            torch.stack([-x[..., 1], x[..., 0], z], -1)], -2)
+    numeric.cross_product_matrix = cross_product_matrix
+    epi.numeric = numeric
+    conv = types.ModuleType("kornia.geometry.conversions")
+    conv.convert_points_to_homogeneous = lambda p: torch.cat([p, torch.ones_like(p[..., :1])], -1)
+    sys.modules["kornia.geometry.epipolar"] = epi
+    sys.modules["kornia.geometry.epipolar.numeric"] = numeric
+    sys.modules["kornia.geometry.conversions"] = conv
+    sys.modules["kornia.geometry"].epipolar = epi
+    sys.modules["kornia.geometry"].conversions = conv
+    from utils.metrics import compute_symmetrical_epipolar_errors
+    inp = epipolar_inputs()
+    data = {k: torch.as_tensor(v) for k, v in inp.items()}
+    compute_symmetrical_epipolar_errors(data)
+    e = data['epi_errs'].numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), epi_errs=e)
+    print(f"{name}: M={e.shape[0]} epi range [{e.min():.3e}, {e.max():.3e}], {int((e < 1e-4).sum())} below 1e-4")
+
+
 def kat_cases_round2():
     """Round-2 known-answer cases (kats_r2.npz): a per-sample scale0/scale1 case with many matches, and a pair
     of cases whose only difference is ONE float32 ulp of one descriptor's scale, chosen by bisection on the
@@ -362,9 +413,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "net_tail":
         net_tail_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "epi":
+        epipolar_case()
+        sys.exit(0)
     kat_cases()
     kat_cases_round2()
     net_tail_case()
+    epipolar_case()
     full_case("cfg1_peaky", "cfg1", "peaky")
     full_case("cfg1_borderline", "cfg1", "borderline")
     full_case("cfg2_peaky", "cfg2", "peaky")

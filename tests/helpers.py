@@ -75,3 +75,23 @@ def net_tail_inputs(meta=NET_TAIL):
     mix = synth.mix_weights(seed, 49)
     return dict(feat_c0=to_map(f0), feat_c1=to_map(f1), feat_f0=ff0, feat_f1=ff1, w_coarse=w_coarse, w_fine=w_fine,
                 w_prep=w_prep, mix=mix, hw_i=(meta['h'], meta['w']))
+
+
+def epipolar_inputs(seed=51, n=3, m=240):
+    """Seeded matches / poses / intrinsics of the epi_small fixture (tests/golden/make_golden.py:epipolar_inputs
+    restated)."""
+    u = lambda st, shape: synth.uniform(seed, st, int(np.prod(shape))).reshape(shape)
+    b = np.sort((u(1, (m,)) * n).astype(np.int64))
+    k0 = np.concatenate([u(2, (m, 2)) * [640, 480], u(3, (m, 1))], 1).astype(np.float32)
+    k1 = (k0 + np.concatenate([synth.normal(seed, 4, (m, 2)) * 6.0, np.zeros((m, 1))], 1)).astype(np.float32)
+    T = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    for i in range(n):
+        w = synth.normal(seed + i, 5, (3,)) * 0.2
+        th = float(np.linalg.norm(w)); kx = w / th
+        Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+        T[i, :3, :3] = (np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx).astype(np.float32)
+        T[i, :3, 3] = synth.normal(seed + i, 6, (3,)).astype(np.float32)
+    K = np.tile(np.array([[500.0, 0, 320], [0, 510, 240], [0, 0, 1]], np.float32), (n, 1, 1))
+    K0 = K + (u(7, (n, 3, 3)) * [[20, 0, 10], [0, 20, 10], [0, 0, 0]]).astype(np.float32)
+    K1 = K + (u(8, (n, 3, 3)) * [[20, 0, 10], [0, 20, 10], [0, 0, 0]]).astype(np.float32)
+    return dict(m_bids=b, mkpts0_f=k0, mkpts1_f=k1, T_0to1=T, K0=K0.astype(np.float32), K1=K1.astype(np.float32))

@@ -14,7 +14,7 @@ import torch
 from featurematching_amd import modules, ops, synth
 from featurematching_amd import _lib
 from oracle import matcher_ref as orc
-from helpers import load_golden, load_kats, case_inputs, compare_match_sets, net_tail_inputs, NET_TAIL
+from helpers import load_golden, load_kats, case_inputs, compare_match_sets, net_tail_inputs, NET_TAIL, epipolar_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -584,3 +584,27 @@ def test_pair_gather_equals_two_single_gathers(w):
                                      packed_w=packed, ctx0=ctx0, ctx1=ctx1)
     assert torch.equal(b0, ops.gather_merge_windows(ff0, packed, ctx0, o['b_ids'], o['i_ids'], w, 4, h0, w0))
     assert torch.equal(b1, ops.gather_merge_windows(ff1, packed, ctx1, o['b_ids'], o['j_ids'], w, 4, h1, w1, cells=cells[1]))
+
+
+# ------------------------------------------------------------------ the step after the path (8(f) row 4)
+def test_epipolar_errors_against_reference_fixture():
+    """fm_epipolar_errors vs the fixture the reference's compute_symmetrical_epipolar_errors (utils/metrics.py:60-81)
+    produced; the per-pair inlier score against the oracle's distances; drop-in form on a data dict."""
+    from featurematching_amd import post
+    g = load_golden("epi_small")
+    inp = epipolar_inputs()
+    t = {k: torch.as_tensor(v, device=DEV) for k, v in inp.items()}
+    epi, inl, per = post.epipolar_errors(t['mkpts0_f'], t['mkpts1_f'], t['m_bids'], t['T_0to1'], t['K0'], t['K1'],
+                                         inlier_thr=1e-2)
+    np.testing.assert_allclose(epi.cpu().numpy(), g['epi_errs'], rtol=2e-4, atol=1e-9)
+    ref_in = g['epi_errs'] < 1e-2
+    far = np.abs(g['epi_errs'] - 1e-2) > 1e-5
+    assert np.array_equal(inl.cpu().numpy()[far], ref_in[far])
+    per = per.cpu().numpy()
+    assert per[:, 0].tolist() == np.bincount(inp['m_bids'], minlength=3).tolist()
+    assert np.abs(per[:, 1] - np.bincount(inp['m_bids'], weights=ref_in, minlength=3)).max() <= (~far).sum()
+    data = dict(t)
+    post.compute_symmetrical_epipolar_errors(data)
+    assert torch.equal(data['epi_errs'], epi)
+    e0, i0, p0 = post.epipolar_errors(t['mkpts0_f'][:0], t['mkpts1_f'][:0], t['m_bids'][:0], t['T_0to1'], t['K0'], t['K1'])
+    assert e0.shape == (0,) and int(p0.sum()) == 0

@@ -5,7 +5,7 @@ import torch
 
 from featurematching_amd import synth
 from oracle import matcher_ref as orc
-from helpers import load_golden, load_kats, case_inputs, net_tail_inputs, NET_TAIL
+from helpers import load_golden, load_kats, case_inputs, net_tail_inputs, NET_TAIL, epipolar_inputs
 
 
 def _check_coarse(out, g):
@@ -183,3 +183,37 @@ def test_transformer_module_loads_reference_state_dict_names():
         a0, a1 = tf(x0, x1)
     b0, b1 = orc.local_feature_transformer(x0, x1, w, 8, ['self', 'cross'])
     assert (a0 - b0).abs().max() < 1e-5 and (a1 - b1).abs().max() < 1e-5
+
+
+def test_epipolar_errors_match_reference():
+    """utils/metrics.py:33-81 restated in oracle.symmetric_epipolar_errors, against the fixture
+    the reference's own compute_symmetrical_epipolar_errors produced."""
+    g = load_golden("epi_small")
+    inp = epipolar_inputs()
+    e = orc.symmetric_epipolar_errors(inp['mkpts0_f'], inp['mkpts1_f'], inp['m_bids'], inp['T_0to1'], inp['K0'], inp['K1'])
+    np.testing.assert_allclose(e.numpy(), g['epi_errs'], rtol=1e-5, atol=1e-9)
+    assert g['epi_errs'].shape == (240,) and (g['epi_errs'] > 0).all()
+
+
+def test_match_list_wire_format_roundtrip(tmp_path):
+    from featurematching_amd import post
+    from featurematching_amd import dist as fdist
+    inp = epipolar_inputs()
+    conf = torch.as_tensor(synth.uniform(9, 1, 240).astype(np.float32))
+    rec = fdist.pack_records(torch.as_tensor(inp['m_bids']), torch.as_tensor(inp['mkpts0_f']), torch.as_tensor(inp['mkpts1_f']),
+                             conf, pair_offset=7)
+    buf = post.dumps(rec)
+    assert buf[:4] == b"FMT1" and len(buf) == 16 + 240 * 24
+    assert int.from_bytes(buf[4:8], "little") == 1 and int.from_bytes(buf[8:12], "little") == 24
+    assert int.from_bytes(buf[16:20], "little") == int(inp['m_bids'][0]) + 7          # first record: int32 pair id
+    assert torch.equal(post.loads(buf), rec)
+    path = str(tmp_path / "m.fmt")
+    assert post.save_matches(path, torch.as_tensor(inp['m_bids']), torch.as_tensor(inp['mkpts0_f']),
+                             torch.as_tensor(inp['mkpts1_f']), conf) == 240
+    ids, k0, k1, c = post.load_matches(path)
+    assert torch.equal(ids, torch.as_tensor(inp['m_bids'])) and torch.equal(c, conf)
+    assert torch.equal(k0, torch.as_tensor(inp['mkpts0_f'][:, :2]))
+    with pytest.raises(ValueError):
+        post.loads(buf[:-3])
+    with pytest.raises(ValueError):
+        post.loads(b"XXXX" + buf[4:])
