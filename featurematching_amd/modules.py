@@ -29,9 +29,13 @@ logger = logging.getLogger("featurematching_amd")
 class CoarseMatching(nn.Module):
     """`conf_matrix=True` also materialises the dense data['conf_matrix'] [N,L,S] the reference
     always writes (coarse_matching_new.py:70; only its training loss reads it) - one more sweep and
-    N*L*S*4 bytes, so it is opt-in; it is required in training mode."""
+    N*L*S*4 bytes, so it is opt-in; it is required in training mode, where it carries the gradient of the dual
+    softmax back to the descriptors (ops.attach_conf_matrix_grad).
+    `gt_pad_sampler=True` selects the older training sampler (network/utils/coarse_matching.py:114-141: predicted
+    matches sub-sampled to train_coarse_percent and padded with ground-truth matches up to train_pad_num_gt_min)
+    instead of coarse_matching_new.py's plain substitution of the supervision ids (:113-116)."""
 
-    def __init__(self, config, conf_matrix: bool = False):
+    def __init__(self, config, conf_matrix: bool = False, gt_pad_sampler: bool = False):
         super().__init__()
         self.config = config
         self.thr = config['thr']
@@ -40,27 +44,47 @@ class CoarseMatching(nn.Module):
         self.train_pad_num_gt_min = config.get('train_pad_num_gt_min', 200)
         self.temperature = config['dsmax_temperature']
         self.conf_matrix = conf_matrix
+        self.gt_pad_sampler = gt_pad_sampler
 
-    @torch.no_grad()
     def forward(self, feat_c0, feat_c1, data, mask_c0=None, mask_c1=None):
         """Writes b_ids, i_ids, j_ids, gt_mask, m_bids, mkpts0_c, mkpts1_c, mconf (and conf_matrix on
         request) into ``data`` (coarse_matching_new.py:70,118-141).  mask_c0/mask_c1 are accepted and
         ignored, as in the reference.  In training mode the ids that select the fine windows are the
-        supervision ids data['spv_*_ids'] (:113-116); the kernels are forward-only, so no gradient
-        flows through conf_matrix."""
+        supervision ids data['spv_*_ids'] (:113-116); data['conf_matrix'] then carries the gradient of the dual
+        softmax (the match lists themselves are not differentiable, as in the reference's @torch.no_grad
+        get_coarse_match)."""
         if self.training and not self.conf_matrix:
             raise RuntimeError("training-mode CoarseMatching needs conf_matrix=True (the loss reads data['conf_matrix'])")
         scale = data['hw0_i'][0] / data['hw0_c'][0]
-        out = ops.coarse_match(feat_c0, feat_c1, data['hw0_c'], data['hw1_c'], scale, self.thr, self.border_rm,
-                               self.temperature, data.get('scale0'), data.get('scale1'),
-                               conf_matrix=self.conf_matrix)
+        with torch.no_grad():
+            out = ops.coarse_match(feat_c0, feat_c1, data['hw0_c'], data['hw1_c'], scale, self.thr, self.border_rm,
+                                   self.temperature, data.get('scale0'), data.get('scale1'),
+                                   conf_matrix=self.conf_matrix)
         if self.conf_matrix:
-            data.update({'conf_matrix': out['conf_matrix']})
+            conf = out['conf_matrix']
+            if torch.is_grad_enabled() and (feat_c0.requires_grad or feat_c1.requires_grad):
+                conf = ops.attach_conf_matrix_grad(feat_c0, feat_c1, conf, self.temperature)
+            data.update({'conf_matrix': conf})
         mconf = out['mconf']
         b_ids, i_ids, j_ids = out['b_ids'], out['i_ids'], out['j_ids']
         mkpts0_c, mkpts1_c = out['mkpts0_c'], out['mkpts1_c']
-        if self.training:                                                    # :113-116, :126-134
+        if self.training and self.gt_pad_sampler:                            # coarse_matching.py:114-141
+            n, l, s = feat_c0.shape[0], feat_c0.shape[1], feat_c1.shape[1]
+            num_train = int(n * max(l, s) * self.train_coarse_percent)
+            num_pred = b_ids.shape[0]
+            assert self.train_pad_num_gt_min < num_train, "min-num-gt-pad should be less than num-train-matches"
+            dev = b_ids.device
+            if num_pred <= num_train - self.train_pad_num_gt_min:
+                pred_idx = torch.arange(num_pred, device=dev)
+            else:
+                pred_idx = torch.randint(num_pred, (num_train - self.train_pad_num_gt_min,), device=dev)
+            gt_idx = torch.randint(len(data['spv_b_ids']), (max(num_train - num_pred, self.train_pad_num_gt_min),), device=dev)
+            pick = lambda pred, gt: torch.cat([pred[pred_idx], gt[gt_idx]], dim=0)
+            b_ids, i_ids, j_ids = pick(b_ids, data['spv_b_ids']), pick(i_ids, data['spv_i_ids']), pick(j_ids, data['spv_j_ids'])
+            mconf = pick(mconf, torch.zeros(len(data['spv_b_ids']), device=dev))    # padded ground truth: mconf == 0
+        elif self.training:                                                  # :113-116, :126-134
             b_ids, i_ids, j_ids = data['spv_b_ids'], data['spv_i_ids'], data['spv_j_ids']
+        if self.training:                                                    # keypoints of the ids in use
             scale0 = scale * data['scale0'][b_ids] if 'scale0' in data else scale
             scale1 = scale * data['scale1'][b_ids] if 'scale1' in data else scale
             w0c, w1c = data['hw0_c'][1], data['hw1_c'][1]
@@ -70,7 +94,7 @@ class CoarseMatching(nn.Module):
             data['_fm_coarse'] = out['_coarse_buffers']
         data.update({'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids,
                      'gt_mask': mconf == 0, 'm_bids': b_ids,
-                     'mkpts0_c': mkpts0_c, 'mkpts1_c': mkpts1_c, 'mconf': mconf})
+                     'mkpts0_c': mkpts0_c, 'mkpts1_c': mkpts1_c, 'mconf': mconf[mconf != 0]})   # :137-141
 
 
 class FinePreprocess(nn.Module):

@@ -181,6 +181,45 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
     raise RuntimeError("coarse_match: overflow persisted after retries")
 
 
+class _ConfMatrixGrad(torch.autograd.Function):
+    """Attaches the gradient of the dual softmax to the conf_matrix the HIP forward produced, so that the
+    reference's coarse loss (losses/loss.py:27-67 reads data['conf_matrix']) trains the descriptors.
+
+    conf = A * B with A = softmax(sim, dim 1), B = softmax(sim, dim 2), sim = f0 . f1^T / (C T)
+    (coarse_matching_new.py:64-68).  With G = dL/dconf and c = conf:
+        dL/dsim = 2 G c - A u - B v,   u_j = sum_i (G c)_ij,   v_i = sum_j (G c)_ij
+        dL/df0  = dL/dsim . f1 / (C T),   dL/df1 = dL/dsim^T . f0 / (C T)
+    The forward values come from the HIP kernels; the backward recomputes A and B with torch ops and uses plain
+    library GEMMs (three dense [N,L,S] temporaries - training only)."""
+
+    @staticmethod
+    def forward(ctx, feat_c0, feat_c1, conf, temperature):
+        ctx.save_for_backward(feat_c0, feat_c1, conf)
+        ctx.temperature = float(temperature)
+        return conf.view_as(conf)
+
+    @staticmethod
+    def backward(ctx, grad):
+        f0, f1, conf = ctx.saved_tensors
+        k = 1.0 / (f0.shape[-1] * ctx.temperature)
+        sim = torch.bmm(f0.float(), f1.float().transpose(1, 2)) * k
+        gc = grad * conf
+        a = torch.softmax(sim, dim=1)
+        dsim = 2.0 * gc - a * gc.sum(dim=1, keepdim=True)
+        del a
+        dsim -= torch.softmax(sim, dim=2) * gc.sum(dim=2, keepdim=True)
+        del sim, gc
+        g0 = torch.bmm(dsim, f1.float()) * k
+        g1 = torch.bmm(dsim.transpose(1, 2), f0.float()) * k
+        return g0.to(f0.dtype), g1.to(f1.dtype), None, None
+
+
+def attach_conf_matrix_grad(feat_c0: torch.Tensor, feat_c1: torch.Tensor, conf_matrix: torch.Tensor,
+                            temperature: float) -> torch.Tensor:
+    """conf_matrix (from coarse_match(..., conf_matrix=True)) as a differentiable function of the descriptors."""
+    return _ConfMatrixGrad.apply(feat_c0, feat_c1, conf_matrix, temperature)
+
+
 def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor, w: int, stride: int,
                    w_c: int, pad: int = 2, count: Optional[torch.Tensor] = None,
                    out: Optional[torch.Tensor] = None, cells=None, h_c: Optional[int] = None) -> torch.Tensor:

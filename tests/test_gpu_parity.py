@@ -458,6 +458,65 @@ def test_dense_conf_matrix_and_training_ids():
         modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1}).train()(t0, t1, dict(data))
 
 
+def test_conf_matrix_carries_the_dual_softmax_gradient():
+    """the reference's coarse loss reads data['conf_matrix'] (losses/loss.py:27-67, sparse focal
+    loss on the ground-truth entries); the conf_matrix of the HIP forward must hand the same gradient to the
+    descriptors as autograd through the reference's own expression (coarse_matching_new.py:64-68)."""
+    f0, f1 = synth.coarse_descriptors(17, 2, 12 * 16, 64, "borderline")
+    hw_c, hw_i = (12, 16), (96, 128)
+    a0 = torch.as_tensor(f0, device=DEV).requires_grad_(True)
+    a1 = torch.as_tensor(f1, device=DEV).requires_grad_(True)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    gt = torch.stack([torch.randint(2, (60,), generator=g), torch.randint(192, (60,), generator=g),
+                      torch.randint(192, (60,), generator=g)], 1).to(DEV)
+
+    def focal(conf):       # compute_coarse_loss, 'focal', sparse supervision (loss.py:53-60), alpha 0.25 gamma 2
+        p = torch.clamp(conf, 1e-6, 1 - 1e-6)[gt[:, 0], gt[:, 1], gt[:, 2]]
+        return (-0.25 * torch.pow(1 - p, 2.0) * p.log()).mean()
+
+    cm = modules.CoarseMatching({'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1}, conf_matrix=True).train()
+    spv = dict(spv_b_ids=gt[:, 0].contiguous(), spv_i_ids=gt[:, 1].contiguous(), spv_j_ids=gt[:, 2].contiguous())
+    data = dict(hw0_i=hw_i, hw1_i=hw_i, hw0_c=hw_c, hw1_c=hw_c, **spv)
+    cm(a0, a1, data)
+    assert data['conf_matrix'].requires_grad
+    focal(data['conf_matrix']).backward()
+    # the reference's expression under autograd
+    b0 = torch.as_tensor(f0, device=DEV, dtype=torch.float64).requires_grad_(True)
+    b1 = torch.as_tensor(f1, device=DEV, dtype=torch.float64).requires_grad_(True)
+    sim = torch.einsum("nlc,nsc->nls", b0 / 64 ** .5, b1 / 64 ** .5) / 0.1
+    focal(torch.softmax(sim, 1) * torch.softmax(sim, 2)).backward()
+    for got, ref in ((a0.grad, b0.grad), (a1.grad, b1.grad)):
+        scale = ref.abs().max().item()
+        assert scale > 0 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
+
+
+def test_gt_padding_sampler():
+    """The older training sampler (network/utils/coarse_matching.py:114-141): predicted matches (sub-sampled when
+    there are too many) followed by randomly drawn ground-truth matches with mconf = 0; gt_mask marks them and
+    data['mconf'] drops them (:137-141)."""
+    f0, f1 = synth.coarse_descriptors(19, 2, 12 * 16, 64, "peaky")
+    hw_c, hw_i = (12, 16), (96, 128)
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    spv = dict(spv_b_ids=torch.tensor([0, 1, 1], device=DEV), spv_i_ids=torch.tensor([40, 7, 100], device=DEV),
+               spv_j_ids=torch.tensor([41, 8, 5], device=DEV))
+    cfg = {'thr': 0.2, 'border_rm': 2, 'dsmax_temperature': 0.1, 'train_coarse_percent': 1.0, 'train_pad_num_gt_min': 20}
+    ev = dict(hw0_i=hw_i, hw1_i=hw_i, hw0_c=hw_c, hw1_c=hw_c)
+    modules.CoarseMatching(cfg).eval()(t0, t1, ev)
+    m_pred = ev['b_ids'].shape[0]
+    data = dict(hw0_i=hw_i, hw1_i=hw_i, hw0_c=hw_c, hw1_c=hw_c, **spv)
+    modules.CoarseMatching(cfg, conf_matrix=True, gt_pad_sampler=True).train()(t0, t1, data)
+    num_train = 2 * 192
+    n_gt = max(num_train - m_pred, 20)
+    assert data['b_ids'].shape[0] == m_pred + n_gt and m_pred <= num_train - 20
+    assert torch.equal(data['i_ids'][:m_pred], ev['i_ids']) and torch.equal(data['j_ids'][:m_pred], ev['j_ids'])
+    gtp = torch.stack([data['b_ids'][m_pred:], data['i_ids'][m_pred:], data['j_ids'][m_pred:]], 1).cpu().tolist()
+    assert all(tuple(r) in {(0, 40, 41), (1, 7, 8), (1, 100, 5)} for r in gtp)
+    assert data['gt_mask'].sum().item() == n_gt and not data['gt_mask'][:m_pred].any()
+    assert data['mconf'].shape[0] == m_pred and torch.equal(data['mconf'], ev['mconf'])
+    assert data['mkpts0_c'].shape == (m_pred + n_gt, 2)
+    assert data['mkpts0_c'][m_pred:].cpu().tolist() == [[(r[1] % 16) * 8.0, (r[1] // 16) * 8.0] for r in gtp]
+
+
 # ------------------------------------------------------------------ cell-ordered window crops
 @pytest.mark.parametrize("w", [5, 7])
 def test_cell_ordered_gather_equals_list_ordered_gather(w):
