@@ -47,6 +47,9 @@ SIGNATURES = {
     "fm_gather_merge_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "fm_gather_windows_pair": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p,
                                     _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "fm_fine_tf_packed_bytes": (C.c_size_t, []),
+    "fm_fine_tf_pack_weights": (_i, [_p, _p, _p, _p]),
+    "fm_fine_transformer": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "fm_epipolar_errors": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
 }

@@ -346,3 +346,40 @@ def fine_match(win0: torch.Tensor, win1: torch.Tensor, mix0: torch.Tensor, mix1:
                            _stream(dev))
     _lib.check(st, "fm_fine_match")
     return out0, out1
+
+
+_TF_NAMES = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight",
+             "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+def pack_fine_transformer(state_dict: dict, device) -> torch.Tensor:
+    """state dict of a fine LocalFeatureTransformer (layers.0 = 'self', layers.1 = 'cross'; d_model 64, 8 heads) ->
+    the packed operand fragments fm_fine_transformer reads (fm_fine_tf_pack_weights)."""
+    lib = _lib.load()
+    keep, arrs = [], []
+    for l in range(2):
+        ptrs = []
+        for name in _TF_NAMES:
+            t = state_dict[f"layers.{l}.{name}"].detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            ptrs.append(t.data_ptr())
+        arrs.append((C.c_void_p * 10)(*ptrs))
+    shapes = [tuple(t.shape) for t in keep[:10]]
+    if shapes != [(64, 64)] * 4 + [(128, 128), (64, 128)] + [(64,)] * 4:
+        raise ValueError(f"fm_fine_transformer serves d_model 64 only, got {shapes}")
+    packed = torch.empty(int(lib.fm_fine_tf_packed_bytes()), dtype=torch.uint8, device=device)
+    _lib.check(lib.fm_fine_tf_pack_weights(arrs[0], arrs[1], _ptr(packed), _stream(packed.device)), "fm_fine_tf_pack_weights")
+    torch.cuda.current_stream(packed.device).synchronize()       # the sources in `keep` may be freed after this
+    return packed
+
+
+def fine_transformer(win0: torch.Tensor, win1: torch.Tensor, packed: torch.Tensor, count: Optional[torch.Tensor] = None):
+    """The fine context layers (network/net.py:79-80) on the windows [M, WW, 64] of both images, WW in {25, 49}."""
+    lib = _lib.load()
+    win0, win1 = _f32c(win0, "win0"), _f32c(win1, "win1")
+    m, ww, cf = win0.shape
+    out0, out1 = torch.empty_like(win0), torch.empty_like(win1)
+    if m:
+        _lib.check(lib.fm_fine_transformer(_ptr(win0), _ptr(win1), m, _ptr(count), ww, cf, _ptr(packed), _ptr(out0),
+                                           _ptr(out1), _stream(win0.device)), "fm_fine_transformer")
+    return out0, out1

@@ -209,6 +209,22 @@ int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t
                   float* out0, float* out1, void* stream);
 
 /*
+ * Fine-level context layers between the window crop and the fine matching (network/net.py:79-80): the reference's
+ * LocalFeatureTransformer (network/module/transformer.py:34-57,78-96, attentions.py:19-46) in its default fine
+ * configuration - d_model 64, 8 heads, layer_names ['self', 'cross'], linear attention, no masks - as ONE kernel,
+ * one wave per match, activations in registers from the window load to the window store, float32-equivalent
+ * products (hi/lo-split float16 MFMAs).  win0/win1, out0/out1 [dev] float32 [m_max, WW, 64], WW in {25, 49}; out may
+ * alias win.  packed = fm_fine_tf_packed_bytes() bytes [dev] filled once per weight update by
+ * fm_fine_tf_pack_weights(layer0, layer1, ...): each a HOST array of 10 DEVICE pointers in state-dict order -
+ * q_proj, k_proj, v_proj, merge .weight [64,64]; mlp.0.weight [128,128]; mlp.2.weight [64,128]; norm1.weight,
+ * norm1.bias, norm2.weight, norm2.bias [64] - of layers.0 ('self') and layers.1 ('cross').
+ */
+size_t fm_fine_tf_packed_bytes(void);
+int fm_fine_tf_pack_weights(const float* const* layer0, const float* const* layer1, void* packed, void* stream);
+int fm_fine_transformer(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
+                        const void* packed, float* out0, float* out1, void* stream);
+
+/*
  * Match post-processing (the step after the path; utils/metrics.py:33-81): squared symmetric epipolar distance
  * of every match against a relative pose, and a RANSAC-free inlier score per pair.
  *   mkpts0/mkpts1 [dev] float32 [m_max, kpt_stride] (x, y in pixels first; kpt_stride = 3 for the fine

@@ -667,3 +667,20 @@ def test_epipolar_errors_against_reference_fixture():
     assert torch.equal(data['epi_errs'], epi)
     e0, i0, p0 = post.epipolar_errors(t['mkpts0_f'][:0], t['mkpts1_f'][:0], t['m_bids'][:0], t['T_0to1'], t['K0'], t['K1'])
     assert e0.shape == (0,) and int(p0.sum()) == 0
+
+
+# ------------------------------------------------------------------ fine context layers in HIP (8(f) row 1)
+@pytest.mark.parametrize("w", [7, 5])
+def test_fine_transformer_vs_oracle(w):
+    """fm_fine_transformer (one wave per match, activations in registers, hi/lo-split MFMAs) against the oracle's
+    restatement of the reference's LocalFeatureTransformer (pinned by net_tail_small) on seeded windows/weights."""
+    ww, m = w * w, 37
+    wts = synth.transformer_weights(77, 64, 2)
+    x0 = synth.normal(78, 1, (m, ww, 64)).astype(np.float32)
+    x1 = synth.normal(78, 2, (m, ww, 64)).astype(np.float32)
+    r0, r1 = orc.local_feature_transformer(x0, x1, wts, 8, ['self', 'cross'])
+    packed = ops.pack_fine_transformer({k: torch.as_tensor(v) for k, v in wts.items()}, DEV)
+    g0, g1 = ops.fine_transformer(torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV), packed)
+    e0 = (g0.cpu() - r0).abs().max().item()
+    e1 = (g1.cpu() - r1).abs().max().item()
+    assert e0 <= 2e-5 and e1 <= 2e-5, (e0, e1)
