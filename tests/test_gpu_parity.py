@@ -684,3 +684,13 @@ def test_fine_transformer_vs_oracle(w):
     e0 = (g0.cpu() - r0).abs().max().item()
     e1 = (g1.cpu() - r1).abs().max().item()
     assert e0 <= 2e-5 and e1 <= 2e-5, (e0, e1)
+    # the module takes the kernel by itself in inference, its torch ops otherwise
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    tf = LocalFeatureTransformer(dict(d_model=64, nhead=8, layer_names=['self', 'cross'], attention='linear')).to(DEV).eval()
+    tf.load_state_dict({k: torch.as_tensor(v) for k, v in wts.items()})
+    t0, t1 = torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV)
+    with torch.no_grad():
+        a0, _ = tf(t0, t1)
+    assert torch.equal(a0, g0)
+    b0, _ = tf(t0, t1)                       # grad mode: torch ops
+    assert not torch.equal(b0, g0) and (b0.detach() - g0).abs().max().item() <= 2e-5
