@@ -37,6 +37,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // matrix cores, as in the coarse stage: window values and weights are split x = hi + lo (f16 each) and
 // hi*hi + lo*hi + hi*lo is accumulated in f32 (~2^-22 relative).  wpack = the weights pre-split into MFMA B
 // fragments by fm_merge_pack_weights: [n-tile 2][k-step 4][hi|lo][lane 64] x 8 halfs.
+// Both operands carry exact power-of-two scales (window values x kMergeActScale, weights x kMergeWgtScale, undone on
+// the accumulator): the matrix cores flush float16 SUBNORMAL inputs, and the lo half of anything below 2^-3 - every
+// weight of a 128-wide Linear layer - would be one (see fine_tf.hip).
+constexpr float kMergeActScale = 256.f;       // |window value| < 256 stays inside float16
+constexpr float kMergeWgtScale = 4096.f;
 template <int W>
 __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const half8* __restrict__ wpack,
                                                 const float* __restrict__ ctx_row) {
@@ -64,9 +69,10 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
       const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const _Float16 hh = (_Float16)x[e];
+        const float xs = x[e] * kMergeActScale;
+        const _Float16 hh = (_Float16)xs;
         ahi[mt][ks][e] = hh;
-        alo[mt][ks][e] = (_Float16)(x[e] - (float)hh);
+        alo[mt][ks][e] = (_Float16)(xs - (float)hh);
       }
     }
   }
@@ -77,7 +83,7 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
     for (int nt = 0; nt < 2; ++nt) {
       f32x16 acc;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) acc[g] = nt ? c1 : c0;       // column n = 32*nt + r of the output
+      for (int g = 0; g < 16; ++g) acc[g] = (nt ? c1 : c0) * (kMergeActScale * kMergeWgtScale);   // column n = 32*nt + r
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mt][ks], bhi[nt][ks], acc, 0, 0, 0);
@@ -87,7 +93,7 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int row = 32 * mt + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (row < WW) tile[row * PITCH + 32 * nt + r] = acc[g];
+        if (row < WW) tile[row * PITCH + 32 * nt + r] = acc[g] * (1.0f / (kMergeActScale * kMergeWgtScale));
       }
     }
   }
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(256) void k_merge_pack(const float* __restrict__ me
   half8 hh, ll;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float x = src[j];
+    const float x = src[j] * kMergeWgtScale;
     hh[j] = (_Float16)x;
     ll[j] = (_Float16)(x - (float)hh[j]);
   }
