@@ -37,6 +37,7 @@ SIGNATURES = {
     "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
     "fm_debug_launch_corr": (_i, [_p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "fm_debug_launch_sum_sparse": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "fm_debug_launch_prep_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "fm_read_count": (_i, [_p, _i, C.POINTER(C.c_int32), _p]),
     "fm_gather_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),

@@ -82,6 +82,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.l1_0 = take(rows * 4); w.l1_1 = take(cols * 4);
   w.bl1_0 = take(rows / 32 * 4); w.bl1_1 = take(cols / 32 * 4);
   w.emarg = take((size_t)N * 4);
+  w.f16inv = take((size_t)N * 4);
   w.rowS = take(rows * w.splits_s * 4); w.colS = take(cols * w.panels * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * kColParts * 4);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
@@ -201,6 +202,10 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   // flags the units with too many significant entries (flat similarity) for the dense kernel
   e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, st);
   if (e != hipSuccess) return (int)e;
+  // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or the
+  // conf_matrix sweep will run); exits at once otherwise
+  e = launch_prep_f16(feat0, feat1, in_dtype, C, w, base, (exact_screening || conf_matrix) ? 1 : 0, st);
+  if (e != hipSuccess) return (int)e;
   // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
   // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
   e = launch_corr(1, w, base, inv_ct, thr, st);
@@ -263,6 +268,17 @@ extern "C" int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, c
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   return (int)launch_sum_sparse(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr,
                                 (hipStream_t)stream);
+}
+
+// Diagnostic: launch the float16 plane kernel alone (force = 1: every sample; 0: the samples flagged for the dense
+// kernel) on a workspace a previous fm_coarse_match filled.
+extern "C" int fm_debug_launch_prep_f16(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
+                                        int C, int cand_slots, int force, void* stream) {
+  if (!workspace || !feat0 || !feat1) return FM_E_NULL;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  return (int)launch_prep_f16(feat0, feat1, FM_F32, C, w, (char*)workspace, force, (hipStream_t)stream);
 }
 
 // Diagnostic: zero the candidate counters and the scalars, so that the sum kernels can be launched again on a

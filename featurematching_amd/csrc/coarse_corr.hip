@@ -71,7 +71,8 @@ struct CorrArgs {
   float* umax;            // [N][Lp/32][Sp/32] unit maxima of the raw f16 product (written by MODE 0)
   const int* dense_cnt;   // [N] units per sample the sparse sum kernel left to the dense one (> 0: MODE 1 redoes the sample)
   const int* dense_units; // their total (0: MODE 1 has nothing to do)
-  const float* emarg;     // [N] log2-domain bound of |f16 product - exact product| * k
+  const float* emarg;     // [N] log2-domain bound of |screening product - exact product| * k
+  const float* f16inv;    // [N] 1 / (power-of-two scales of the two images' float16 planes): accumulator -> dot product
   int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
   int* cand_count_b; int* cand_j_b; float* cand_x_b;   // the dense kernel's candidate set (samples it redid)
   float* conf;            // MODE 3: dense [N,L,S] output
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
   if (MODE == 1 && a.dense_cnt[b] == 0) return;      // uniform: this sample was handled by the sparse sum kernel
+  const float inv_sc = a.f16inv[b];                  // the planes carry exact power-of-two scales (k_prep_f16)
+  const float kq = a.k * inv_sc;                     // accumulator -> log2-domain similarity
   // candidate set of this sample: the dense kernel's own for the samples it redoes
   const bool dense_sample = MODE == 1 || (MODE == 2 && a.dense_cnt[b] != 0);
   int* const cand_count = dense_sample ? a.cand_count_b : a.cand_count;
@@ -404,8 +407,8 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
         for (int e = 0; e < 4; ++e) {
           const int row = wrow0 + 8 * q + 4 * h + e;
           const float x = acc[4 * q + e];
-          const float cf = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, nm[e])) *
-                           __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, nmc));
+          const float cf = __builtin_amdgcn_exp2f(__builtin_fmaf(x, kq, nm[e])) *
+                           __builtin_amdgcn_exp2f(__builtin_fmaf(x, kq, nmc));
           if (row < a.L && cvalid) a.conf[((long)b * a.L + row) * a.S + col] = cf;
         }
       }
@@ -426,8 +429,8 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const float x = acc[g];
-        const float rr = __builtin_fmaf(x, a.k, nmr[g]);   // x = -inf for padded rows / columns
-        const float cc = __builtin_fmaf(x, a.k, nmc);
+        const float rr = __builtin_fmaf(x, kq, nmr[g]);   // x = -inf for padded rows / columns
+        const float cc = __builtin_fmaf(x, kq, nmc);
         if (MODE == 1) {
           rstat[g] += __builtin_amdgcn_exp2f(rr);
           cstat += __builtin_amdgcn_exp2f(cc);
@@ -453,15 +456,15 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
           for (int e = 0; e < 4; ++e) {
             const int g = 4 * q + e;
             const float x = acc[g];
-            const float rr = __builtin_fmaf(x, a.k, nmr[g]);
-            const float cc = __builtin_fmaf(x, a.k, nmc);
+            const float rr = __builtin_fmaf(x, kq, nmr[g]);
+            const float cc = __builtin_fmaf(x, kq, nmc);
             const int rl = rbase + e;                             // row inside this wave's 32
             if (rr > a.lt && cc > a.lt && wrow0 + rl < a.L && cvalid) {
               int qi;                                             // LDS atomic on the wave-private counter
               { const int one = 1;
                 asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(qi) : "v"(qcnt_a), "v"(one) : "memory"); }
-              if (qi < kCandQueue) { lds_store_b32(qkey_a + qi * 4, (col << 5) | rl); lds_store_b32(qx_a + qi * 4, x); }
-              else record_candidate((long)b * a.Lp + wrow0 + rl, col, x);     // queue full: straight to the lists
+              if (qi < kCandQueue) { lds_store_b32(qkey_a + qi * 4, (col << 5) | rl); lds_store_b32(qx_a + qi * 4, x * inv_sc); }
+              else record_candidate((long)b * a.Lp + wrow0 + rl, col, x * inv_sc);     // queue full: straight to the lists
             }
           }
         }
@@ -655,6 +658,7 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.cand_x_b = (float*)(base + w.cand_conf_b);
   a.dense_units = &((const Scalars*)(base + w.scalars))->dense_units;
   a.umax = (float*)(base + w.umax); a.emarg = (const float*)(base + w.emarg);
+  a.f16inv = (const float*)(base + w.f16inv);
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
   a.cand_x = (float*)(base + w.cand_conf);   // raw dot product now, replaced by conf in k_cand_conf
   a.flags = (unsigned*)(base + w.scalars);

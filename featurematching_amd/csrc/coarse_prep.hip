@@ -18,7 +18,9 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 struct PrepArgs {
   const void* src0; const void* src1; int in_dtype;      // FM_F32 / FM_F16 / FM_BF16 rows [N, rows, c_in]
-  _Float16* hi0; _Float16* lo0; _Float16* hi1; _Float16* lo1;
+  _Float16* hi0; _Float16* lo0; _Float16* hi1; _Float16* lo1;      // k_prep_f16 only
+  const int* dense_cnt; int force; float* f16inv;        // k_prep_f16: which samples need planes; 1 / (scale0 scale1)
+  const float* bsig0r; const float* bsig1r; int N;
   signed char* q0; signed char* q1;   // int8 screening planes (fragment-major for v_mfma_i32_32x32x32_i8)
   float* sig0; float* sig1;           // quantisation step of every descriptor (row)
   float* bsig0; float* bsig1;         // largest step per 32-row block
@@ -37,7 +39,8 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 // C = padded channel count of the planes (64/128/256); c_in <= C = channels of the source rows,
 // the planes are zero beyond c_in (a dot product does not change under zero padding).
 //   All planes are FRAGMENT-major, one workgroup per 32-row block.
-//   float16 planes (hi, lo = x - hi; the dense sum kernel's float32-equivalent product): element (row, k) lives at
+//   float16 planes (hi, lo = x - hi; the dense sum kernel's float32-equivalent product) are written by k_prep_f16
+//   below, only for the samples that need them: element (row, k) lives at
 //     (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8   with chunk q = k/8 = h*KSTEPS + ks,
 //   i.e. the 64 lanes (h, row%32) of a v_mfma_f32_32x32x16_f16 operand fragment are one contiguous 1 KiB block
 //   per (32-row block, k-step).
@@ -52,7 +55,6 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 // turns that into FM_DEV_RANGE (the flag word itself is cleared by this kernel, so it cannot be set here).
 template <int C>
 __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
-  constexpr int KSTEPS = C / 16;
   constexpr int KS8 = C / 32;
   constexpr int NCH = C / 8 / 8;          // 8-channel chunks per thread
   const int tid = threadIdx.x;
@@ -67,8 +69,6 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   const bool img1 = (int)blockIdx.x >= a.blocks0;
   const long rb = img1 ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;   // row block over N*Lp/32 (N*Sp/32)
   const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
-  _Float16* const hi = img1 ? a.hi1 : a.hi0;
-  _Float16* const lo = img1 ? a.lo1 : a.lo0;
   signed char* const qp = img1 ? a.q1 : a.q0;
   const int b = (int)(rb * 32 / rows_pad);
   const int r = tid & 31;
@@ -101,19 +101,11 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
     bad = bad || bad_value(v0) || bad_value(v1);
     x[n][0] = v0.x; x[n][1] = v0.y; x[n][2] = v0.z; x[n][3] = v0.w;
     x[n][4] = v1.x; x[n][5] = v1.y; x[n][6] = v1.z; x[n][7] = v1.w;
-    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-    half8 hh, ll;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      hh[e] = (_Float16)x[n][e];
-      ll[e] = (_Float16)(x[n][e] - (float)hh[e]);
       s1 += fabsf(x[n][e]);
       amax = fmaxf(amax, fabsf(x[n][e]));
     }
-    const int h = q / KSTEPS, ks = q - h * KSTEPS;
-    const long off = (((rb * KSTEPS + ks) * 2 + h) * 32 + r) * 8;
-    *reinterpret_cast<half8*>(hi + off) = hh;
-    *reinterpret_cast<half8*>(lo + off) = ll;
   }
   // per-row maximum of |x| -> quantisation step; per-row L1 norms (a row's channels sit in 8 threads)
   __shared__ float sm2[8][33];
@@ -165,9 +157,85 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   }
 }
 
-hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                       hipStream_t st) {
-  PrepArgs a;
+// The float16 hi / lo planes of the samples the dense sum kernel will redo (dense_cnt[b] > 0), or of every sample
+// when `force` (the exact-screening and conf_matrix sweeps read them too).  Peaked data never needs them: 9.8 MB of
+// writes per 640x480 pair that k_prep_split used to do unconditionally.
+// Each image of a sample is scaled by an exact power of two that brings its largest |x| into [2^13, 2^14) before the
+// split: the matrix cores flush float16 SUBNORMAL inputs, so without it the lo half of every value below 2^-3 -
+// |lo| ~ 2^-12 |x| < 2^-14 - would be lost (such elements would carry 11 instead of 22 bits).  f16inv[b] = 1 / (scale0
+// scale1) turns the accumulator back into the dot product.
+template <int C>
+__global__ __launch_bounds__(256) void k_prep_f16(PrepArgs a) {
+  constexpr int KSTEPS = C / 16;
+  constexpr int NCH = C / 8 / 8;
+  const int tid = threadIdx.x;
+  const bool img1 = (int)blockIdx.x >= a.blocks0;
+  const long rb = img1 ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;
+  const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
+  const int b = (int)(rb * 32 / rows_pad);
+  if (!a.force && a.dense_cnt[b] == 0) return;                 // uniform
+  // largest |x| of both images of this sample (127 x the largest quantisation step of k_prep_split)
+  __shared__ float wred[2][4];
+  float m0 = 0.f, m1 = 0.f;
+  for (int i = tid; i < a.Lp / 32; i += 256) m0 = fmaxf(m0, a.bsig0r[(long)b * (a.Lp / 32) + i]);
+  for (int i = tid; i < a.Sp / 32; i += 256) m1 = fmaxf(m1, a.bsig1r[(long)b * (a.Sp / 32) + i]);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, m)); m1 = fmaxf(m1, __shfl_xor(m1, m)); }
+  if ((tid & 63) == 0) { wred[0][tid >> 6] = m0; wred[1][tid >> 6] = m1; }
+  __syncthreads();
+  m0 = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3])) * 127.f;
+  m1 = fmaxf(fmaxf(wred[1][0], wred[1][1]), fmaxf(wred[1][2], wred[1][3])) * 127.f;
+  auto pow2_scale = [](float amax) {        // 2^k with amax * 2^k in [2^13, 2^14); 1 for an all-zero (or bad) image
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
+    int e;
+    frexpf(amax, &e);                       // amax = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+  };
+  const float sc0 = pow2_scale(m0), sc1 = pow2_scale(m1);
+  const float sc = img1 ? sc1 : sc0;
+  if (!img1 && rb * 32 == (long)b * rows_pad && tid == 0) a.f16inv[b] = (1.0f / sc0) * (1.0f / sc1);
+  _Float16* const hi = img1 ? a.hi1 : a.hi0;
+  _Float16* const lo = img1 ? a.lo1 : a.lo0;
+  const int r = tid & 31;
+  const int local = (int)(rb * 32 - (long)b * rows_pad) + r;
+  const long row_off = ((long)b * rows + local) * a.c_in;
+  const void* const src = img1 ? a.src1 : a.src0;
+#pragma unroll
+  for (int n = 0; n < NCH; ++n) {
+    const int q = n * 8 + (tid >> 5);
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (local < rows) {
+      if (a.in_dtype == FM_F32) {
+        const float* row = (const float*)src + row_off;
+        if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
+        if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
+      } else {
+        const unsigned short* row = (const unsigned short*)src + row_off;
+        uint2 h0 = make_uint2(0u, 0u), h1 = h0;
+        if (q * 8 < a.c_in) h0 = *reinterpret_cast<const uint2*>(row + q * 8);
+        if (q * 8 + 4 < a.c_in) h1 = *reinterpret_cast<const uint2*>(row + q * 8 + 4);
+        v0 = half4_to_float4(h0, a.in_dtype);
+        v1 = half4_to_float4(h1, a.in_dtype);
+      }
+    }
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    half8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xs = x[e] * sc;
+      hh[e] = (_Float16)xs;
+      ll[e] = (_Float16)(xs - (float)hh[e]);
+    }
+    const int h = q / KSTEPS, ks = q - h * KSTEPS;
+    const long off = (((rb * KSTEPS + ks) * 2 + h) * 32 + r) * 8;
+    *reinterpret_cast<half8*>(hi + off) = hh;
+    *reinterpret_cast<half8*>(lo + off) = ll;
+  }
+}
+
+static void fill_prep_args(PrepArgs& a, const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w,
+                           char* base) {
   a.src0 = feat0; a.src1 = feat1; a.in_dtype = in_dtype;
   a.hi0 = (_Float16*)(base + w.hi0); a.lo0 = (_Float16*)(base + w.lo0);
   a.hi1 = (_Float16*)(base + w.hi1); a.lo1 = (_Float16*)(base + w.lo1);
@@ -179,6 +247,29 @@ hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c
   a.zero = (uint4*)(base + w.zero_begin); a.zero_vec = (int)((w.zero_end - w.zero_begin) / 16);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.c_in = c_in;
   a.blocks0 = (int)((long)w.N * w.Lp / 32);
+  a.dense_cnt = (const int*)(base + w.dense_cnt); a.force = 0; a.f16inv = (float*)(base + w.f16inv);
+  a.bsig0r = (const float*)(base + w.bsig0); a.bsig1r = (const float*)(base + w.bsig1); a.N = w.N;
+}
+
+hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
+                           int force, hipStream_t st) {
+  PrepArgs a;
+  fill_prep_args(a, feat0, feat1, in_dtype, c_in, w, base);
+  a.force = force;
+  const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / 32);
+  switch (w.C) {
+    case 64: hipLaunchKernelGGL(k_prep_f16<64>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 128: hipLaunchKernelGGL(k_prep_f16<128>, dim3(blocks), dim3(256), 0, st, a); break;
+    case 256: hipLaunchKernelGGL(k_prep_f16<256>, dim3(blocks), dim3(256), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
+                       hipStream_t st) {
+  PrepArgs a;
+  fill_prep_args(a, feat0, feat1, in_dtype, c_in, w, base);
   const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / 32);
   switch (w.C) {
     case 64: hipLaunchKernelGGL(k_prep_split<64>, dim3(blocks), dim3(256), 0, st, a); break;

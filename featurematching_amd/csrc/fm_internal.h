@@ -47,7 +47,8 @@ struct CoarseWs {
   size_t q0, q1;                              // int8 screening planes
   size_t sig0, sig1, bsig0, bsig1;            // quantisation step per descriptor, largest step per 32-row block
   size_t l1_0, l1_1, bl1_0, bl1_1;            // L1 norm per descriptor, largest L1 norm per 32-row block
-  size_t emarg;                               // [N] log2-domain bound of k * |f16 product - exact product|
+  size_t emarg;                               // [N] log2-domain bound of k * |screening product - exact product|
+  size_t f16inv;                              // [N] 1 / (power-of-two scales of the two images' float16 planes)
   size_t rowS, colS;                          // partial sum-exp of the sparse sum kernel: rows [N][splits_s][Lp],
                                               // columns [N][panels][Sp]
   size_t rowB, colB;                          // partial sum-exp of the dense sum kernel: rows [N][splits][Lp],
@@ -74,6 +75,8 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
 hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                        hipStream_t st);
+hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
+                           int force, hipStream_t st);
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st);
 hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st,
                        float* conf = nullptr);

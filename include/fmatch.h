@@ -124,6 +124,8 @@ int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_s
                          float temperature, float thr, int mode, void* stream);
 int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
                                int C, int cand_slots, float temperature, float thr, void* stream);   /* float32 rows */
+int fm_debug_launch_prep_f16(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
+                             int cand_slots, int force, void* stream);
 int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream);
 
 /* Copy {M, status} to the host and wait for the stream (the one host sync of the

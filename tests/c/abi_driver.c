@@ -35,6 +35,7 @@ static __typeof__(fm_coarse_match_dtype)* p_fm_coarse_match_dtype;
 static __typeof__(fm_debug_coarse_layout)* p_fm_debug_coarse_layout;
 static __typeof__(fm_debug_launch_corr)* p_fm_debug_launch_corr;
 static __typeof__(fm_debug_launch_sum_sparse)* p_fm_debug_launch_sum_sparse;
+static __typeof__(fm_debug_launch_prep_f16)* p_fm_debug_launch_prep_f16;
 static __typeof__(fm_debug_reset_counters)* p_fm_debug_reset_counters;
 static __typeof__(fm_read_count)* p_fm_read_count;
 static __typeof__(fm_gather_windows)* p_fm_gather_windows;
@@ -52,7 +53,7 @@ int main(int argc, char** argv) {
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes);
   RESOLVE(fm_coarse_match); RESOLVE(fm_coarse_match_dtype); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
-  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
+  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
@@ -123,6 +124,8 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_debug_launch_corr(one, 0, 64, 64, 64, 8, 0.1f, 0.2f, 1, NULL), FM_E_SHAPE);
   EXPECT(p_fm_debug_launch_sum_sparse(one, NULL, one, 1, 64, 64, 64, 8, 0.1f, 0.2f, NULL), FM_E_NULL);
   EXPECT(p_fm_debug_launch_sum_sparse(one, one, one, 1, 64, 64, 64, 16 + 1, 0.1f, 0.2f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_debug_launch_prep_f16(one, one, NULL, 1, 64, 64, 64, 8, 1, NULL), FM_E_NULL);
+  EXPECT(p_fm_debug_launch_prep_f16(one, one, one, 1, 64, 64, 64, 64 + 1, 1, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_debug_reset_counters(NULL, 1, 64, 64, 64, 8, NULL), FM_E_NULL);
   EXPECT(p_fm_debug_reset_counters(one, 1, 64, 0, 64, 8, NULL), FM_E_SHAPE);
 

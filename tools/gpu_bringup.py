@@ -69,12 +69,21 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     lo0 = unfrag(view(ws, base, lay["lo0"], n * Lp * cp, torch.float16), Lp)
     hi1 = unfrag(view(ws, base, lay["hi1"], n * Sp * cp, torch.float16), Sp)
     lo1 = unfrag(view(ws, base, lay["lo1"], n * Sp * cp, torch.float16), Sp)
-    e_hi = np.abs(hi0[:, :l].astype(np.float32) - f0.astype(np.float16).astype(np.float32)).max()
-    rec = np.abs(hi0[:, :l].astype(np.float64) + lo0[:, :l].astype(np.float64) - f0).max()
-    rec1 = np.abs(hi1[:, :s].astype(np.float64) + lo1[:, :s].astype(np.float64) - f1).max()
-    pad = max(np.abs(hi0[:, l:]).max() if Lp > l else 0, np.abs(hi1[:, s:]).max() if Sp > s else 0)
-    print(f"   planes: hi err {e_hi:.2e}  hi+lo recon err {rec:.2e}/{rec1:.2e}  pad max {pad}")
-    ok &= e_hi == 0 and rec < 1e-5 and pad == 0
+    # k_prep_f16 writes the planes only for the samples the dense kernel redoes, scaled by a power of two per image
+    dcnt_planes = view(ws, base, lay["dense_cnt"], n, torch.int32)
+    for b in range(n):
+        if dcnt_planes[b] == 0:
+            continue
+        sc0 = 2.0 ** (14 - np.frexp(np.abs(f0[b]).max())[1]) if np.abs(f0[b]).max() > 0 else 1.0
+        sc1 = 2.0 ** (14 - np.frexp(np.abs(f1[b]).max())[1]) if np.abs(f1[b]).max() > 0 else 1.0
+        x0, x1 = (f0[b] * np.float32(sc0)).astype(np.float32), (f1[b] * np.float32(sc1)).astype(np.float32)
+        e_hi = np.abs(hi0[b, :l].astype(np.float32) - x0.astype(np.float16).astype(np.float32)).max()
+        rec = np.abs(hi0[b, :l].astype(np.float64) + lo0[b, :l].astype(np.float64) - x0).max() / sc0
+        rec1 = np.abs(hi1[b, :s].astype(np.float64) + lo1[b, :s].astype(np.float64) - x1).max() / sc1
+        pad = max(np.abs(hi0[b, l:]).max() if Lp > l else 0, np.abs(hi1[b, s:]).max() if Sp > s else 0)
+        print(f"   planes[{b}]: scales 2^{int(np.log2(sc0))}/2^{int(np.log2(sc1))} hi err {e_hi:.2e}  hi+lo recon err "
+              f"{rec:.2e}/{rec1:.2e}  pad max {pad}")
+        ok &= e_hi == 0 and rec < 1e-5 and pad == 0
 
     def unfrag8(a, rows_pad):           # int8 planes: [rowblock][ks][h][r][16]
         ks8 = cp // 32
