@@ -48,6 +48,10 @@ SIGNATURES = {
     "fm_gather_merge_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "fm_gather_windows_pair": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p,
                                     _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "fm_coarse_tf_packed_bytes": (C.c_size_t, [_i]),
+    "fm_coarse_tf_workspace_bytes": (_i, [_i, _i, _i, C.POINTER(C.c_size_t)]),
+    "fm_coarse_tf_pack_weights": (_i, [_p, _i, _p, _p]),
+    "fm_coarse_transformer": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, C.c_size_t, _p, _p, _p]),
     "fm_fine_tf_packed_bytes": (C.c_size_t, []),
     "fm_fine_tf_pack_weights": (_i, [_p, _p, _p, _p]),
     "fm_fine_transformer": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),

@@ -352,6 +352,52 @@ _TF_NAMES = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", 
              "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
 
 
+def pack_coarse_transformer(state_dict: dict, n_layers: int, device) -> torch.Tensor:
+    """state dict of a coarse LocalFeatureTransformer (d_model 256, 8 heads, `n_layers` encoder layers) -> the
+    A-operand fragments fm_coarse_transformer reads (fm_coarse_tf_pack_weights)."""
+    lib = _lib.load()
+    keep, arrs = [], []
+    want = [(256, 256)] * 4 + [(512, 512), (256, 512)] + [(256,)] * 4
+    for l in range(n_layers):
+        ts = [state_dict[f"layers.{l}.{name}"].detach().to(device=device, dtype=torch.float32).contiguous()
+              for name in _TF_NAMES]
+        if [tuple(t.shape) for t in ts] != want:
+            raise ValueError(f"fm_coarse_transformer serves d_model 256 only, got {[tuple(t.shape) for t in ts]}")
+        keep.extend(ts)
+        arrs.append((C.c_void_p * 10)(*[t.data_ptr() for t in ts]))
+    table = (C.POINTER(C.c_void_p) * n_layers)(*[C.cast(a, C.POINTER(C.c_void_p)) for a in arrs])
+    nbytes = int(lib.fm_coarse_tf_packed_bytes(n_layers))
+    if nbytes == 0:
+        raise ValueError(f"fm_coarse_transformer: unsupported layer count {n_layers}")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _lib.check(lib.fm_coarse_tf_pack_weights(C.cast(table, C.c_void_p), n_layers, _ptr(packed), _stream(packed.device)),
+               "fm_coarse_tf_pack_weights")
+    torch.cuda.current_stream(packed.device).synchronize()       # the sources in `keep` may be freed after this
+    return packed
+
+
+def coarse_transformer(feat0: torch.Tensor, feat1: torch.Tensor, packed: torch.Tensor, layer_names, nhead: int = 8,
+                       workspace: Optional[torch.Tensor] = None):
+    """The coarse context layers (network/net.py:74) on feat0 [N,L,256], feat1 [N,S,256]; layer_names as in the
+    reference's config (['self', 'cross', ...])."""
+    lib = _lib.load()
+    feat0, feat1 = _f32c(feat0, "feat0"), _f32c(feat1, "feat1")
+    n, l, c = feat0.shape
+    s = feat1.shape[1]
+    if feat1.shape[0] != n or feat1.shape[2] != c:
+        raise ValueError(f"feat0 {tuple(feat0.shape)} and feat1 {tuple(feat1.shape)} do not belong together")
+    kinds = (C.c_int * len(layer_names))(*[{'self': 0, 'cross': 1}[k] for k in layer_names])
+    nbytes = C.c_size_t()
+    _lib.check(lib.fm_coarse_tf_workspace_bytes(n, l, s, C.byref(nbytes)), "fm_coarse_tf_workspace_bytes")
+    if workspace is None or workspace.numel() < nbytes.value:
+        workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=feat0.device)
+    out0, out1 = torch.empty_like(feat0), torch.empty_like(feat1)
+    _lib.check(lib.fm_coarse_transformer(_ptr(feat0), _ptr(feat1), n, l, s, c, nhead, kinds, len(layer_names),
+                                         _ptr(packed), _ptr(workspace), workspace.numel(), _ptr(out0), _ptr(out1),
+                                         _stream(feat0.device)), "fm_coarse_transformer")
+    return out0, out1
+
+
 def pack_fine_transformer(state_dict: dict, device) -> torch.Tensor:
     """state dict of a fine LocalFeatureTransformer (layers.0 = 'self', layers.1 = 'cross'; d_model 64, 8 heads) ->
     the packed operand fragments fm_fine_transformer reads (fm_fine_tf_pack_weights)."""

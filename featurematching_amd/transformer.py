@@ -2,11 +2,11 @@
 (network/net.py:74 coarse, :79-80 fine; network/module/transformer.py:34-57,78-96;
 network/module/attentions.py:19-46).
 
-The coarse layers (8 x [N,4800,256]) belong to the feature side of the boundary and run on PyTorch-ROCm (SURVEY.md:
-the CNN/FPN feature stack hands over to the HIP kernels).  The FINE layers in the reference's default configuration
-(d_model 64, 8 heads, ['self', 'cross'], windows of 25 or 49 tokens) take the fused HIP kernel fm_fine_transformer
-in inference (one wave per match, ~11x the PyTorch module at 640x480); training and every
-other configuration use the torch ops below.  Parameter names and shapes equal the reference's, so a reference
+In inference both of the reference's default configurations take fused HIP kernels: the FINE
+layers (d_model 64, 8 heads, ['self', 'cross'], windows of 25 or 49 tokens) fm_fine_transformer - one wave per
+match, 13x the PyTorch module at 640x480 - and the COARSE layers (d_model 256, 8 heads, any self / cross sequence,
+8 x [N,4800,256] in the reference) fm_coarse_transformer - three launches per encoder layer on the float32 matrix
+cores.  Training and every other configuration use the torch ops below.  Parameter names and shapes equal the reference's, so a reference
 state dict loads unchanged:
 
     layers.<k>.{q_proj,k_proj,v_proj,merge}.weight [d,d]   layers.<k>.mlp.{0,2}.weight [2d,2d] / [d,2d]
@@ -70,29 +70,43 @@ class LocalFeatureTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def _hip_ok(self, feat0, feat1) -> bool:
-        """fm_fine_transformer serves inference on float32 GPU windows with the default fine configuration;
-        FM_HIP_FINE_TF=0 forces the torch ops."""
-        return not self.training and not torch.is_grad_enabled() and feat0.is_cuda and feat0.dtype == torch.float32 \
-            and self.d_model == 64 and self.layer_names == ['self', 'cross'] and self.layers[0].nhead == 8 \
-            and feat0.shape == feat1.shape and feat0.shape[1] in (25, 49) \
-            and os.environ.get("FM_HIP_FINE_TF", "1") != "0"
+    def _hip_kind(self, feat0, feat1):
+        """Which fused HIP kernel serves this call (inference on float32 GPU tensors only): 'fine' =
+        fm_fine_transformer (d_model 64, 8 heads, ['self', 'cross'], windows of 25 or 49 tokens), 'coarse' =
+        fm_coarse_transformer (d_model 256, 8 heads, any self / cross sequence), None = the torch ops below.
+        FM_HIP_FINE_TF=0 / FM_HIP_COARSE_TF=0 force the torch ops."""
+        if self.training or torch.is_grad_enabled() or not feat0.is_cuda or feat0.dtype != torch.float32 \
+                or feat1.dtype != torch.float32 or self.layers[0].nhead != 8 or feat0.shape[0] != feat1.shape[0]:
+            return None
+        if self.d_model == 64 and self.layer_names == ['self', 'cross'] and feat0.shape == feat1.shape \
+                and feat0.shape[1] in (25, 49) and os.environ.get("FM_HIP_FINE_TF", "1") != "0":
+            return 'fine'
+        if self.d_model == 256 and all(k in ('self', 'cross') for k in self.layer_names) and feat0.shape[1] > 0 \
+                and feat1.shape[1] > 0 and os.environ.get("FM_HIP_COARSE_TF", "1") != "0":
+            return 'coarse'
+        return None
 
-    def _packed(self, device):
-        """operand fragments of the two layers, re-packed when a parameter changes (in-place updates bump torch's
+    def _packed(self, device, kind):
+        """operand fragments of the layers, re-packed when a parameter changes (in-place updates bump torch's
         version counters)"""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device), kind)
         if getattr(self, '_pack_key', None) != key:
             from . import ops
-            self._pack_cache = ops.pack_fine_transformer(self.state_dict(), device)
+            if kind == 'fine':
+                self._pack_cache = ops.pack_fine_transformer(self.state_dict(), device)
+            else:
+                self._pack_cache = ops.pack_coarse_transformer(self.state_dict(), len(self.layer_names), device)
             self._pack_key = key
         return self._pack_cache
 
     def forward(self, feat0: torch.Tensor, feat1: torch.Tensor):
         assert feat0.shape[2] == self.d_model, "the feature number of src and transformer must be equal"
-        if self._hip_ok(feat0, feat1):
+        kind = self._hip_kind(feat0, feat1)
+        if kind is not None:
             from . import ops
-            return ops.fine_transformer(feat0, feat1, self._packed(feat0.device))
+            if kind == 'fine':
+                return ops.fine_transformer(feat0, feat1, self._packed(feat0.device, kind))
+            return ops.coarse_transformer(feat0, feat1, self._packed(feat0.device, kind), self.layer_names)
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
                 feat0, feat1 = layer(feat0, feat0), layer(feat1, feat1)

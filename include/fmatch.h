@@ -211,6 +211,26 @@ int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t
                   float* out0, float* out1, void* stream);
 
 /*
+ * Coarse-level context layers in front of the coarse matching (network/net.py:74): the reference's
+ * LocalFeatureTransformer (network/module/transformer.py:34-57,78-96, attentions.py:19-46) in its default coarse
+ * configuration - d_model 256, 8 heads, linear attention, no masks, any sequence of 'self' / 'cross' layers - on
+ * feat0 [dev] float32 [N,L,256] and feat1 [N,S,256].  Float32 arithmetic on the float32 matrix cores; three launches
+ * per encoder layer (K/V projection + per-tile KV partials, their fold, the fused query-side layer).
+ * packed = fm_coarse_tf_packed_bytes(n_layers) bytes [dev], filled once per weight update by
+ * fm_coarse_tf_pack_weights: layers[l] = HOST array of 10 DEVICE pointers in state-dict order - q_proj, k_proj,
+ * v_proj, merge .weight [256,256]; mlp.0.weight [512,512]; mlp.2.weight [256,512]; norm1.weight, norm1.bias,
+ * norm2.weight, norm2.bias [256].  layer_kinds [host] n_layers ints: 0 = 'self', 1 = 'cross'.  workspace [dev]
+ * fm_coarse_tf_workspace_bytes(N, L, S) bytes, 16-byte aligned.  out0 / out1 must not alias the inputs.
+ * FM_E_UNSUPPORTED for any other C / nhead / layer kind (the caller keeps its own layers then).
+ */
+size_t fm_coarse_tf_packed_bytes(int n_layers);
+int fm_coarse_tf_workspace_bytes(int N, int L, int S, size_t* bytes);
+int fm_coarse_tf_pack_weights(const float* const* const* layers, int n_layers, void* packed, void* stream);
+int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, int S, int C, int nhead,
+                          const int* layer_kinds, int n_layers, const void* packed, void* workspace,
+                          size_t workspace_bytes, float* out0, float* out1, void* stream);
+
+/*
  * Fine-level context layers between the window crop and the fine matching (network/net.py:79-80): the reference's
  * LocalFeatureTransformer (network/module/transformer.py:34-57,78-96, attentions.py:19-46) in its default fine
  * configuration - d_model 64, 8 heads, layer_names ['self', 'cross'], linear attention, no masks - as ONE kernel,

@@ -37,6 +37,10 @@ static __typeof__(fm_debug_launch_corr)* p_fm_debug_launch_corr;
 static __typeof__(fm_debug_launch_sum_sparse)* p_fm_debug_launch_sum_sparse;
 static __typeof__(fm_debug_launch_prep_f16)* p_fm_debug_launch_prep_f16;
 static __typeof__(fm_debug_reset_counters)* p_fm_debug_reset_counters;
+static __typeof__(fm_coarse_tf_packed_bytes)* p_fm_coarse_tf_packed_bytes;
+static __typeof__(fm_coarse_tf_workspace_bytes)* p_fm_coarse_tf_workspace_bytes;
+static __typeof__(fm_coarse_tf_pack_weights)* p_fm_coarse_tf_pack_weights;
+static __typeof__(fm_coarse_transformer)* p_fm_coarse_transformer;
 static __typeof__(fm_read_count)* p_fm_read_count;
 static __typeof__(fm_gather_windows)* p_fm_gather_windows;
 static __typeof__(fm_coarse_cell_maps)* p_fm_coarse_cell_maps;
@@ -57,6 +61,8 @@ int main(int argc, char** argv) {
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
+  RESOLVE(fm_coarse_tf_packed_bytes); RESOLVE(fm_coarse_tf_workspace_bytes); RESOLVE(fm_coarse_tf_pack_weights);
+  RESOLVE(fm_coarse_transformer);
 
   EXPECT(p_fm_version(), FM_VERSION);
   for (int s = FM_E_RANGE; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
@@ -164,6 +170,27 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_epipolar_errors(f, f, 3, ids, NULL, 5, 1, f, f, NULL, 1e-4f, f, NULL, NULL, NULL), FM_E_NULL);
   EXPECT(p_fm_epipolar_errors(f, f, 1, ids, NULL, 5, 1, f, f, f, 1e-4f, f, NULL, NULL, NULL), FM_E_SHAPE);
   EXPECT(p_fm_epipolar_errors(f, f, 3, ids, NULL, 5, 0, f, f, f, 1e-4f, f, NULL, NULL, NULL), FM_E_SHAPE);
+
+  {  /* coarse context layers: every host-decided status */
+    size_t nb = 0;
+    float g[4];
+    const int kinds[2] = {0, 1}, bad_kind[1] = {2};
+    EXPECT(p_fm_coarse_tf_packed_bytes(0) == 0 ? FM_OK : 1, FM_OK);
+    EXPECT(p_fm_coarse_tf_packed_bytes(8) == (size_t)8 * (655360 + 1024) * 4 ? FM_OK : 1, FM_OK);
+    EXPECT(p_fm_coarse_tf_workspace_bytes(1, 4800, 4800, NULL), FM_E_NULL);
+    EXPECT(p_fm_coarse_tf_workspace_bytes(1, 0, 4800, &nb), FM_E_SHAPE);
+    EXPECT(p_fm_coarse_tf_workspace_bytes(1, 4800, 4801, &nb), FM_OK);
+    EXPECT(nb == (size_t)(150 + 151 + 2) * 8448 * 4 ? FM_OK : 1, FM_OK);
+    EXPECT(p_fm_coarse_tf_pack_weights(NULL, 8, f, NULL), FM_E_NULL);
+    EXPECT(p_fm_coarse_tf_pack_weights((const float* const* const*)f, 0, f, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, NULL, f, nb, f, g, NULL), FM_E_NULL);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 0, 256, 8, kinds, 2, f, f, nb, g, g + 1, NULL), FM_E_SHAPE);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 128, 8, kinds, 2, f, f, nb, g, g + 1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 4, kinds, 2, f, f, nb, g, g + 1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, bad_kind, 1, f, f, nb, g, g + 1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, f, f, nb, (float*)f, g, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, f, f, 16, g, g + 1, NULL), FM_E_WORKSPACE);
+  }
 
   printf("abi_driver: %d checks, %d failures\n", checks, failures);
   return failures ? 1 : 0;

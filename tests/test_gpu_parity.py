@@ -694,3 +694,36 @@ def test_fine_transformer_vs_oracle(w):
     assert torch.equal(a0, g0)
     b0, _ = tf(t0, t1)                       # grad mode: torch ops
     assert not torch.equal(b0, g0) and (b0.detach() - g0).abs().max().item() <= 2e-5
+
+
+# ------------------------------------------------------------------ coarse context layers in HIP (8(f) row 1)
+@pytest.mark.parametrize("n,l,s,layers", [(1, 300, 300, ['self', 'cross'] * 4),      # the reference's 8 layers
+                                          (2, 77, 130, ['self', 'cross']),           # ragged tiles, L != S, batch
+                                          (1, 32, 5, ['cross', 'self', 'self'])])    # one tile; fewer tokens than a tile
+def test_coarse_transformer_vs_oracle(n, l, s, layers):
+    """fm_coarse_transformer (K/V partials + fused query-side layer on the float32 matrix cores) against the
+    oracle's restatement of the reference's LocalFeatureTransformer (pinned by net_tail_small), d_model 256."""
+    wts = synth.transformer_weights(91, 256, len(layers))
+    x0 = (2.0 * synth.normal(92, 1, (n, l, 256))).astype(np.float32)
+    x1 = (2.0 * synth.normal(92, 2, (n, s, 256))).astype(np.float32)
+    r0, r1 = orc.local_feature_transformer(x0, x1, wts, 8, layers)
+    tw = {k: torch.as_tensor(v) for k, v in wts.items()}
+    packed = ops.pack_coarse_transformer(tw, len(layers), DEV)
+    t0, t1 = torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV)
+    g0, g1 = ops.coarse_transformer(t0, t1, packed, layers)
+    e0 = (g0.cpu() - r0).abs().max().item()
+    e1 = (g1.cpu() - r1).abs().max().item()
+    # float32 products in another summation order than torch-CPU's; |x| reaches ~10 after eight residual layers
+    assert e0 <= 5e-5 and e1 <= 5e-5, (e0, e1)
+    assert torch.equal(t0.cpu(), torch.as_tensor(x0)) and torch.equal(t1.cpu(), torch.as_tensor(x1))    # inputs untouched
+    h0, h1 = ops.coarse_transformer(t0, t1, packed, layers)
+    assert torch.equal(g0, h0) and torch.equal(g1, h1)               # deterministic (no float atomics)
+    # the module takes the kernels by itself in inference, its torch ops otherwise
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    tf = LocalFeatureTransformer(dict(d_model=256, nhead=8, layer_names=layers, attention='linear')).to(DEV).eval()
+    tf.load_state_dict(tw)
+    with torch.no_grad():
+        a0, a1 = tf(t0, t1)
+    assert torch.equal(a0, g0) and torch.equal(a1, g1)
+    b0, b1 = tf(t0, t1)                      # grad mode: torch ops
+    assert (b0.detach() - g0).abs().max().item() <= 5e-5 and (b1.detach() - g1).abs().max().item() <= 5e-5
