@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "fm_internal.h"
 #include "fmatch.h"
@@ -64,7 +65,16 @@ struct TfArgs {
   int tiles0;            // workgroups of segment 0 (= N * seg[0].tiles); the rest belong to segment 1
   int N;
   const float* w;        // this layer's packed weights
+#ifdef FM_DIAG_CTF
+  float* diag;           // diagnostic build: [workgroups of k_ctx_layer][4 waves][16] shader-clock stamps
+#endif
 };
+
+#ifdef FM_DIAG_CTF
+#define CTF_STAMP(k) do { const long long c_ = __builtin_amdgcn_s_memtime(); if (lane == 0) dg[k] = (float)(c_ - c0_); } while (0)
+#else
+#define CTF_STAMP(k) do {} while (0)
+#endif
 
 // W [n_out][K] row-major -> fragments: ((rb * K/8 + j) * 64 + lane) * 4 + t  =  W[32 rb + (lane & 31)][8j + 4 (lane >> 5) + t]
 __global__ void k_ctx_pack(const float* __restrict__ w, int n_out, int K, float* __restrict__ dst) {
@@ -78,35 +88,87 @@ __global__ void k_ctx_pack(const float* __restrict__ w, int n_out, int K, float*
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }     // elu(x) + 1
 
-// acc[i] += W[row block rb0 + i] . ACT  for a [K/8][32][8] float32 activation tile in LDS (KCH = K / 8 chunks)
+// acc[i] += W[row block rb0 + i] . ACT  for a [K/8][32][8] float32 activation tile in LDS (KCH = K / 8 chunks).
+// The weight fragments travel L2 -> registers through a ring of P chunks, the B operand (LDS) one chunk ahead.  Both
+// are issued from inline asm with counted waits: written as plain loads, hipcc re-materialises every fragment right
+// in front of its first use (the loads are from read-only memory), which exposes the full L2 latency per chunk
+// (measured: 97-113 cycles per MFMA instead of 64).  VMEM returns in order, so `vmcnt(younger loads)` means the
+// wanted chunk has landed; the stage drains its own loads before it returns.
+#define CTF_GLOAD(dst, ptr, imm) \
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(ptr), "n"(imm) : "memory")
+#define CTF_DSREAD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"(imm) : "memory")
+
+template <int VM>
+__device__ __forceinline__ void ctf_wait(f32x4 (&w)[2], f32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(b) : "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void ctf_wait(f32x4 (&w)[4], f32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(b) : "n"(VM) : "memory");
+}
+
+// one chunk: wait for its fragments, start the next B read, 4 k-steps x NB products, refill the ring slot
+template <int NB, int P, int p, bool kTail>
+__device__ __forceinline__ void ctf_step(f32x4 (&wa)[P][NB], f32x4 (&bq)[2], const char* (&wn)[NB], unsigned ba,
+                                         f32x16 (&acc)[NB]) {
+  ctf_wait<(kTail ? P - 1 - p : P - 1) * NB>(wa[p], bq[p & 1]);
+  if (!kTail || p + 1 < P) CTF_DSREAD(bq[(p + 1) & 1], ba, (p + 1) * 1024);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[p][i][t], bq[p & 1][t], acc[i], 0, 0, 0);
+  // refill the slot the products above have just read.  The registers of an in-flight load must never be touched by
+  // compiler-generated code (it believes the asm's result is there at once): the ring is only ever named by the asm
+  // statements and by products that follow a wait, and the tied "+v" keeps each slot in one physical register.
+  if (!kTail) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) CTF_GLOAD(wa[p][i], wn[i], p * 1024 - 4096);
+  }
+}
+
+template <int NB, int P, bool kTail>
+__device__ __forceinline__ void ctf_group(f32x4 (&wa)[P][NB], f32x4 (&bq)[2], const char* (&wn)[NB], unsigned ba,
+                                          f32x16 (&acc)[NB]) {
+  ctf_step<NB, P, 0, kTail>(wa, bq, wn, ba, acc);
+  ctf_step<NB, P, 1, kTail>(wa, bq, wn, ba, acc);
+  ctf_step<NB, P, 2, kTail>(wa, bq, wn, ba, acc);
+  ctf_step<NB, P, 3, kTail>(wa, bq, wn, ba, acc);
+  if constexpr (P == 8) {
+    ctf_step<NB, P, 4, kTail>(wa, bq, wn, ba, acc);
+    ctf_step<NB, P, 5, kTail>(wa, bq, wn, ba, acc);
+    ctf_step<NB, P, 6, kTail>(wa, bq, wn, ba, acc);
+    ctf_step<NB, P, 7, kTail>(wa, bq, wn, ba, acc);
+  }
+}
+
 template <int NB, int KCH>
 __device__ __forceinline__ void gemm_stage(const float* __restrict__ wp, int rb0, const float* act, f32x16 (&acc)[NB],
                                            int lane) {
-  constexpr int P = 4;           // chunks in flight
-  static_assert(KCH % P == 0, "chunk count");
-  const f32x4* wb[NB];
+  constexpr int P = 16 / NB;     // chunks in flight: ~4k cycles of matrix-core work ahead of their use
+  constexpr int G = KCH / P;
+  static_assert(KCH % P == 0 && (P == 4 || P == 8) && G >= 2, "chunk count");
+  // byte address of this lane's fragment of chunk P (the first one the loop prefetches), biased by +4096 so that the
+  // chunk offsets p * 1024 - 4096 fit the signed 13-bit immediate
+  const char* wn[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) wb[i] = reinterpret_cast<const f32x4*>(wp) + (size_t)(rb0 + i) * KCH * 64 + lane;
-  const f32x4* ab = reinterpret_cast<const f32x4*>(act) + (lane & 31) * 2 + (lane >> 5);
-  f32x4 wa[P][NB];
+  for (int i = 0; i < NB; ++i)
+    wn[i] = reinterpret_cast<const char*>(wp) + ((size_t)(rb0 + i) * KCH * 64 + lane) * 16 + 4096;
+  unsigned ba = (unsigned)(uintptr_t)act + (unsigned)((lane & 31) * 2 + (lane >> 5)) * 16u;      // LDS byte address
+  f32x4 wa[P][NB] = {}, bq[2] = {};
 #pragma unroll
   for (int p = 0; p < P; ++p)
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wa[p][i] = wb[i][p * 64];
-  for (int j = 0; j < KCH; j += P) {
+    for (int i = 0; i < NB; ++i) CTF_GLOAD(wa[p][i], wn[i], p * 1024 - 4096);
+  CTF_DSREAD(bq[0], ba, 0);
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const f32x4 b = ab[(j + p) * 64];
-      f32x4 a[NB];
-      const int nx = min(j + p + P, KCH - 1);        // unconditional prefetch (the last ones re-read the final chunk)
+  for (int i = 0; i < NB; ++i) wn[i] += P * 1024;
+  for (int g = 0; g < G - 1; ++g) {      // every chunk this group prefetches exists
+    ctf_group<NB, P, false>(wa, bq, wn, ba, acc);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) { a[i] = wa[p][i]; wa[p][i] = wb[i][nx * 64]; }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[t], acc[i], 0, 0, 0);
-    }
+    for (int i = 0; i < NB; ++i) wn[i] += P * 1024;
+    ba += P * 1024;
   }
+  ctf_group<NB, P, true>(wa, bq, wn, ba, acc);      // last P chunks: nothing left to prefetch, the waits count down to zero
 }
 
 // accumulator of output row block `rbg` (32 channels: register g <-> channel (g & 3) + 8 (g >> 2) + 4 h) -> activation
@@ -287,8 +349,13 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
   const Seg& sg = a.seg[s1 ? 1 : 0];
   const int wg = s1 ? (int)blockIdx.x - a.tiles0 : (int)blockIdx.x;
   const int b = wg / sg.tiles, tile = wg - b * sg.tiles, tok0 = tile * kTok;
+#ifdef FM_DIAG_CTF
+  const long long c0_ = __builtin_amdgcn_s_memtime();
+  float* const dg = a.diag + ((size_t)blockIdx.x * 4 + wv) * 16;
+#endif
   load_tile(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xm, tid);
   __syncthreads();
+  CTF_STAMP(0);
   const float* const kvp = sg.kv + (size_t)b * kKvFloats;
   const float* const ln = a.w + kOffLn;
 
@@ -296,6 +363,7 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
   {
     f32x16 acc[2] = {};
     gemm_stage<2, 32>(a.w + kOffQ, 2 * wv, xm, acc, lane);
+    CTF_STAMP(1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) store_act(hb, 2 * wv + i, acc[i], lane, [](float v, int, int) { return elu1(v); });
   }
@@ -324,29 +392,37 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
     const float S = sg.src_len;
     store_act(hb, hd, o, lane, [z, S](float v, int, int) { return v * z * S; });
   }
+  CTF_STAMP(2);
   __syncthreads();
+  CTF_STAMP(3);
   // ---- merge + LayerNorm 1 -> chunks 32..63 of the MLP input ----
   {
     f32x16 acc[2] = {};
     gemm_stage<2, 32>(a.w + kOffM, 2 * wv, hb, acc, lane);
+    CTF_STAMP(4);
     layer_norm(acc, ln, ln + kD, red0, red1, wv, lane);       // (its barriers also fence the reads of hb above)
 #pragma unroll
     for (int i = 0; i < 2; ++i) store_act(xm, 8 + 2 * wv + i, acc[i], lane, [](float v, int, int) { return v; });
   }
   __syncthreads();
+  CTF_STAMP(5);
   // ---- MLP: hidden = relu(W1 [x, msg]) ----
   {
     f32x16 acc[4] = {};
     gemm_stage<4, 64>(a.w + kOffW1, 4 * wv, xm, acc, lane);
+    CTF_STAMP(6);
 #pragma unroll
     for (int i = 0; i < 4; ++i) store_act(hb, 4 * wv + i, acc[i], lane, [](float v, int, int) { return fmaxf(v, 0.f); });
   }
   __syncthreads();
+  CTF_STAMP(7);
   // ---- W2 hidden -> LayerNorm 2 -> residual ----
   {
     f32x16 acc[2] = {};
     gemm_stage<2, 64>(a.w + kOffW2, 2 * wv, hb, acc, lane);
+    CTF_STAMP(8);
     layer_norm(acc, ln + 2 * kD, ln + 3 * kD, red0, red1, wv, lane);
+    CTF_STAMP(9);
     if (tok0 + r < sg.L) {
       float* const orow = sg.out + ((size_t)b * sg.L + tok0 + r) * kD;
 #pragma unroll
@@ -364,13 +440,18 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
       }
     }
   }
+  CTF_STAMP(10);
 }
 
 constexpr int kMaxLayers = 32;
 
 size_t ws_floats(int N, int L, int S) {
   const size_t t0 = (size_t)N * ((L + kTok - 1) / kTok), t1 = (size_t)N * ((S + kTok - 1) / kTok);
-  return (t0 + t1) * kKvFloats + 2 * (size_t)N * kKvFloats;
+  size_t n = (t0 + t1) * kKvFloats + 2 * (size_t)N * kKvFloats;
+#ifdef FM_DIAG_CTF
+  n += (t0 + t1) * 4 * 16;
+#endif
+  return n;
 }
 
 }  // namespace
@@ -439,6 +520,9 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
   part[1] = part[0] + (size_t)N * tl[0] * kKvFloats;
   kv[0] = part[1] + (size_t)N * tl[1] * kKvFloats;
   kv[1] = kv[0] + (size_t)N * kKvFloats;
+#ifdef FM_DIAG_CTF
+  float* const diag = kv[1] + (size_t)N * kKvFloats;
+#endif
   const float* cur[2] = {feat0, feat1};
   float* out[2] = {out0, out1};
 
@@ -447,6 +531,9 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
     TfArgs a{};
     a.N = N;
     a.w = w;
+#ifdef FM_DIAG_CTF
+    a.diag = diag;
+#endif
     // K / V side: the SOURCE tokens
     int tiles_kv = 0;
     for (int s = 0; s < nseg; ++s) {
