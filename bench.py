@@ -39,6 +39,7 @@ from featurematching_amd import dist as fdist  # noqa: E402
 
 PEAK_F16_DENSE_TFLOPS = 2500.0     # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PEAK_I8_DENSE_TOPS = 5000.0        # ... I8 MFMA: the cycles of the BF16 form at twice the k
+PEAK_F32_MFMA_TFLOPS = 157.3       # ... FP32 MFMA (v_mfma_f32_32x32x2_f32: 256 flop / clk / CU)
 HBM_PEAK_GBS = 8000.0              # ... HBM3E 8 TB/s spec (6.3 TB/s measured with a float4 copy)
 WORKLOADS = {
     "cfg2": dict(n=1, h=480, w=640, c=256, cf=64, label="640x480 pair, C=256 @1/8 (L=S=4800), Cf=64 @1/2"),
@@ -313,6 +314,63 @@ def module_api_rate(wl, window, dev, iters=60):
     return wl["n"] * iters / (time.perf_counter() - t0)
 
 
+def context_layer_times(wl, dev, iters=10):
+    """The layers either side of the hot path, HIP kernels against the PyTorch-ROCm modules, and
+    the whole `net.forward` tail (network/net.py:66-83) through matcher.Matcher.forward_features, W = 7."""
+    from featurematching_amd.matcher import Matcher
+    sh = synth.config_shapes(wl)
+    n, l, hc, wc = wl["n"], sh["l"], sh["hc"], sh["wc"]
+    torch.manual_seed(0)
+    m = Matcher().to(dev).eval()
+    f0, f1 = synth.coarse_descriptors(4243, n, l, wl["c"], "peaky")
+    ff0, ff1 = synth.fine_maps(4243, n, wl["cf"], sh["hf"], sh["wf"])
+    x0, x1, ff0, ff1 = (torch.as_tensor(x, device=dev) for x in (f0, f1, ff0, ff1))
+    fc0 = x0.view(n, hc, wc, -1).permute(0, 3, 1, 2).contiguous()
+    fc1 = x1.view(n, hc, wc, -1).permute(0, 3, 1, 2).contiguous()
+    base = {'bs': n, 'hw0_i': (wl["h"], wl["w"]), 'hw1_i': (wl["h"], wl["w"])}
+
+    def timed(fn):
+        with torch.no_grad():
+            for _ in range(3):
+                out = fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                out = fn()
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters, out
+
+    res = {}
+    t_c, _ = timed(lambda: m.coarse(x0, x1))
+    d = dict(base, hw0_c=(hc, wc), hw1_c=(hc, wc), hw0_f=(sh["hf"], sh["wf"]), hw1_f=(sh["hf"], sh["wf"]))
+    with torch.no_grad():
+        m.coarse_matching(x0, x1, d)
+        w0, w1 = m.fine_preprocess(ff0, ff1, x0, x1, d)
+    t_f, _ = timed(lambda: m.fine(w0, w1))
+    t_all, _ = timed(lambda: m.forward_features(fc0, fc1, ff0, ff1, dict(base)))
+    os.environ["FM_HIP_COARSE_TF"] = os.environ["FM_HIP_FINE_TF"] = "0"
+    try:
+        t_c_t, _ = timed(lambda: m.coarse(x0, x1))
+        t_f_t, _ = timed(lambda: m.fine(w0, w1))
+    finally:
+        del os.environ["FM_HIP_COARSE_TF"], os.environ["FM_HIP_FINE_TF"]
+    nl = len(m.coarse.layer_names)
+    flop_c = 2.0 * n * 2 * l * 655360 * nl
+    mm = int(w0.shape[0])
+    res["coarse"] = {"kernel": "k_ctx_kv + k_ctx_kv_sum + k_ctx_layer (float32 MFMA)", "layers": nl, "ms": round(t_c, 4),
+                     "torch_module_ms": round(t_c_t, 4), "tflops_f32": round(flop_c / t_c / 1e9, 1),
+                     "frac_of_f32_mfma_peak": round(flop_c / t_c / 1e9 / PEAK_F32_MFMA_TFLOPS, 3)}
+    res["fine"] = {"kernel": "k_fine_tf<49> (hi/lo-split f16 MFMA)", "matches": mm, "ms": round(t_f, 4),
+                   "torch_module_ms": round(t_f_t, 4)}
+    res["forward_features"] = {"ms": round(t_all, 4), "image_pairs_per_s": round(1e3 * n / t_all, 1),
+                               "note": "net.forward after the backbone: coarse context layers -> coarse matching -> "
+                                       "crop + context merge -> fine context layers -> fine matching, eager, one pair "
+                                       "per call, host sync on the match count"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -527,6 +585,11 @@ def main():
                                            "time, with the host sync on the match count and per-call allocations"}
         except Exception as e:
             extra["module_api"] = {"error": repr(e)}
+        if a.workload == "cfg2":
+            try:
+                extra["context_layers"] = context_layer_times(wl, dev)
+            except Exception as e:
+                extra["context_layers"] = {"error": repr(e)}
         out["extra"] = extra
     if not a.skip_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(wl, a.window, 1)
