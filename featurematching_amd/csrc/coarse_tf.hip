@@ -5,28 +5,33 @@
 //
 // One encoder layer  x <- x + LN2(MLP([x, LN1(merge(attn(q(x), k(src), v(src))))]))  is three launches:
 //
-//   k_ctx_kv      one workgroup per 32 SOURCE tokens: k = Wk src, v = Wv src on the float32 matrix cores
-//                 (v_mfma_f32_32x32x2_f32), K = elu(k) + 1, V = v / S, then this tile's share of the per-head
-//                 KV[d][v] = sum_s K[s][d] V[s][v] (a 32 x 32 x 32 product per head, again on the matrix cores) and of
-//                 Ksum[d] = sum_s K[s][d]; written as a partial, already in the operand-fragment order k_ctx_layer reads.
+//   k_ctx_kv      one workgroup per 32 SOURCE tokens: k = Wk src, v = Wv src, K = elu(k) + 1, V = v / S, then this
+//                 tile's share of the per-head KV[d][v] = sum_s K[s][d] V[s][v] (a 32 x 32 x 32 product per head on
+//                 the float32 matrix cores) and of Ksum[d] = sum_s K[s][d]; written as a partial, already in the
+//                 operand-fragment order k_ctx_layer reads.
 //   k_ctx_kv_sum  folds the partials of a sample in tile order (deterministic; no float atomics).
 //   k_ctx_layer   one workgroup per 32 tokens of x, 4 waves, each owning a quarter of every layer's output
 //                 channels: q projection -> elu + 1 -> per-head Q KV and the normaliser 1 / (Q . Ksum + eps) ->
 //                 merge -> LayerNorm -> MLP (512 -> 512, ReLU, 512 -> 256) -> LayerNorm -> residual.  The activations
-//                 of the tile never leave the CU: they sit in LDS as [k / 8][token][8] float32, which is both what
-//                 an accumulator writes (4 consecutive channels per register quad: ds_write_b128) and what the next
-//                 product's B operand reads (ds_read_b128 = 4 k-steps), without bank conflicts.  Weights stream from
-//                 L2 straight into registers as A-operand fragments, packed so that a wave's 64 lanes read one
-//                 contiguous 1 KiB per (32 output channels, 8 input channels); a four-chunk register ring keeps
-//                 the loads ~2k cycles ahead of their use.
+//                 of the tile never leave the CU.
 //
-// Arithmetic is float32 throughout (float32 MFMA: 157 TFLOP/s dense peak on MI355X), so the result differs from the
-// PyTorch module by summation order only.  Work: 2 * 655 360 flop per token and layer-call = 100.7 GFLOP per 640x480
-// pair for the reference's 8 layers.
+// The six linear layers (655 360 MACs per token, >98 % of the work) are float32-EQUIVALENT products on the float16
+// matrix cores: x = hi + lo with hi = f16(2^e x), lo = f16(2^e x - hi) (22 significant bits), W likewise, and
+// W x ~ hi_W hi_x + lo_W hi_x + hi_W lo_x = 3 x v_mfma_f32_32x32x16_f16 per 16 k - 5.3x the rate of the float32
+// MFMA (8 x 64 cycles against 3 x 32).  Every operand carries an exact power-of-two scale that brings its largest
+// magnitude to [2^13, 2^14): the matrix cores flush float16 SUBNORMAL inputs, so an unscaled lo half would vanish
+// for every |x| < 2^-3.  Weights: one scale per matrix, fixed at pack time.  Activations: one scale per TOKEN, from
+// the token's exact maximum over all channels (one LDS reduction per operand).  The accumulator is scaled back in
+// the epilogue (exact).  The per-head 32 x 32 attention products stay on the float32 MFMA.
 //
-// k-index convention of every product here: chunk j covers k = 8j .. 8j+7; in step t (0..3) of the chunk the lanes
-// of half h (= lane >> 5) contract k = 8j + 4h + t.  A-operand fragments (weights, KV) and B-operand reads
-// (activations) both follow it, so a lane's 16 bytes are 4 consecutive k-steps.
+// Operand traffic: activations sit in LDS as float16 planes [k / 16][k % 16 / 8][token][8] (hi) + the same for lo -
+// what the next product's B operand reads with one ds_read_b128 per plane and k-step; an accumulator register quad is
+// 4 consecutive channels = one ds_write_b64 per plane.  Weights stream from L2 straight into registers as A-operand
+// fragments (1 KiB hi + 1 KiB lo per 32 output channels and 16 input channels, contiguous) through a register ring
+// of 16 / NB k-steps, issued from inline asm with counted waits: written as plain loads, hipcc re-materialises every
+// fragment right in front of its first use (the loads are from read-only memory), which exposes the full L2
+// latency per k-step.  At 2.1 MB of fragments per tile and layer the kernel is bound by the L2 -> CU path
+// (64 B / clk / CU), not by the matrix cores.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -44,12 +49,19 @@ constexpr int kH = 8, kHD = 32;          // heads x head dim
 constexpr int kTok = 32;                 // tokens per workgroup
 constexpr int kKvFloats = kH * kHD * kHD + kH * kHD;      // per sample: KV fragments [h][j][lane][4], then Ksum [h][d]
 
-// packed layer: A-operand fragments of the six weight matrices, then the four LayerNorm vectors
-constexpr size_t kOffQ = 0, kOffK = 65536, kOffV = 131072, kOffM = 196608, kOffW1 = 262144, kOffW2 = 524288,
-                 kOffLn = 655360, kLayerFloats = kOffLn + 4 * kD;
+// packed layer (bytes): float16 A-operand fragments of the six weight matrices (hi + lo = 4 bytes per weight), then
+// a float header: the four LayerNorm vectors, 1 / scale of every matrix, the bound of |LN1 output|, the matrices'
+// largest magnitudes (bit patterns; scratch of the packing)
+constexpr size_t kFragQ = 0, kFragK = 65536 * 4, kFragV = 2 * 65536 * 4, kFragM = 3 * 65536 * 4, kFragW1 = 4 * 65536 * 4,
+                 kFragW2 = kFragW1 + 262144 * 4, kFragEnd = kFragW2 + 131072 * 4;
+constexpr int kHdrLn = 0, kHdrWinv = 4 * kD, kHdrMsgBound = kHdrWinv + 6, kHdrAbsmax = kHdrMsgBound + 1, kHdrFloats = kHdrAbsmax + 6 + 3;
+constexpr size_t kLayerBytes = kFragEnd + (size_t)kHdrFloats * 4;
+static_assert(kLayerBytes % 16 == 0, "layer stride keeps the fragments 16-byte aligned");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 struct Seg {
   const float* x;        // [N, L, 256] tokens this launch reads (k_ctx_kv: the SOURCE; k_ctx_layer: the image updated)
@@ -64,7 +76,7 @@ struct TfArgs {
   Seg seg[2];
   int tiles0;            // workgroups of segment 0 (= N * seg[0].tiles); the rest belong to segment 1
   int N;
-  const float* w;        // this layer's packed weights
+  const char* w;         // this layer's packed weights
 #ifdef FM_DIAG_CTF
   float* diag;           // diagnostic build: [workgroups of k_ctx_layer][4 waves][16] shader-clock stamps
 #endif
@@ -76,176 +88,285 @@ struct TfArgs {
 #define CTF_STAMP(k) do {} while (0)
 #endif
 
-// W [n_out][K] row-major -> fragments: ((rb * K/8 + j) * 64 + lane) * 4 + t  =  W[32 rb + (lane & 31)][8j + 4 (lane >> 5) + t]
-__global__ void k_ctx_pack(const float* __restrict__ w, int n_out, int K, float* __restrict__ dst) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)n_out * K) return;
-  const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
-  const long c = i >> 8;
-  const int j = (int)(c % (K / 8)), rb = (int)(c / (K / 8));
-  dst[i] = w[(long)(32 * rb + (lane & 31)) * K + 8 * j + 4 * (lane >> 5) + t];
+// exact power of two s with amax * s in [2^13, 2^14) and its inverse (zero, denormal or non-finite amax: 1)
+__host__ __device__ __forceinline__ void pow2_scale(float amax, float& s, float& inv) {
+  unsigned bits;
+  __builtin_memcpy(&bits, &amax, 4);
+  const int e = (int)((bits >> 23) & 0xffu);           // amax in [2^(e-127), 2^(e-126))
+  int k = 140 - e;                                     // 13 - (e - 127)
+  if (e == 0 || e == 255) k = 0;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  const unsigned sb = (unsigned)(127 + k) << 23, ib = (unsigned)(127 - k) << 23;
+  __builtin_memcpy(&s, &sb, 4);
+  __builtin_memcpy(&inv, &ib, 4);
+}
+
+// ------------------------------------------------------------------------------------------------ packing
+__global__ void k_ctx_absmax(const float* __restrict__ w, int n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+
+// W [n_out][K] row-major -> per (32-row block rb, 16-k step c): 64 lanes x 8 float16 of hi (1 KiB), then of lo;
+// lane (r, h) holds W[32 rb + r][16 c + 8 h .. + 7] * scale
+__global__ void k_ctx_pack16(const float* __restrict__ w, int n_out, int K, const unsigned* __restrict__ absmax_bits,
+                             half8* __restrict__ dst, float* __restrict__ winv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (rb, c, lane)
+  if (i >= n_out * K / 8) return;
+  float s, inv;
+  pow2_scale(__uint_as_float(*absmax_bits), s, inv);
+  if (i == 0) *winv = inv;
+  const int lane = i & 63, c = (i >> 6) % (K / 16), rb = (i >> 6) / (K / 16);
+  const float* row = w + (size_t)(32 * rb + (lane & 31)) * K + 16 * c + 8 * (lane >> 5);
+  half8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = row[e] * s;
+    hi[e] = (_Float16)v;
+    lo[e] = (_Float16)(v - (float)hi[e]);
+  }
+  half8* o = dst + (size_t)(i >> 6) * 128 + lane;
+  o[0] = hi;
+  o[64] = lo;
+}
+
+// LayerNorm vectors into the header + the bound |LN1(.)| <= max|gamma| sqrt(d - 1) + max|beta| of the merged message
+__global__ void k_ctx_pack_ln(const float* g1, const float* b1, const float* g2, const float* b2, float* hdr) {
+  const int t = threadIdx.x;       // 256 threads
+  hdr[kHdrLn + t] = g1[t];
+  hdr[kHdrLn + kD + t] = b1[t];
+  hdr[kHdrLn + 2 * kD + t] = g2[t];
+  hdr[kHdrLn + 3 * kD + t] = b2[t];
+  __shared__ float sg[4], sb[4];
+  float mg = fabsf(g1[t]), mb = fabsf(b1[t]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { mg = fmaxf(mg, __shfl_xor(mg, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+  if ((t & 63) == 0) { sg[t >> 6] = mg; sb[t >> 6] = mb; }
+  __syncthreads();
+  if (t == 0)
+    hdr[kHdrMsgBound] = fmaxf(fmaxf(sg[0], sg[1]), fmaxf(sg[2], sg[3])) * 16.0f + fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3]));
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }     // elu(x) + 1
+__device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32); }
 
-// acc[i] += W[row block rb0 + i] . ACT  for a [K/8][32][8] float32 activation tile in LDS (KCH = K / 8 chunks).
-// The weight fragments travel L2 -> registers through a ring of P chunks, the B operand (LDS) one chunk ahead.  Both
-// are issued from inline asm with counted waits: written as plain loads, hipcc re-materialises every fragment right
-// in front of its first use (the loads are from read-only memory), which exposes the full L2 latency per chunk
-// (measured: 97-113 cycles per MFMA instead of 64).  VMEM returns in order, so `vmcnt(younger loads)` means the
-// wanted chunk has landed; the stage drains its own loads before it returns.
+// ------------------------------------------------------------------------------------------------ the split product
 #define CTF_GLOAD(dst, ptr, imm) \
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(ptr), "n"(imm) : "memory")
 #define CTF_DSREAD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"(imm) : "memory")
 
 template <int VM>
-__device__ __forceinline__ void ctf_wait(f32x4 (&w)[2], f32x4& b) {
-  asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(b) : "n"(VM) : "memory");
+__device__ __forceinline__ void ctf_wait(half8 (&w)[2][2], half8 (&b)[2]) {
+  asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)"
+               : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(b[0]), "+v"(b[1]) : "n"(VM) : "memory");
 }
 template <int VM>
-__device__ __forceinline__ void ctf_wait(f32x4 (&w)[4], f32x4& b) {
-  asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(b) : "n"(VM) : "memory");
+__device__ __forceinline__ void ctf_wait(half8 (&w)[4][2], half8 (&b)[2]) {
+  asm volatile("s_waitcnt vmcnt(%10) lgkmcnt(0)"
+               : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]),
+                 "+v"(w[3][1]), "+v"(b[0]), "+v"(b[1]) : "n"(VM) : "memory");
 }
 
-// one chunk: wait for its fragments, start the next B read, 4 k-steps x NB products, refill the ring slot
-template <int NB, int P, int p, bool kTail>
-__device__ __forceinline__ void ctf_step(f32x4 (&wa)[P][NB], f32x4 (&bq)[2], const char* (&wn)[NB], unsigned ba,
+// one 16-k step: wait for its fragments, start the next B reads, 3 x NB products, refill the ring slot.
+// The registers of an in-flight load must never be touched by compiler-generated code (it believes the asm's result
+// is there at once): the ring is only ever named by the asm statements and by products that follow a wait, and the
+// tied "+v" keeps each slot in one physical register.
+template <int NB, int P, int LO, int p, bool kTail>
+__device__ __forceinline__ void ctf_step(half8 (&wa)[P][NB][2], half8 (&bq)[2][2], const char* (&wn)[NB], unsigned ba,
                                          f32x16 (&acc)[NB]) {
-  ctf_wait<(kTail ? P - 1 - p : P - 1) * NB>(wa[p], bq[p & 1]);
-  if (!kTail || p + 1 < P) CTF_DSREAD(bq[(p + 1) & 1], ba, (p + 1) * 1024);
+  ctf_wait<(kTail ? P - 1 - p : P - 1) * 2 * NB>(wa[p], bq[p & 1]);
+  if (!kTail || p + 1 < P) {
+    CTF_DSREAD(bq[(p + 1) & 1][0], ba, (p + 1) * 1024);
+    CTF_DSREAD(bq[(p + 1) & 1][1], ba, (p + 1) * 1024 + LO);
+  }
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[p][i][0], bq[p & 1][0], acc[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[p][i][t], bq[p & 1][t], acc[i], 0, 0, 0);
-  // refill the slot the products above have just read.  The registers of an in-flight load must never be touched by
-  // compiler-generated code (it believes the asm's result is there at once): the ring is only ever named by the asm
-  // statements and by products that follow a wait, and the tied "+v" keeps each slot in one physical register.
+  for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[p][i][1], bq[p & 1][0], acc[i], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[p][i][0], bq[p & 1][1], acc[i], 0, 0, 0);
   if (!kTail) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) CTF_GLOAD(wa[p][i], wn[i], p * 1024 - 4096);
+    for (int i = 0; i < NB; ++i) {
+      CTF_GLOAD(wa[p][i][0], wn[i], 0);
+      CTF_GLOAD(wa[p][i][1], wn[i], 1024);
+      wn[i] += 2048;
+    }
   }
 }
 
-template <int NB, int P, bool kTail>
-__device__ __forceinline__ void ctf_group(f32x4 (&wa)[P][NB], f32x4 (&bq)[2], const char* (&wn)[NB], unsigned ba,
+template <int NB, int P, int LO, bool kTail>
+__device__ __forceinline__ void ctf_group(half8 (&wa)[P][NB][2], half8 (&bq)[2][2], const char* (&wn)[NB], unsigned ba,
                                           f32x16 (&acc)[NB]) {
-  ctf_step<NB, P, 0, kTail>(wa, bq, wn, ba, acc);
-  ctf_step<NB, P, 1, kTail>(wa, bq, wn, ba, acc);
-  ctf_step<NB, P, 2, kTail>(wa, bq, wn, ba, acc);
-  ctf_step<NB, P, 3, kTail>(wa, bq, wn, ba, acc);
+  ctf_step<NB, P, LO, 0, kTail>(wa, bq, wn, ba, acc);
+  ctf_step<NB, P, LO, 1, kTail>(wa, bq, wn, ba, acc);
+  ctf_step<NB, P, LO, 2, kTail>(wa, bq, wn, ba, acc);
+  ctf_step<NB, P, LO, 3, kTail>(wa, bq, wn, ba, acc);
   if constexpr (P == 8) {
-    ctf_step<NB, P, 4, kTail>(wa, bq, wn, ba, acc);
-    ctf_step<NB, P, 5, kTail>(wa, bq, wn, ba, acc);
-    ctf_step<NB, P, 6, kTail>(wa, bq, wn, ba, acc);
-    ctf_step<NB, P, 7, kTail>(wa, bq, wn, ba, acc);
+    ctf_step<NB, P, LO, 4, kTail>(wa, bq, wn, ba, acc);
+    ctf_step<NB, P, LO, 5, kTail>(wa, bq, wn, ba, acc);
+    ctf_step<NB, P, LO, 6, kTail>(wa, bq, wn, ba, acc);
+    ctf_step<NB, P, LO, 7, kTail>(wa, bq, wn, ba, acc);
   }
 }
 
-template <int NB, int KCH>
-__device__ __forceinline__ void gemm_stage(const float* __restrict__ wp, int rb0, const float* act, f32x16 (&acc)[NB],
-                                           int lane) {
-  constexpr int P = 16 / NB;     // chunks in flight: ~4k cycles of matrix-core work ahead of their use
-  constexpr int G = KCH / P;
-  static_assert(KCH % P == 0 && (P == 4 || P == 8) && G >= 2, "chunk count");
-  // byte address of this lane's fragment of chunk P (the first one the loop prefetches), biased by +4096 so that the
-  // chunk offsets p * 1024 - 4096 fit the signed 13-bit immediate
+// acc[i] += W[row block rb0 + i] . ACT over KS k-steps of 16; `frag` = the matrix's fragments, `hi` = LDS address of the
+// hi plane's first k-step (the lo plane LO bytes behind it)
+template <int NB, int KS, int LO>
+__device__ __forceinline__ void gemm_stage(const char* __restrict__ frag, int rb0, const void* hi, f32x16 (&acc)[NB], int lane) {
+  constexpr int P = 16 / NB;     // k-steps in flight
+  constexpr int G = KS / P;
+  static_assert(KS % P == 0 && (P == 4 || P == 8) && G >= 2, "step count");
   const char* wn[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i)
-    wn[i] = reinterpret_cast<const char*>(wp) + ((size_t)(rb0 + i) * KCH * 64 + lane) * 16 + 4096;
-  unsigned ba = (unsigned)(uintptr_t)act + (unsigned)((lane & 31) * 2 + (lane >> 5)) * 16u;      // LDS byte address
-  f32x4 wa[P][NB] = {}, bq[2] = {};
+  for (int i = 0; i < NB; ++i) wn[i] = frag + ((size_t)(rb0 + i) * KS * 128 + lane) * 16;
+  unsigned ba = (unsigned)(uintptr_t)hi + (unsigned)lane * 16u;      // this lane's (token, k half) slot of a k-step
+  half8 wa[P][NB][2] = {}, bq[2][2] = {};
 #pragma unroll
   for (int p = 0; p < P; ++p)
 #pragma unroll
-    for (int i = 0; i < NB; ++i) CTF_GLOAD(wa[p][i], wn[i], p * 1024 - 4096);
-  CTF_DSREAD(bq[0], ba, 0);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) wn[i] += P * 1024;
-  for (int g = 0; g < G - 1; ++g) {      // every chunk this group prefetches exists
-    ctf_group<NB, P, false>(wa, bq, wn, ba, acc);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) wn[i] += P * 1024;
+    for (int i = 0; i < NB; ++i) {
+      CTF_GLOAD(wa[p][i][0], wn[i], 0);
+      CTF_GLOAD(wa[p][i][1], wn[i], 1024);
+      wn[i] += 2048;
+    }
+  CTF_DSREAD(bq[0][0], ba, 0);
+  CTF_DSREAD(bq[0][1], ba, LO);
+  for (int g = 0; g < G - 1; ++g) {      // every k-step this group prefetches exists
+    ctf_group<NB, P, LO, false>(wa, bq, wn, ba, acc);
     ba += P * 1024;
   }
-  ctf_group<NB, P, true>(wa, bq, wn, ba, acc);      // last P chunks: nothing left to prefetch, the waits count down to zero
+  ctf_group<NB, P, LO, true>(wa, bq, wn, ba, acc);      // last P steps: nothing left to prefetch, the waits count down
 }
 
-// accumulator of output row block `rbg` (32 channels: register g <-> channel (g & 3) + 8 (g >> 2) + 4 h) -> activation
-// tile: chunk 4 rbg + q, this lane's token, elements 4h .. 4h+3
-template <class F>
-__device__ __forceinline__ void store_act(float* buf, int rbg, const f32x16& acc, int lane, F f) {
-  f32x4* p = reinterpret_cast<f32x4*>(buf) + (size_t)(4 * rbg) * 64 + (lane & 31) * 2 + (lane >> 5);
+// accumulator values v[g] (register g <-> channel (g & 3) + 8 (g >> 2) + 4 h of output row block `rbg`), already
+// multiplied by the token's scale -> the planes: k-step 2 rbg + (q >> 1), k half q & 1, this token, elements 4h .. 4h+3
+__device__ __forceinline__ void store_planes(char* hi, int lo_off, int rbg, const f32x16& v, int lane) {
+  char* p = hi + (size_t)(2 * rbg) * 1024 + (lane & 31) * 16 + (lane >> 5) * 8;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    f32x4 v;
+    half4 h4, l4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = f(acc[4 * q + e], q, e);
-    p[q * 64] = v;
+    for (int e = 0; e < 4; ++e) {
+      h4[e] = (_Float16)v[4 * q + e];
+      l4[e] = (_Float16)(v[4 * q + e] - (float)h4[e]);
+    }
+    char* o = p + (q >> 1) * 1024 + (q & 1) * 512;
+    *reinterpret_cast<half4*>(o) = h4;
+    *reinterpret_cast<half4*>(o + lo_off) = l4;
   }
 }
 
-// tokens [tok0, tok0 + 32) of x [L, 256] -> [32 chunks][token][8]; rows beyond L are zero
-__device__ __forceinline__ void load_tile(const float* __restrict__ x, int tok0, int L, float* buf, int tid) {
-  // thread -> (token = tid & 31, chunk = tid >> 5 + 8 i): consecutive lanes write consecutive 32-byte LDS slots
-  const int tok = tid & 31;
+// tokens [tok0, tok0 + 32) of x [L, 256] -> planes (k-steps 0..15) scaled per token by the power of two that fits
+// max(|x| of the token, floor_max); scale and 1 / scale per token -> xsc[32], xinv[32].  Rows beyond L are zero.  Contains two barriers.
+__device__ __forceinline__ void load_tile(const float* __restrict__ x, int tok0, int L, char* hi, int lo_off, float* red8,
+                                          float* xinv, float* xsc, float floor_max, int tid) {
+  // thread -> (token = tid & 31, 8-channel groups (tid >> 5) + 8 i)
+  const int tok = tid & 31, g = tid >> 5;
   const bool ok = tok0 + tok < L;
   const float* row = x + (size_t)(tok0 + tok) * kD;
+  f32x4 v[4][2];
+  float m = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int j = (tid >> 5) + 8 * i;
-    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    const int j = g + 8 * i;
+    v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ok) {
-      v0 = *reinterpret_cast<const f32x4*>(row + 8 * j);
-      v1 = *reinterpret_cast<const f32x4*>(row + 8 * j + 4);
+      v[i][0] = *reinterpret_cast<const f32x4*>(row + 8 * j);
+      v[i][1] = *reinterpret_cast<const f32x4*>(row + 8 * j + 4);
     }
-    f32x4* p = reinterpret_cast<f32x4*>(buf) + ((size_t)j * 32 + tok) * 2;
-    p[0] = v0;
-    p[1] = v1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(v[i][0][e]), fabsf(v[i][1][e])));
   }
+  red8[g * 32 + tok] = m;
+  __syncthreads();
+  m = floor_max;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m = fmaxf(m, red8[k * 32 + tok]);
+  float s, inv;
+  pow2_scale(m, s, inv);
+  if (g == 0) { xinv[tok] = inv; xsc[tok] = s; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = g + 8 * i;                  // channels 8j .. 8j+7 = k-step j >> 1, half j & 1: one 16-byte slot
+    half8 h8, l8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xs = (e < 4 ? v[i][0][e] : v[i][1][e - 4]) * s;
+      h8[e] = (_Float16)xs;
+      l8[e] = (_Float16)(xs - (float)h8[e]);
+    }
+    char* o = hi + (size_t)(j >> 1) * 1024 + (j & 1) * 512 + tok * 16;
+    *reinterpret_cast<half8*>(o) = h8;
+    *reinterpret_cast<half8*>(o + lo_off) = l8;
+  }
+  __syncthreads();
 }
 
-__device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32); }
+// largest |v| of every token over all 256 / 512 channels of the workgroup (this wave holds NB x 16 x 2 of them);
+// contains one barrier.  Returns the token's power-of-two scale and its inverse.
+template <int NB>
+__device__ __forceinline__ void token_scale(const f32x16 (&v)[NB], float* redm, int wv, int lane, float& s, float& inv) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) m = fmaxf(m, fabsf(v[i][g]));
+  m = fmaxf(m, other_half(m));
+  const int r = lane & 31;
+  if (lane < 32) redm[wv * 32 + r] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(redm[r], redm[32 + r]), fmaxf(redm[64 + r], redm[96 + r]));
+  pow2_scale(m, s, inv);
+}
 
 // ------------------------------------------------------------------------------------------------ k_ctx_kv
 constexpr int kKtStride = 36;            // floats per channel row of the K / V transposes (32 tokens + pad, 16-byte aligned)
-constexpr int kKvLdsFloats = 32 * 32 * 8 + 2 * kD * kKtStride;
+constexpr int kPlane = 16 * 1024;        // bytes of one float16 plane of 256 channels x 32 tokens
+constexpr int kKvLdsBytes = 2 * kPlane + 2 * kD * kKtStride * 4 + (8 * 32 + 2 * 32) * 4;
 
 __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
-  extern __shared__ float lds[];
-  float* const xs = lds;                                  // [32][32][8] source tile
-  float* const kt = lds + 32 * 32 * 8;                    // [256][36]  K, channel-major
-  float* const vt = kt + kD * kKtStride;                  // [256][36]  V
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const xh = lds;                                                   // source tile: hi plane, lo plane
+  float* const kt = reinterpret_cast<float*>(lds + 2 * kPlane);           // [256][36]  K, channel-major
+  float* const vt = kt + kD * kKtStride;                                  // [256][36]  V
+  float* const red8 = vt + kD * kKtStride;
+  float* const xinv = red8 + 8 * 32;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const bool s1 = (int)blockIdx.x >= a.tiles0;
   const Seg& sg = a.seg[s1 ? 1 : 0];
   const int wg = s1 ? (int)blockIdx.x - a.tiles0 : (int)blockIdx.x;
   const int b = wg / sg.tiles, tile = wg - b * sg.tiles, tok0 = tile * kTok;
-  load_tile(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xs, tid);
-  __syncthreads();
+  load_tile(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xh, kPlane, red8, xinv, xinv + 32, 0.f, tid);
+  const float* const hdr = reinterpret_cast<const float*>(a.w + kFragEnd);
   const bool tok_ok = tok0 + r < sg.L;
-  const float S = sg.src_len;
+  const float S = sg.src_len, xi = xinv[r];
   // this wave: heads 2 wv, 2 wv + 1 = output row blocks 2 wv, 2 wv + 1 of both projections
   {
     f32x16 acc[2] = {};
-    gemm_stage<2, 32>(a.w + kOffK, 2 * wv, xs, acc, lane);
+    gemm_stage<2, 16, kPlane>(a.w + kFragK, 2 * wv, xh, acc, lane);
+    const float f = hdr[kHdrWinv + 1] * xi;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int ch = 32 * (2 * wv + i) + (g & 3) + 8 * (g >> 2) + 4 * h;
-        kt[ch * kKtStride + r] = tok_ok ? elu1(acc[i][g]) : 0.f;       // padding tokens contribute nothing
+        kt[ch * kKtStride + r] = tok_ok ? elu1(acc[i][g] * f) : 0.f;       // padding tokens contribute nothing
       }
   }
   {
     f32x16 acc[2] = {};
-    gemm_stage<2, 32>(a.w + kOffV, 2 * wv, xs, acc, lane);
+    gemm_stage<2, 16, kPlane>(a.w + kFragV, 2 * wv, xh, acc, lane);
+    const float f = hdr[kHdrWinv + 2] * xi;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int ch = 32 * (2 * wv + i) + (g & 3) + 8 * (g >> 2) + 4 * h;
-        vt[ch * kKtStride + r] = acc[i][g] / S;                          // values / S (attentions.py:41-42)
+        vt[ch * kKtStride + r] = acc[i][g] * f / S;                          // values / S (attentions.py:41-42)
       }
   }
   __builtin_amdgcn_wave_barrier();        // the rows read below were written by this wave only
@@ -254,8 +375,8 @@ __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int hd = 2 * wv + i;
-    // KV[d][v] = sum_tok K[tok][d] V[tok][v]: A = K^T (rows d), B = V (columns v); in step (c, t) half h contracts
-    // token 16 h + 4 c + t
+    // KV[d][v] = sum_tok K[tok][d] V[tok][v] on the float32 MFMA: A = K^T (rows d), B = V (columns v); in step (c, t)
+    // half h contracts token 16 h + 4 c + t
     const f32x4* ka = reinterpret_cast<const f32x4*>(kt + (hd * 32 + r) * kKtStride + 16 * h);
     const f32x4* vb = reinterpret_cast<const f32x4*>(vt + (hd * 32 + r) * kKtStride + 16 * h);
     f32x16 kv = {};
@@ -268,7 +389,7 @@ __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
       for (int t = 0; t < 4; ++t) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(ka4[t], vb4[t], kv, 0, 0, 0);
     }
     ks += other_half(ks);
-    // register 4q + e of lane (v = r, h) is KV[d = 8q + 4h + e][v]: exactly lane's f32x4 of chunk q in the A-operand
+    // register 4q + e of lane (v = r, h) is KV[d = 8q + 4h + e][v]: exactly the lane's f32x4 of chunk q in the A-operand
     // fragment order of k_ctx_layer's Q KV product
     f32x4* o = reinterpret_cast<f32x4*>(part) + (size_t)(hd * 4) * 64 + lane;
 #pragma unroll
@@ -299,7 +420,11 @@ __global__ __launch_bounds__(256) void k_ctx_kv_sum(TfArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_ctx_layer
-constexpr int kLayerLdsFloats = 2 * 64 * 32 * 8 + 2 * 4 * 32;      // x | msg, hidden (its first half: Q / attention), 2 reductions
+// LDS (bytes): [0, 64K) planes of the MLP input: hi k-steps 0..15 = x, 16..31 = LN1(merge(attention)), then lo;
+// [64K, 128K): first Q as float32 [chunk of 8 channels][token][8] (32K) and the planes of the attention output (2 x 16K),
+// later the planes of the MLP hidden layer (2 x 32K); then the reduction scratch.
+constexpr int kXmLo = 32 * 1024, kRegion2 = 64 * 1024, kAttHi = kRegion2 + 32 * 1024, kHidLo = 32 * 1024;
+constexpr int kLayerLdsBytes = 128 * 1024 + (8 * 32 + 3 * 4 * 32 + 2 * 32) * 4;
 
 // LayerNorm over the 256 channels of every token: this wave holds 64 of them (2 row blocks x 16 registers x 2 halves)
 __device__ __forceinline__ void layer_norm(f32x16 (&y)[2], const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -339,11 +464,16 @@ __device__ __forceinline__ void layer_norm(f32x16 (&y)[2], const float* __restri
 }
 
 __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
-  extern __shared__ float lds[];
-  float* const xm = lds;                          // chunks 0..31: x, 32..63: LN1(merge(attention))
-  float* const hb = lds + 64 * 32 * 8;            // chunks 0..63: MLP hidden; before that chunks 0..31: Q, then the attention output
-  float* const red0 = hb + 64 * 32 * 8;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const xm = lds;                                             // MLP input planes
+  float* const qf = reinterpret_cast<float*>(lds + kRegion2);       // Q, float32
+  char* const at = lds + kAttHi;                                    // attention output planes (hi, +16K lo)
+  char* const hb = lds + kRegion2;                                  // hidden planes (hi, +32K lo)
+  float* const red8 = reinterpret_cast<float*>(lds + 128 * 1024);
+  float* const red0 = red8 + 8 * 32;
   float* const red1 = red0 + 4 * 32;
+  float* const redm = red1 + 4 * 32;
+  float* const xinv = redm + 4 * 32;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const bool s1 = (int)blockIdx.x >= a.tiles0;
   const Seg& sg = a.seg[s1 ? 1 : 0];
@@ -353,27 +483,42 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
   const long long c0_ = __builtin_amdgcn_s_memtime();
   float* const dg = a.diag + ((size_t)blockIdx.x * 4 + wv) * 16;
 #endif
-  load_tile(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xm, tid);
-  __syncthreads();
+  const float* const hdr = reinterpret_cast<const float*>(a.w + kFragEnd);
+  const float* const ln = hdr + kHdrLn;
+  // x and (later) the LayerNorm-ed message share one scale per token, so that the MLP reads one operand: the scale
+  // fits the larger of the token's |x| and the bound of the message (known at pack time)
+  load_tile(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xm, kXmLo, red8, xinv, xinv + 32, hdr[kHdrMsgBound], tid);
   CTF_STAMP(0);
   const float* const kvp = sg.kv + (size_t)b * kKvFloats;
-  const float* const ln = a.w + kOffLn;
+  const float xi = xinv[r], xscale = xinv[32 + r];
 
-  // ---- Q = elu(Wq x) + 1: this wave's two heads ----
+  // ---- Q = elu(Wq x) + 1: this wave's two heads, float32 in LDS for the per-head products ----
   {
     f32x16 acc[2] = {};
-    gemm_stage<2, 32>(a.w + kOffQ, 2 * wv, xm, acc, lane);
+    gemm_stage<2, 16, kXmLo>(a.w + kFragQ, 2 * wv, xm, acc, lane);
     CTF_STAMP(1);
+    const float f = hdr[kHdrWinv + 0] * xi;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) store_act(hb, 2 * wv + i, acc[i], lane, [](float v, int, int) { return elu1(v); });
+    for (int i = 0; i < 2; ++i) {
+      f32x4* p = reinterpret_cast<f32x4*>(qf) + (size_t)(4 * (2 * wv + i)) * 64 + r * 2 + h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = elu1(acc[i][4 * q + e] * f);
+        p[q * 64] = v;
+      }
+    }
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  // ---- per head: (Q KV) / (Q . Ksum + eps) * S, written over Q (attentions.py:43-46) ----
+  // ---- per head: (Q KV) / (Q . Ksum + eps) * S  (attentions.py:43-46), float32 MFMA; chunk j of 8 channels, step t:
+  // half h contracts d = 8j + 4h + t ----
+  f32x16 att[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int hd = 2 * wv + i;
-    const f32x4* qa = reinterpret_cast<const f32x4*>(hb) + (size_t)(4 * hd) * 64 + r * 2 + h;
+    const f32x4* qa = reinterpret_cast<const f32x4*>(qf) + (size_t)(4 * hd) * 64 + r * 2 + h;
     const f32x4* ka = reinterpret_cast<const f32x4*>(kvp) + (size_t)(4 * hd) * 64 + lane;
     f32x16 o = {};
     float den = 0.f;
@@ -388,50 +533,84 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
       }
     }
     den += other_half(den);
-    const float z = 1.0f / (den + 1e-6f);
-    const float S = sg.src_len;
-    store_act(hb, hd, o, lane, [z, S](float v, int, int) { return v * z * S; });
+    const float zs = 1.0f / (den + 1e-6f) * sg.src_len;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) att[i][g] = o[g] * zs;
   }
   CTF_STAMP(2);
+  float as, ainv;
+  token_scale<2>(att, redm, wv, lane, as, ainv);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) att[i][g] *= as;
+    store_planes(at, kPlane, 2 * wv + i, att[i], lane);
+  }
   __syncthreads();
   CTF_STAMP(3);
-  // ---- merge + LayerNorm 1 -> chunks 32..63 of the MLP input ----
+  // ---- merge + LayerNorm 1 -> k-steps 16..31 of the MLP input, in the token's x scale ----
   {
     f32x16 acc[2] = {};
-    gemm_stage<2, 32>(a.w + kOffM, 2 * wv, hb, acc, lane);
+    gemm_stage<2, 16, kPlane>(a.w + kFragM, 2 * wv, at, acc, lane);
     CTF_STAMP(4);
-    layer_norm(acc, ln, ln + kD, red0, red1, wv, lane);       // (its barriers also fence the reads of hb above)
+    const float f = hdr[kHdrWinv + 3] * ainv;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) store_act(xm, 8 + 2 * wv + i, acc[i], lane, [](float v, int, int) { return v; });
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][g] *= f;
+    layer_norm(acc, ln, ln + kD, red0, red1, wv, lane);       // (its barriers also fence the reads of `at` above)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][g] *= xscale;
+      store_planes(xm, kXmLo, 8 + 2 * wv + i, acc[i], lane);
+    }
   }
   __syncthreads();
   CTF_STAMP(5);
   // ---- MLP: hidden = relu(W1 [x, msg]) ----
+  float hinv;
   {
     f32x16 acc[4] = {};
-    gemm_stage<4, 64>(a.w + kOffW1, 4 * wv, xm, acc, lane);
+    gemm_stage<4, 32, kXmLo>(a.w + kFragW1, 4 * wv, xm, acc, lane);
     CTF_STAMP(6);
+    const float f = hdr[kHdrWinv + 4] * xi;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) store_act(hb, 4 * wv + i, acc[i], lane, [](float v, int, int) { return fmaxf(v, 0.f); });
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][g] = fmaxf(acc[i][g] * f, 0.f);
+    float hs;
+    token_scale<4>(acc, redm, wv, lane, hs, hinv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][g] *= hs;
+      store_planes(hb, kHidLo, 4 * wv + i, acc[i], lane);
+    }
   }
   __syncthreads();
   CTF_STAMP(7);
   // ---- W2 hidden -> LayerNorm 2 -> residual ----
   {
     f32x16 acc[2] = {};
-    gemm_stage<2, 64>(a.w + kOffW2, 2 * wv, hb, acc, lane);
+    gemm_stage<2, 32, kHidLo>(a.w + kFragW2, 2 * wv, hb, acc, lane);
     CTF_STAMP(8);
+    const float f = hdr[kHdrWinv + 5] * hinv;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][g] *= f;
     layer_norm(acc, ln + 2 * kD, ln + 3 * kD, red0, red1, wv, lane);
     CTF_STAMP(9);
     if (tok0 + r < sg.L) {
+      const float* const xrow = sg.x + ((size_t)b * sg.L + tok0 + r) * kD;
       float* const orow = sg.out + ((size_t)b * sg.L + tok0 + r) * kD;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int rbg = 2 * wv + i;
-        const f32x4* xp = reinterpret_cast<const f32x4*>(xm) + (size_t)(4 * rbg) * 64 + r * 2 + h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 xv = xp[q * 64];
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + 32 * rbg + 8 * q + 4 * h);
           f32x4 ov;
 #pragma unroll
           for (int e = 0; e < 4; ++e) ov[e] = xv[e] + acc[i][4 * q + e];
@@ -457,7 +636,7 @@ size_t ws_floats(int N, int L, int S) {
 }  // namespace
 
 extern "C" size_t fm_coarse_tf_packed_bytes(int n_layers) {
-  return n_layers > 0 && n_layers <= kMaxLayers ? (size_t)n_layers * kLayerFloats * 4 : 0;
+  return n_layers > 0 && n_layers <= kMaxLayers ? (size_t)n_layers * kLayerBytes : 0;
 }
 
 extern "C" int fm_coarse_tf_workspace_bytes(int N, int L, int S, size_t* bytes) {
@@ -472,24 +651,28 @@ extern "C" int fm_coarse_tf_workspace_bytes(int N, int L, int S, size_t* bytes) 
 extern "C" int fm_coarse_tf_pack_weights(const float* const* const* layers, int n_layers, void* packed, void* stream) {
   if (!layers || !packed) return FM_E_NULL;
   if (n_layers <= 0 || n_layers > kMaxLayers) return FM_E_UNSUPPORTED;
+  if ((uintptr_t)packed & 15) return FM_E_WORKSPACE;
   for (int l = 0; l < n_layers; ++l) {
     if (!layers[l]) return FM_E_NULL;
     for (int i = 0; i < 10; ++i)
       if (!layers[l][i]) return FM_E_NULL;
   }
   hipStream_t st = (hipStream_t)stream;
-  const size_t off[6] = {kOffQ, kOffK, kOffV, kOffM, kOffW1, kOffW2};
+  const size_t off[6] = {kFragQ, kFragK, kFragV, kFragM, kFragW1, kFragW2};
   const int n_out[6] = {256, 256, 256, 256, 512, 256}, n_in[6] = {256, 256, 256, 256, 512, 512};
   for (int l = 0; l < n_layers; ++l) {
-    float* dst = (float*)packed + (size_t)l * kLayerFloats;
+    char* dst = (char*)packed + (size_t)l * kLayerBytes;
+    float* hdr = (float*)(dst + kFragEnd);
+    hipError_t e = hipMemsetAsync(hdr, 0, kHdrFloats * 4, st);
+    if (e != hipSuccess) return (int)e;
     for (int i = 0; i < 6; ++i) {
       const int n = n_out[i] * n_in[i];
-      hipLaunchKernelGGL(k_ctx_pack, dim3((n + 255) / 256), dim3(256), 0, st, layers[l][i], n_out[i], n_in[i], dst + off[i]);
+      unsigned* amax = (unsigned*)(hdr + kHdrAbsmax + i);
+      hipLaunchKernelGGL(k_ctx_absmax, dim3(64), dim3(256), 0, st, layers[l][i], n, amax);
+      hipLaunchKernelGGL(k_ctx_pack16, dim3((n / 8 + 255) / 256), dim3(256), 0, st, layers[l][i], n_out[i], n_in[i], amax,
+                         (half8*)(dst + off[i]), hdr + kHdrWinv + i);
     }
-    for (int i = 0; i < 4; ++i) {
-      hipError_t e = hipMemcpyAsync(dst + kOffLn + (size_t)i * kD, layers[l][6 + i], kD * 4, hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) return (int)e;
-    }
+    hipLaunchKernelGGL(k_ctx_pack_ln, dim3(1), dim3(256), 0, st, layers[l][6], layers[l][7], layers[l][8], layers[l][9], hdr);
   }
   return (int)hipGetLastError();
 }
@@ -505,12 +688,13 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
   for (int l = 0; l < n_layers; ++l)
     if (layer_kinds[l] != 0 && layer_kinds[l] != 1) return FM_E_UNSUPPORTED;
   if (feat0 == out0 || feat1 == out1 || out0 == out1) return FM_E_UNSUPPORTED;
-  if (workspace_bytes < ws_floats(N, L, S) * 4 || ((uintptr_t)workspace & 15)) return FM_E_WORKSPACE;
+  if (workspace_bytes < ws_floats(N, L, S) * 4 || ((uintptr_t)workspace & 15) || ((uintptr_t)packed & 15))
+    return FM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   static unsigned long long set_kv = 0, set_layer = 0;
-  hipError_t e = ensure_dynamic_lds(&k_ctx_kv, kKvLdsFloats * 4, &set_kv);
+  hipError_t e = ensure_dynamic_lds(&k_ctx_kv, kKvLdsBytes, &set_kv);
   if (e != hipSuccess) return (int)e;
-  e = ensure_dynamic_lds(&k_ctx_layer, kLayerLdsFloats * 4, &set_layer);
+  e = ensure_dynamic_lds(&k_ctx_layer, kLayerLdsBytes, &set_layer);
   if (e != hipSuccess) return (int)e;
 
   const int tl[2] = {(L + kTok - 1) / kTok, (S + kTok - 1) / kTok}, len[2] = {L, S};
@@ -527,7 +711,7 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
   float* out[2] = {out0, out1};
 
   // one encoder layer on `nseg` (image, source) pairs: x[img[s]] <- layer(x[img[s]], x[src[s]])
-  auto run = [&](const float* w, int nseg, const int* img, const int* src) -> hipError_t {
+  auto run = [&](const char* w, int nseg, const int* img, const int* src) -> hipError_t {
     TfArgs a{};
     a.N = N;
     a.w = w;
@@ -543,7 +727,7 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
       tiles_kv += N * g.tiles;
     }
     a.tiles0 = N * a.seg[0].tiles;
-    hipLaunchKernelGGL(k_ctx_kv, dim3(tiles_kv), dim3(256), kKvLdsFloats * 4, st, a);
+    hipLaunchKernelGGL(k_ctx_kv, dim3(tiles_kv), dim3(256), kKvLdsBytes, st, a);
     hipLaunchKernelGGL(k_ctx_kv_sum, dim3((kKvFloats + 255) / 256, N, nseg), dim3(256), 0, st, a);
     // query side: the tokens that are updated
     int tiles_x = 0;
@@ -554,13 +738,13 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
       tiles_x += N * g.tiles;
     }
     a.tiles0 = N * a.seg[0].tiles;
-    hipLaunchKernelGGL(k_ctx_layer, dim3(tiles_x), dim3(256), kLayerLdsFloats * 4, st, a);
+    hipLaunchKernelGGL(k_ctx_layer, dim3(tiles_x), dim3(256), kLayerLdsBytes, st, a);
     for (int s = 0; s < nseg; ++s) cur[img[s]] = out[img[s]];
     return hipGetLastError();
   };
 
   for (int l = 0; l < n_layers; ++l) {
-    const float* w = (const float*)packed + (size_t)l * kLayerFloats;
+    const char* w = (const char*)packed + (size_t)l * kLayerBytes;
     if (layer_kinds[l] == 0) {
       const int img[2] = {0, 1}, src[2] = {0, 1};
       e = run(w, 2, img, src);

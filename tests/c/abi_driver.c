@@ -176,7 +176,7 @@ int main(int argc, char** argv) {
     float g[4];
     const int kinds[2] = {0, 1}, bad_kind[1] = {2};
     EXPECT(p_fm_coarse_tf_packed_bytes(0) == 0 ? FM_OK : 1, FM_OK);
-    EXPECT(p_fm_coarse_tf_packed_bytes(8) == (size_t)8 * (655360 + 1024) * 4 ? FM_OK : 1, FM_OK);
+    EXPECT(p_fm_coarse_tf_packed_bytes(8) == (size_t)8 * (655360 + 1040) * 4 ? FM_OK : 1, FM_OK);
     EXPECT(p_fm_coarse_tf_workspace_bytes(1, 4800, 4800, NULL), FM_E_NULL);
     EXPECT(p_fm_coarse_tf_workspace_bytes(1, 0, 4800, &nb), FM_E_SHAPE);
     EXPECT(p_fm_coarse_tf_workspace_bytes(1, 4800, 4801, &nb), FM_OK);
