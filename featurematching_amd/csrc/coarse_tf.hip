@@ -48,6 +48,7 @@ constexpr int kD = 256;                  // d_model
 constexpr int kH = 8, kHD = 32;          // heads x head dim
 constexpr int kTok = 32;                 // tokens per workgroup
 constexpr int kKvFloats = kH * kHD * kHD + kH * kHD;      // per sample: KV fragments [h][j][lane][4], then Ksum [h][d]
+static_assert(kKvFloats % 32 == 0, "k_ctx_kv_sum: 32 outputs per workgroup");
 
 // packed layer (bytes): float16 A-operand fragments of the six weight matrices (hi + lo = 4 bytes per weight), then
 // a float header: the four LayerNorm vectors, 1 / scale of every matrix, the bound of |LN1 output|, the matrices'
@@ -401,22 +402,27 @@ __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
   }
 }
 
-// kv[b][o] = sum over the sample's tiles, in tile order
+// kv[b][o] = sum over the sample's tiles in a fixed order: 8 groups of threads take every 8th tile (four loads in
+// flight each: the fold is a chain of L2 round trips, not bandwidth), then the groups are folded in order
 __global__ __launch_bounds__(256) void k_ctx_kv_sum(TfArgs a) {
   const Seg& sg = a.seg[blockIdx.z];
-  const int o = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (o >= kKvFloats) return;
+  const int ol = threadIdx.x & 31, grp = threadIdx.x >> 5, o = blockIdx.x * 32 + ol, b = blockIdx.y;
+  __shared__ float red[8][32];
   const float* p = sg.part + (size_t)b * sg.tiles * kKvFloats + o;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int t = 0;
-  for (; t + 4 <= sg.tiles; t += 4) {
+  int t = grp;
+  for (; t + 24 < sg.tiles; t += 32) {
     s0 += p[(size_t)t * kKvFloats];
-    s1 += p[(size_t)(t + 1) * kKvFloats];
-    s2 += p[(size_t)(t + 2) * kKvFloats];
-    s3 += p[(size_t)(t + 3) * kKvFloats];
+    s1 += p[(size_t)(t + 8) * kKvFloats];
+    s2 += p[(size_t)(t + 16) * kKvFloats];
+    s3 += p[(size_t)(t + 24) * kKvFloats];
   }
-  for (; t < sg.tiles; ++t) s0 += p[(size_t)t * kKvFloats];
-  sg.kv[(size_t)b * kKvFloats + o] = (s0 + s1) + (s2 + s3);
+  for (; t < sg.tiles; t += 8) s0 += p[(size_t)t * kKvFloats];
+  red[grp][ol] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0)
+    sg.kv[(size_t)b * kKvFloats + o] = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) +
+                                       ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
 }
 
 // ------------------------------------------------------------------------------------------------ k_ctx_layer
@@ -600,20 +606,26 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][g] *= f;
+    // the residual's x rows (L2) are requested before the LayerNorm, whose reductions hide the round trip
+    const bool row_ok = tok0 + r < sg.L;
+    const size_t row_off = ((size_t)b * sg.L + (row_ok ? tok0 + r : 0)) * kD;
+    f32x4 xv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[i][q] = *reinterpret_cast<const f32x4*>(sg.x + row_off + 32 * (2 * wv + i) + 8 * q + 4 * h);
     layer_norm(acc, ln + 2 * kD, ln + 3 * kD, red0, red1, wv, lane);
     CTF_STAMP(9);
-    if (tok0 + r < sg.L) {
-      const float* const xrow = sg.x + ((size_t)b * sg.L + tok0 + r) * kD;
-      float* const orow = sg.out + ((size_t)b * sg.L + tok0 + r) * kD;
+    if (row_ok) {
+      float* const orow = sg.out + row_off;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int rbg = 2 * wv + i;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + 32 * rbg + 8 * q + 4 * h);
           f32x4 ov;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ov[e] = xv[e] + acc[i][4 * q + e];
+          for (int e = 0; e < 4; ++e) ov[e] = xv[i][q][e] + acc[i][4 * q + e];
           *reinterpret_cast<f32x4*>(orow + 32 * rbg + 8 * q + 4 * h) = ov;
         }
       }
@@ -728,7 +740,7 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
     }
     a.tiles0 = N * a.seg[0].tiles;
     hipLaunchKernelGGL(k_ctx_kv, dim3(tiles_kv), dim3(256), kKvLdsBytes, st, a);
-    hipLaunchKernelGGL(k_ctx_kv_sum, dim3((kKvFloats + 255) / 256, N, nseg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_ctx_kv_sum, dim3(kKvFloats / 32, N, nseg), dim3(256), 0, st, a);
     // query side: the tokens that are updated
     int tiles_x = 0;
     for (int s = 0; s < nseg; ++s) {
