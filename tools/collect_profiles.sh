@@ -29,6 +29,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python bench.
 echo "cfg3 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- python bench.py --workload cfg5 --steps 50 --warmup 5 --skip-cpu --quick > $O/cfg5.json 2> $O/cfg5.err
 echo "cfg5 done"
+# (6) the context layers either side of the path: kernel time, then matrix-core counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ctx -- python tools/time_matcher.py > $O/ctx.log 2> $O/ctx.err
+echo "ctx done"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/ctxsq -- python tools/time_matcher.py --hip-only > $O/ctxsq.log 2> $O/ctxsq.err
+echo "ctxsq done"
 # keep what is merged back small: stats + counter tables only (traces of 200 steps are large)
 find $O -name '*kernel_trace.csv' -size +8M -delete
 find $O -name '*.db' -delete

@@ -9,6 +9,8 @@ committed under profiles/:
   profiles/<round>_bench_cfg3_kernel_stats.csv, ..._cfg5_...
   profiles/<round>_pmc_fetch_write_cfg2.json             FETCH_SIZE / WRITE_SIZE per launch and kernel (KiB)
   profiles/<round>_pmc_sq_cfg2.csv                       matrix-core busy / wait fractions per kernel
+  profiles/<round>_forward_features_kernel_stats.csv     rocprofv3 --stats of tools/time_matcher.py (net.forward tail)
+  profiles/<round>_pmc_sq_forward_features.csv           the same counters for the context-layer kernels
   profiles/<round>_bench_lines.json                      the JSON lines the profiled commands printed
 """
 import csv
@@ -77,9 +79,12 @@ def main():
                                 "for wide reads on gfx950 (MI355X_MICROARCH.md, HBM section)", **fw}, oh, indent=1)
         print("wrote pmc_fetch_write")
 
-    sq = counters("sq")
-    if sq:
-        with open(os.path.join(DST, f"{rnd}_pmc_sq_cfg2.csv"), "w", newline="") as oh:
+    stats("ctx", f"{rnd}_forward_features_kernel_stats.csv")
+    for tag, out in (("sq", f"{rnd}_pmc_sq_cfg2.csv"), ("ctxsq", f"{rnd}_pmc_sq_forward_features.csv")):
+        sq = counters(tag)
+        if not sq:
+            continue
+        with open(os.path.join(DST, out), "w", newline="") as oh:
             w = csv.writer(oh)
             w.writerow(["kernel", "launches", "mfma_busy_frac_of_simd_cycles", "wait_any", "wait_inst_any",
                         "active_inst_any", "wait_inst_lds", "gui_active_cycles_per_launch"])
@@ -96,7 +101,7 @@ def main():
                 w.writerow([k, n, f"{mfma:.4f}", f"{mean.get('SQ_WAIT_ANY', 0) / wc:.4f}",
                             f"{mean.get('SQ_WAIT_INST_ANY', 0) / wc:.4f}", f"{mean.get('SQ_ACTIVE_INST_ANY', 0) / wc:.4f}",
                             f"{mean.get('SQ_WAIT_INST_LDS', 0) / wc:.4f}", f"{cyc:.0f}"])
-        print("wrote pmc_sq")
+        print("wrote", out)
 
     lines = {}
     for tag in ("default", "serial", "fetch", "write", "sq", "cfg3", "cfg5"):

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--n", type=int, default=1)
     ap.add_argument("--hc", type=int, default=60)
     ap.add_argument("--wc", type=int, default=80)
+    ap.add_argument("--hip-only", action="store_true", help="skip the PyTorch-module comparison (counter runs)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -57,9 +58,11 @@ def main():
         t_fp, (w0, w1) = timed(lambda: m.fine_preprocess(ff0, ff1, x0, x1, d))
         t_ftf, (v0, v1) = timed(lambda: m.fine(w0, w1))
         t_fm, _ = timed(lambda: m.fine_matching(v0, v1, d))
-        os.environ["FM_HIP_FINE_TF"] = "0"
-        t_ftf_t, _ = timed(lambda: m.fine(w0, w1))
-        os.environ["FM_HIP_FINE_TF"] = "1"
+        t_ftf_t = float("nan")
+        if not a.hip_only:
+            os.environ["FM_HIP_FINE_TF"] = "0"
+            t_ftf_t, _ = timed(lambda: m.fine(w0, w1))
+            os.environ["FM_HIP_FINE_TF"] = "1"
     mm = int(d['b_ids'].numel())
     print(f"forward_features N={n} {hc * 8}x{wc * 8}: {t_all:.3f} ms per call (matches through the random context layers: "
           f"{int(data['b_ids'].numel())})")
