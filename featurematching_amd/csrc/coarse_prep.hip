@@ -75,6 +75,25 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   const int local = (int)(rb * 32 - (long)b * rows_pad) + r;
   const long row_off = ((long)b * rows + local) * a.c_in;          // elements
   const void* const src = img1 ? a.src1 : a.src0;
+  // Full float32 rows (the common hand-over): the 32 rows of this block are one contiguous span of the source -
+  // copied to LDS with fully coalesced 16-byte loads (one row per wave instruction at C = 256) and read back in
+  // the (row = lane, 8-channel chunk) order the fragment-major stores need.  Row pitch + 16 bytes: the 32 lanes
+  // of a half-wave then start 4 banks apart.
+  constexpr int PITCH = C + 4;
+  __shared__ float tile[32 * PITCH];
+  const bool staged = a.in_dtype == FM_F32 && a.c_in == C;
+  if (staged) {
+    const int first = (int)(rb * 32 - (long)b * rows_pad);          // first row of the block inside its sample
+    const float4* span = reinterpret_cast<const float4*>((const float*)src + ((long)b * rows + first) * C);
+    const int valid4 = max(0, min(32, rows - first)) * (C / 4);      // float4s that exist (the sample's tail block is short)
+#pragma unroll
+    for (int p = 0; p < 32 * (C / 4) / 256; ++p) {
+      const int idx = p * 256 + tid;
+      const float4 v = idx < valid4 ? span[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&tile[(idx / (C / 4)) * PITCH + (idx % (C / 4)) * 4]) = v;
+    }
+    __syncthreads();
+  }
   float x[NCH][8];
   float s1 = 0.f, amax = 0.f;
   bool bad = false;
@@ -82,7 +101,10 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   for (int n = 0; n < NCH; ++n) {             // C/8 chunks of 8 channels, 8 per pass
     const int q = n * 8 + (tid >> 5);
     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-    if (local < rows) {
+    if (staged) {
+      v0 = *reinterpret_cast<const float4*>(&tile[r * PITCH + q * 8]);
+      v1 = *reinterpret_cast<const float4*>(&tile[r * PITCH + q * 8 + 4]);
+    } else if (local < rows) {
       if (a.in_dtype == FM_F32) {
         const float* row = (const float*)src + row_off;
         if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);

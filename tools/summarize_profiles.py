@@ -32,7 +32,7 @@ def one(pattern):
 
 
 def short(name):
-    return name.replace("void fm::", "").replace("fm::", "").split("(")[0]
+    return name.replace("(anonymous namespace)::", "").replace("void fm::", "").replace("fm::", "").split("(")[0]
 
 
 def stats(tag, out):
