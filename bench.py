@@ -455,6 +455,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         run(i)
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic: host- or GPU-bound?)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -528,7 +529,8 @@ def main():
         "config": {"workload": f"{wl['label']}, {a.window}x{a.window} fine window, '{a.dist}' descriptors",
                    "pairs_per_step_per_gpu": pairs_per_step, "launch": "eager" if a.no_graph else "hipGraph replay",
                    "concurrent_streams": nstreams, "matches_per_pair": round(m_avg, 1),
-                   "launches_per_step": 9, "pair_block": [pair_lo, pair_hi]},
+                   "launches_per_step": 9, "pair_block": [pair_lo, pair_hi],
+                   "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 4)},
         "verified": (ver["ok"] if ver else None), "verification": ver,
         # the dominant kernel of the coarse correlation: the int8 max pass (the one dense sweep; the sum kernels
         # re-execute only the live units).  `coarse_correlation` below prices all three launches of the product.
