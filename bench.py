@@ -362,7 +362,7 @@ def context_layer_times(wl, dev, iters=10):
     res["coarse"] = {"kernel": "k_ctx_kv + k_ctx_kv_sum + k_ctx_layer (float32 MFMA)", "layers": nl, "ms": round(t_c, 4),
                      "torch_module_ms": round(t_c_t, 4), "tflops_f32": round(flop_c / t_c / 1e9, 1),
                      "frac_of_f32_mfma_peak": round(flop_c / t_c / 1e9 / PEAK_F32_MFMA_TFLOPS, 3)}
-    res["fine"] = {"kernel": "k_fine_tf<49> (hi/lo-split f16 MFMA)", "matches": mm, "ms": round(t_f, 4),
+    res["fine"] = {"kernel": "k_fine_tf<49> (hi/lo-split f16 MFMA, 32-token slices)", "matches": mm, "ms": round(t_f, 4),
                    "torch_module_ms": round(t_f_t, 4)}
     res["forward_features"] = {"ms": round(t_all, 4), "image_pairs_per_s": round(1e3 * n / t_all, 1),
                                "note": "net.forward after the backbone: coarse context layers -> coarse matching -> "

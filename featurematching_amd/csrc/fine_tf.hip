@@ -8,12 +8,17 @@
 //                   return x + msg
 //   self : f0 = layer0(f0, f0); f1 = layer0(f1, f1)      cross: f0 = layer1(f0, f1); f1 = layer1(f1, f0_new)
 //
-// ONE WAVE PER MATCH (four matches per workgroup, which share the weight fragments staged through LDS by LDS-DMA:
-// every wave pulling the 640 KB of fragments of the four layer calls by itself made the kernel latency-bound on
-// those loads, 800 us at 640x480), and every activation stays in registers in MFMA accumulator layout from the window load to
-// the window store.  The trick is to compute each product in the orientation whose OUTPUT feeds the next product
-// as an operand without lane movement (an accumulator tile has its column on the lane and its rows in the 16
-// registers, so it is directly the operand of a product that sums over its ROW index):
+// ONE WAVE PER MATCH, eight matches per workgroup, which share the weight fragments staged through LDS by LDS-DMA
+// (every wave pulling the 640 KB of fragments of the four layer calls by itself made the kernel latency-bound on
+// those loads).  A wave works on one 32-token SLICE of a window at a time and keeps it in registers in MFMA
+// accumulator layout from its load to its store; a layer call x <- layer(x, src) is a kv phase over the slices of src
+// (K, V projections, KV += K^T V, sum K) and an update phase over the slices of x, the windows re-read in between (L2).
+// The first version kept both windows of a match in registers (128 of 512) and spilled: its later layer calls took
+// 85-120 k cycles against 57 k for the first; with slices the live state fits 256 registers (two waves per SIMD, no
+// scratch) and a 5 x 5 window is one slice instead of a padded pair: 693 -> 393 us at 3800 matches (W = 7).
+// The trick that keeps activations in registers is to compute each product in the orientation whose OUTPUT feeds the
+// next product as an operand without lane movement (an accumulator tile has its column on the lane and its rows in the
+// 16 registers, so it is directly the operand of a product that sums over its ROW index):
 //   T layout: features in registers, tokens on lanes   (result of  W . X^T ; operand B of the next W . X^T)
 //   N layout: tokens in registers, features on lanes   (result of  S . W^T ; K and V, which are summed over tokens)
 //     q^T   = Wq . x^T                 (T)      k, v = src . W^T            (N: the same src registers as operand A)
@@ -45,7 +50,6 @@ constexpr int kTfFrags = kTfFrag2 + 2 * 8;     // 80 fragments of 64 lanes x 8 h
 constexpr int kTfLayerHalf8 = 2 * kTfFrags * 64;                  // hi plane then lo plane
 constexpr int kTfLayerFloats = 4 * 64;                            // norm1.weight, norm1.bias, norm2.weight, norm2.bias
 
-struct Tile { f32x16 t[2][2]; };        // [row tile][column tile] of a 64 x 64 matrix in accumulator layout
 
 // Operands carry exact power-of-two scales: the lo half of a value below 2^-3 would otherwise be a float16
 // SUBNORMAL (|lo| ~ 2^-12 |x| < 2^-14), which the matrix cores flush - the weights of a 64..128-wide Linear layer
@@ -101,340 +105,324 @@ __device__ __forceinline__ float other_half(float v) {            // v(lane ^ 32
   return (threadIdx.x & 32) ? p : q;
 }
 
-// Y^T[OT*32 x 64 tokens] (+)= W[rows ot0*32.., columns s0*16..] . X^T : T layout in, T layout out.  rows[i] = the
-// i-th 32-feature row tile of the source (its two token tiles), KS = 2 * number of row tiles; wf = the matrix'
-// fragments in LDS (hi plane wf, lo plane wfl), KSW = k-steps of the whole matrix.  The accumulators keep the
-// operand scale until `finish` (so that a product can be accumulated in pieces).
-template <int OT, int KS, int KSW>
-__device__ __forceinline__ void gemm_T(f32x16 (&out)[OT][2], const f32x16 (*const (&rows)[KS / 2])[2],
-                                       const half8* wf, const half8* wfl, int ot0, int s0, bool first, bool finish, int lane) {
-  if (first) {
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) { zero(out[ot][0]); zero(out[ot][1]); }
-  }
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    half8 bh[2], bl[2];
-    split8((*rows[s >> 1])[0], s & 1, bh[0], bl[0]);
-    split8((*rows[s >> 1])[1], s & 1, bh[1], bl[1]);
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-      const int fi = ((ot0 + ot) * KSW + s0 + s) * 64 + lane;
-      const half8 wh = wf[fi], wl = wfl[fi];
-      mma3(out[ot][0], wh, wl, bh[0], bl[0]);
-      mma3(out[ot][1], wh, wl, bh[1], bl[1]);
-    }
-  }
-  if (finish) {
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) { rescale(out[ot][0], 1.0f / kWgtScale); rescale(out[ot][1], 1.0f / kWgtScale); }
-  }
-}
-
-// K[64 tokens x 64] = S . Wk^T and V = S . Wv^T : the T-layout registers of S as operand A (one split serves both
-// products), N layout out (tokens in registers, features on lanes)
-__device__ __forceinline__ void gemm_N2(Tile& outk, Tile& outv, const Tile& src, const half8* wk, const half8* wkl,
-                                        const half8* wv, const half8* wvl, int lane) {
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) { zero(outk.t[rt][0]); zero(outk.t[rt][1]); zero(outv.t[rt][0]); zero(outv.t[rt][1]); }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    half8 ah[2], al[2];
-    split8(src.t[s >> 1][0], s & 1, ah[0], al[0]);       // token tile 0
-    split8(src.t[s >> 1][1], s & 1, ah[1], al[1]);       // token tile 1
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-      const int fi = (ot * 4 + s) * 64 + lane;
-      const half8 kh = wk[fi], kl = wkl[fi];
-      mma3(outk.t[0][ot], ah[0], al[0], kh, kl);
-      mma3(outk.t[1][ot], ah[1], al[1], kh, kl);
-      const half8 vh = wv[fi], vl = wvl[fi];
-      mma3(outv.t[0][ot], ah[0], al[0], vh, vl);
-      mma3(outv.t[1][ot], ah[1], al[1], vh, vl);
-    }
-  }
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) { rescale(outk.t[rt][ct], 1.0f / kWgtScale); rescale(outv.t[rt][ct], 1.0f / kWgtScale); }
-}
-
 // elu(x) + 1 of a tile in the operand scale, result in the operand scale: xs = A x -> A (x > 0 ? x + 1 : exp(x))
 __device__ __forceinline__ float elu1_scaled(float xs) {
   constexpr float kL2A = 8.0f;                          // log2(kActScale)
   return xs > 0.f ? xs + kActScale : __builtin_amdgcn_exp2f(__builtin_fmaf(xs, kLog2e / kActScale, kL2A));
 }
 
-// LayerNorm over the 64 features of every token (T layout: this lane's 32 features + the other half's 32), eps 1e-5;
-// input and output in the operand scale (gamma and beta are packed pre-multiplied by kActScale)
-__device__ __forceinline__ void layer_norm_T(f32x16 (&y)[2][2], const float* __restrict__ gamma,
-                                             const float* __restrict__ beta, int h) {
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    float s = 0.f;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) s += y[rt][ct][g];
-    const float mean = swap_halves_add(s) * (1.0f / 64.0f);
-    float v = 0.f;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) { const float d = y[rt][ct][g] - mean; v += d * d; }
-    const float rstd = 1.0f / sqrtf(swap_halves_add(v) * (1.0f / 64.0f) + 1e-5f * kActScale * kActScale);   // scaled eps
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + 32 * rt + 8 * q + 4 * h);
-        const float4 be = *reinterpret_cast<const float4*>(beta + 32 * rt + 8 * q + 4 * h);
-        const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[rt][ct][4 * q + e] = (y[rt][ct][4 * q + e] - mean) * rstd * gg[e] + bb[e];
-      }
-  }
-}
-
-// x <- x + LN2(MLP([x | LN1(merge(attention(x, src)))]))      (transformer.py:34-57)
-// 1 KiB fragment blocks global -> LDS by LDS-DMA (no registers): fragment f of the block goes to dst + f KiB; the four
-// waves take every fourth fragment.  Completion: stage_wait().
-__device__ __forceinline__ void stage_frags(char* dst, const half8* src, int nfrags, int wv, int lane) {
-  for (int f = wv; f < nfrags; f += 4)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 64 + lane),
-                                     (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
-}
+// completion of the LDS-DMA fragment copies of stage_frags_n (every wave waits for its own, then the barrier)
 __device__ __forceinline__ void stage_wait() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
-
-// LDS map of the staged weights: region A (64 KiB) = the attention matrices q, k, v, merge [hi 32 frags | lo 32 frags],
-// later the second MLP matrix [hi 16 | lo 16]; region B (64 KiB) = the first MLP matrix [hi 32 | lo 32].
 constexpr int kRegionBytes = 64 * 1024;
 
-template <int WW>
-__device__ __forceinline__ void encoder_layer(Tile& x, const Tile& src, const half8* __restrict__ wl, bool load_w1,
-                                              const float* __restrict__ ln, char* lds, float* ksum_lds, int wv, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  // every wave of the workgroup is past the previous layer's use of both regions (barrier), then the weights of this
-  // layer arrive: 32 + 32 fragments of the attention matrices, and - unless the previous call left it there - the
-  // first MLP matrix
-  __syncthreads();
-  stage_frags(lds, wl + kTfFragQ * 64, 32, wv, lane);
-  stage_frags(lds + 32 * 1024, wl + kTfFrags * 64 + kTfFragQ * 64, 32, wv, lane);
-  if (load_w1) {
-    stage_frags(lds + kRegionBytes, wl + kTfFrag1 * 64, 32, wv, lane);
-    stage_frags(lds + kRegionBytes + 32 * 1024, wl + kTfFrags * 64 + kTfFrag1 * 64, 32, wv, lane);
+// ------------------------------------------------------------------------------------------------ the kernel
+// A layer call x <- layer(x, src) is
+//     kv phase:      for each slice of src: K, V projections, KV += K^T V, ksum += sum K   (weights k, v in LDS)
+//     update phase:  for each slice of x:   q, attention with KV, merge, LN, MLP, LN, residual, stored at once
+// with the slices re-read from the windows (L2-resident: a match is 25 KB).  The four calls of a match - self on image
+// 1, self on image 0, cross 0 <- 1, cross 1 <- updated 0 - run in place on the output windows.
+struct KvState {
+  half8 ah[4], al[4];     // KV rows d as operand A of msg^T = KV^T . Q^T, per k-step over d (32 registers; the
+};                        // normaliser's operand Kd is rebuilt from ksum in LDS where it is used)
+
+// Kd fragment of k-step s: row = head r (< 8), element j = sum_s K of feature d = 16 s + 8 (j>>2) + 4 h + (j&3) if in head r
+__device__ __forceinline__ void kd_fragment(const float* ksum_lds, int s, int r, int h, half8& dh, half8& dl) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int d = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+    const float val = (r == (d >> 3)) ? ksum_lds[d] * (kSumScale / kActScale) : 0.f;     // ksum_lds is in the operand scale
+    const _Float16 hh = (_Float16)val;
+    dh[j] = hh;
+    dl[j] = (_Float16)(val - (float)hh);
   }
-  stage_wait();
-  const half8* const la = reinterpret_cast<const half8*>(lds);                       // region A, hi plane
-  const half8* const lal = reinterpret_cast<const half8*>(lds + 32 * 1024);          // region A, lo plane
-  const half8* const lb = reinterpret_cast<const half8*>(lds + kRegionBytes);
-  const half8* const lbl = reinterpret_cast<const half8*>(lds + kRegionBytes + 32 * 1024);
-  // ---- projections ----
-  Tile q;                                   // q^T, T layout
-  {
-    const f32x16 (*const rows[2])[2] = {&x.t[0], &x.t[1]};
-    gemm_T<2, 4, 4>(q.t, rows, la + kTfFragQ * 64, lal + kTfFragQ * 64, 0, 0, true, true, lane);
+}
+
+// [OT x 32 tokens] = W . X^T for one slice: rows[i] = the i-th 32-feature row tile of the source
+template <int OT, int KS, int KSW>
+__device__ __forceinline__ void gemm_T1(f32x16 (&out)[OT], const f32x16* const (&rows)[KS / 2], const half8* wf,
+                                        const half8* wfl, int lane) {
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) zero(out[ot]);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    half8 bh, bl;
+    split8(*rows[s >> 1], s & 1, bh, bl);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const int fi = (ot * KSW + s) * 64 + lane;
+      mma3(out[ot], wf[fi], wfl[fi], bh, bl);
+    }
   }
-  Tile k, v;                                // N layout: token = 32 rt + (g&3) + 8 (g>>2) + 4 h, feature on the lane
-  gemm_N2(k, v, src, la + kTfFragK * 64, lal + kTfFragK * 64, la + kTfFragV * 64, lal + kTfFragV * 64, lane);
-  // feature maps; padded tokens (>= WW) must not enter the sums over tokens
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) rescale(out[ot], 1.0f / kWgtScale);
+}
+
+__device__ __forceinline__ void layer_norm_T1(f32x16 (&y)[2], const float* __restrict__ gamma, const float* __restrict__ beta, int h) {
+  float s = 0.f;
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int g = 0; g < 16; ++g) s += y[rt][g];
+  const float mean = swap_halves_add(s) * (1.0f / 64.0f);
+  float v = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { const float d = y[rt][g] - mean; v += d * d; }
+  const float rstd = 1.0f / sqrtf(swap_halves_add(v) * (1.0f / 64.0f) + 1e-5f * kActScale * kActScale);   // scaled eps
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + 32 * rt + 8 * q + 4 * h);
+      const float4 be = *reinterpret_cast<const float4*>(beta + 32 * rt + 8 * q + 4 * h);
+      const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[rt][4 * q + e] = (y[rt][4 * q + e] - mean) * rstd * gg[e] + bb[e];
+    }
+}
+
+// slice ct of a window [WW, 64] (token-major) <-> T layout: lane (token r, half h) holds features 32 rt + 8 q + 4 h + 0..3
+template <int WW>
+__device__ __forceinline__ void load_slice(f32x16 (&x)[2], const float* win, int ct, int lane) {
+  const int tok = 32 * ct + (lane & 31), h = lane >> 5;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tok < WW) v = *reinterpret_cast<const float4*>(win + tok * 64 + 32 * rt + 8 * q + 4 * h);
+      x[rt][4 * q] = v.x * kActScale; x[rt][4 * q + 1] = v.y * kActScale;      // into the operand scale
+      x[rt][4 * q + 2] = v.z * kActScale; x[rt][4 * q + 3] = v.w * kActScale;
+    }
+}
+template <int WW>
+__device__ __forceinline__ void store_slice(const f32x16 (&x)[2], float* win, int ct, int lane) {
+  const int tok = 32 * ct + (lane & 31), h = lane >> 5;
+  if (tok >= WW) return;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(win + tok * 64 + 32 * rt + 8 * q + 4 * h) =
+          make_float4(x[rt][4 * q] * (1.0f / kActScale), x[rt][4 * q + 1] * (1.0f / kActScale),
+                      x[rt][4 * q + 2] * (1.0f / kActScale), x[rt][4 * q + 3] * (1.0f / kActScale));
+}
+
+// kv phase: region B holds [K hi 8 | V hi 8 | K lo 8 | V lo 8] fragments
+template <int WW>
+__device__ __forceinline__ void kv_phase(const float* src, const half8* lb, float* ksum_lds, KvState& st, int lane) {
+  constexpr int NCT = (WW + 31) / 32;
+  const int r = lane & 31, h = lane >> 5;
+  const half8 *wk = lb, *wv_ = lb + 8 * 64, *wkl = lb + 16 * 64, *wvl = lb + 24 * 64;
+  f32x16 kv[2];
+  zero(kv[0]); zero(kv[1]);
+  float ks[2] = {0.f, 0.f};
+#pragma unroll 1
+  for (int ct = 0; ct < NCT; ++ct) {
+    // (the weight fragments sit at the same LDS addresses for every slice: without this the compiler hoists all of
+    // their loads out of the slice loop and spills them)
+    asm volatile("" : "+v"(lane));
+    f32x16 x[2];
+    load_slice<WW>(x, src, ct, lane);
+    // K, V [32 tokens x 64] = S . W^T: the T-layout registers of S as operand A, N layout out (tokens in registers,
+    // features on lanes)
+    f32x16 k[2], v[2];
+    zero(k[0]); zero(k[1]); zero(v[0]); zero(v[1]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      half8 ah, al;
+      split8(x[s >> 1], s & 1, ah, al);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int fi = (ot * 4 + s) * 64 + lane;
+        mma3(k[ot], ah, al, wk[fi], wkl[fi]);
+        mma3(v[ot], ah, al, wv_[fi], wvl[fi]);
+      }
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        q.t[rt][ct][g] = elu1_scaled(q.t[rt][ct][g]);
-        const bool tok_ok = 32 * rt + (g & 3) + 8 * (g >> 2) + 4 * h < WW;
-        k.t[rt][ct][g] = tok_ok ? elu1_scaled(k.t[rt][ct][g]) : 0.f;
-        v.t[rt][ct][g] = v.t[rt][ct][g] * (1.0f / (float)WW);      // values / S (attentions.py:41-42)
+        const bool tok_ok = 32 * ct + (g & 3) + 8 * (g >> 2) + 4 * h < WW;      // padded tokens stay out of the sums
+        k[ot][g] = tok_ok ? elu1_scaled(k[ot][g] * (1.0f / kWgtScale)) : 0.f;
+        v[ot][g] = v[ot][g] * (1.0f / kWgtScale) * (1.0f / (float)WW);          // values / S (attentions.py:41-42)
+        ks[ot] += k[ot][g];
       }
-  // ---- sum_s K[s][d] per feature d (on the lane): over this lane's token registers, then the other half ----
-  {
+    // KV += K^T . V over this slice's tokens: only the two diagonal 32 x 32 tiles hold head blocks
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      float s = 0.f;
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) s += k.t[rt][ct][g];
-      s = swap_halves_add(s);
-      if (h == 0) ksum_lds[32 * ct + r] = s;
-    }
-    __builtin_amdgcn_wave_barrier();
+      for (int s = 0; s < 2; ++s) {
+        half8 ah, al, bh, bl;
+        split8(k[dt], s, ah, al);
+        split8(v[dt], s, bh, bl);
+        mma3(kv[dt], ah, al, bh, bl);
+      }
   }
-  // ---- KV = K^T . V : only the two diagonal 32 x 32 tiles hold head blocks ----
-  f32x16 kv[2];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt) {
-    zero(kv[dt]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {           // k-steps over the 64 (padded) tokens
-      half8 ah, al, bh, bl;
-      split8(k.t[s >> 1][dt], s & 1, ah, al);
-      split8(v.t[s >> 1][dt], s & 1, bh, bl);
-      mma3(kv[dt], ah, al, bh, bl);
-    }
-#pragma unroll
-    for (int g = 0; g < 16; ++g)            // keep d / 8 == v / 8 (rows d = (g&3) + 8 (g>>2) + 4 h, column v = r)
-      kv[dt][g] = ((g >> 2) != (r >> 3)) ? 0.f : kv[dt][g] * (1.0f / kActScale);     // back to the operand scale
-  }
-  // ---- msg^T = KV^T . Q^T and den^T = Kd . Q^T (both sum over d, the row index of KV and of Q^T) ----
-  Tile msg;
-  f32x16 den[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) { zero(msg.t[0][ct]); zero(msg.t[1][ct]); zero(den[ct]); }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {             // k-steps over d
-    const int dt = s >> 1;
-    half8 ah, al;                           // KV rows d as operand A (X^T . B form)
-    split8(kv[dt], s & 1, ah, al);
-    // Kd fragment: row = head r (< 8), element j = sum_s K of feature d = 16 s + 8 (j>>2) + 4 h + (j&3) if in head r
-    half8 dh, dl;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int d = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-      const float val = (r == (d >> 3)) ? ksum_lds[d] * (kSumScale / kActScale) : 0.f;     // ksum_lds is in the operand scale
-      const _Float16 hh = (_Float16)val;
-      dh[j] = hh;
-      dl[j] = (_Float16)(val - (float)hh);
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      half8 bh, bl;
-      split8(q.t[dt][ct], s & 1, bh, bl);
-      mma3(msg.t[dt][ct], ah, al, bh, bl);  // KV[dt] only reaches output rows v in tile dt
-      mma3(den[ct], dh, dl, bh, bl);
-    }
+  for (int ot = 0; ot < 2; ++ot) {
+    const float t = swap_halves_add(ks[ot]);
+    if (h == 0) ksum_lds[32 * ot + r] = t;
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    rescale(msg.t[0][ct], 1.0f / kActScale);
-    rescale(msg.t[1][ct], 1.0f / kActScale);
-  }
-  // Z[token][head] = 1 / (den + eps): den rows 0..3 sit in registers 0..3 of half 0, rows 4..7 in half 1
+  for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    float z[8];
+    for (int g = 0; g < 16; ++g)            // keep d / 8 == v / 8 (rows d = (g&3) + 8 (g>>2) + 4 h, column v = r)
+      kv[dt][g] = ((g >> 2) != (r >> 3)) ? 0.f : kv[dt][g] * (1.0f / kActScale);     // back to the operand scale
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float mine = den[ct][e] * (1.0f / (kSumScale * kActScale)), theirs = other_half(den[ct][e]) * (1.0f / (kSumScale * kActScale));   // true scale
-      z[e] = h ? theirs : mine;             // heads 0..3
-      z[4 + e] = h ? mine : theirs;         // heads 4..7
+  for (int s = 0; s < 4; ++s) split8(kv[s >> 1], s & 1, st.ah[s], st.al[s]);
+}
+
+// update phase: region A holds [Q 8 | M 8 | W2 16 hi, then the same lo], region B [W1 32 hi | 32 lo]
+template <int WW>
+__device__ __forceinline__ void update_phase(const float* xin, float* xout, const KvState& st, const float* ksum_lds,
+                                             const half8* la, const half8* lb, const float* __restrict__ ln, int lane) {
+  constexpr int NCT = (WW + 31) / 32;
+  const int r = lane & 31, h = lane >> 5;
+  const half8 *lal = la + 32 * 64, *lbl = lb + 32 * 64;
+#pragma unroll 1
+  for (int ct = 0; ct < NCT; ++ct) {
+    asm volatile("" : "+v"(lane));          // see kv_phase
+    f32x16 x[2];
+    load_slice<WW>(x, xin, ct, lane);
+    f32x16 q[2];
+    {
+      const f32x16* const rows[2] = {&x[0], &x[1]};
+      gemm_T1<2, 4, 4>(q, rows, la, lal, lane);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = (float)WW / (z[e] + 1e-6f);     // ... * S (attentions.py:46)
-    // msg^T rows v = 32 rt + (g&3) + 8 (g>>2) + 4 h: head = 4 rt + (g >> 2)
-#pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) msg.t[rt][ct][g] *= z[4 * rt + (g >> 2)];
-  }
-  // ---- merge + LayerNorm1 ----
-  Tile m1;
-  {
-    const f32x16 (*const rows[2])[2] = {&msg.t[0], &msg.t[1]};
-    gemm_T<2, 4, 4>(m1.t, rows, la + kTfFragM * 64, lal + kTfFragM * 64, 0, 0, true, true, lane);
-  }
-  // region A is free once every wave has finished its merge product: the second MLP matrix takes its place while
-  // the first MLP product runs out of region B
-  __syncthreads();
-  stage_frags(lds, wl + kTfFrag2 * 64, 16, wv, lane);
-  stage_frags(lds + 16 * 1024, wl + kTfFrags * 64 + kTfFrag2 * 64, 16, wv, lane);
-  layer_norm_T(m1.t, ln, ln + 64, h);
-  // ---- MLP on [x | msg] + LayerNorm2 + residual (one split of x and msg serves all four hidden row tiles) ----
-  f32x16 hid[4][2];
-  {
-    const f32x16 (*const rows[4])[2] = {&x.t[0], &x.t[1], &m1.t[0], &m1.t[1]};
-    gemm_T<4, 8, 8>(hid, rows, lb, lbl, 0, 0, true, true, lane);
-  }
+      for (int g = 0; g < 16; ++g) q[rt][g] = elu1_scaled(q[rt][g]);
+    // msg^T = KV^T . Q^T and den^T = Kd . Q^T (both sum over d, the row index of KV and of Q^T)
+    f32x16 msg[2], den;
+    zero(msg[0]); zero(msg[1]); zero(den);
 #pragma unroll
-  for (int ot = 0; ot < 4; ++ot)
+    for (int s = 0; s < 4; ++s) {
+      half8 bh, bl, dh, dl;
+      split8(q[s >> 1], s & 1, bh, bl);
+      kd_fragment(ksum_lds, s, r, h, dh, dl);
+      mma3(msg[s >> 1], st.ah[s], st.al[s], bh, bl);     // KV[dt] only reaches output rows v in tile dt
+      mma3(den, dh, dl, bh, bl);
+    }
+    rescale(msg[0], 1.0f / kActScale);
+    rescale(msg[1], 1.0f / kActScale);
+    {
+      // Z[token][head] = 1 / (den + eps): den rows 0..3 sit in registers 0..3 of half 0, rows 4..7 in half 1
+      float z[8];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) hid[ot][ct][g] = fmaxf(hid[ot][ct][g], 0.f);
-  stage_wait();
-  Tile m2;
-  {
-    const f32x16 (*const rows[4])[2] = {&hid[0], &hid[1], &hid[2], &hid[3]};
-    gemm_T<2, 8, 8>(m2.t, rows, la, reinterpret_cast<const half8*>(lds + 16 * 1024), 0, 0, true, true, lane);
-  }
-  layer_norm_T(m2.t, ln + 128, ln + 192, h);
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) x.t[rt][ct][g] += m2.t[rt][ct][g];
-}
-
-// window [WW, 64] (token-major) <-> T layout: lane (token r of tile ct, half h) holds features 32 rt + 8 q + 4 h + 0..3
-template <int WW>
-__device__ __forceinline__ void load_window_T(Tile& x, const float* __restrict__ win, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int tok = 32 * ct + r;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tok < WW) v = *reinterpret_cast<const float4*>(win + tok * 64 + 32 * rt + 8 * q + 4 * h);
-        x.t[rt][ct][4 * q] = v.x * kActScale; x.t[rt][ct][4 * q + 1] = v.y * kActScale;      // into the operand scale
-        x.t[rt][ct][4 * q + 2] = v.z * kActScale; x.t[rt][ct][4 * q + 3] = v.w * kActScale;
+      for (int e = 0; e < 4; ++e) {
+        const float mine = den[e] * (1.0f / (kSumScale * kActScale)), theirs = other_half(den[e]) * (1.0f / (kSumScale * kActScale));
+        z[e] = h ? theirs : mine;             // heads 0..3
+        z[4 + e] = h ? mine : theirs;         // heads 4..7
       }
-  }
-}
-template <int WW>
-__device__ __forceinline__ void store_window_T(const Tile& x, float* __restrict__ win, int lane) {
-  const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int tok = 32 * ct + r;
-    if (tok >= WW) continue;
+      for (int e = 0; e < 8; ++e) z[e] = (float)WW / (z[e] + 1e-6f);     // ... * S (attentions.py:46)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) msg[rt][g] *= z[4 * rt + (g >> 2)];
+    }
+    f32x16 m1[2];
+    {
+      const f32x16* const rows[2] = {&msg[0], &msg[1]};
+      gemm_T1<2, 4, 4>(m1, rows, la + 8 * 64, lal + 8 * 64, lane);
+    }
+    layer_norm_T1(m1, ln, ln + 64, h);
+    // MLP in two halves of the hidden layer (64 of its 128 features at a time: 32 registers instead of 64):
+    // m2 = sum over halves of W2[:, half] . relu(W1[half, :] . [x | m1])
+    f32x16 m2[2];
+    zero(m2[0]); zero(m2[1]);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      f32x16 hid[2];
+      {
+        const f32x16* const rows[4] = {&x[0], &x[1], &m1[0], &m1[1]};
+        gemm_T1<2, 8, 8>(hid, rows, lb + (2 * hf) * 8 * 64, lbl + (2 * hf) * 8 * 64, lane);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) hid[ot][g] = fmaxf(hid[ot][g], 0.f);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {             // k-steps 4 hf .. 4 hf + 3 of the second MLP matrix
+        half8 bh, bl;
+        split8(hid[s >> 1], s & 1, bh, bl);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+          const int fi = (ot * 8 + 4 * hf + s) * 64 + lane;
+          mma3(m2[ot], la[16 * 64 + fi], lal[16 * 64 + fi], bh, bl);
+        }
+      }
+    }
+    rescale(m2[0], 1.0f / kWgtScale);
+    rescale(m2[1], 1.0f / kWgtScale);
+    layer_norm_T1(m2, ln + 128, ln + 192, h);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(win + tok * 64 + 32 * rt + 8 * q + 4 * h) =
-            make_float4(x.t[rt][ct][4 * q] * (1.0f / kActScale), x.t[rt][ct][4 * q + 1] * (1.0f / kActScale),
-                        x.t[rt][ct][4 * q + 2] * (1.0f / kActScale), x.t[rt][ct][4 * q + 3] * (1.0f / kActScale));
+      for (int g = 0; g < 16; ++g) x[rt][g] += m2[rt][g];
+    store_slice<WW>(x, xout, ct, lane);
   }
 }
 
-template <int WW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_fine_tf(const float* __restrict__ win0, const float* __restrict__ win1, int m_max,
-               const int32_t* __restrict__ d_count, const half8* __restrict__ wpack, const float* __restrict__ lnp,
-               float* __restrict__ out0, float* __restrict__ out1) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];      // 128 KiB of staged weight fragments (two regions)
-  __shared__ float ksum[4][64];
+// nfrags 1 KiB fragment blocks global -> LDS by LDS-DMA, spread over the NW waves of the workgroup
+template <int NW>
+__device__ __forceinline__ void stage_frags_n(char* dst, const half8* src, int nfrags, int wv, int lane) {
+  for (int f = wv; f < nfrags; f += NW)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 64 + lane),
+                                     (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+}
+
+template <int WW, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const float* win1, int m_max,
+                                                      const int32_t* __restrict__ d_count, const half8* __restrict__ wpack,
+                                                      const float* __restrict__ lnp, float* out0, float* out1) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // region A (64 KiB), region B (64 KiB)
+  __shared__ float ksum[NW][64];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = d_count ? min(d_count[0], m_max) : m_max;
-  if ((int)blockIdx.x * 4 >= M) return;                           // uniform: nothing left for this workgroup
-  // one wave per match, four matches per workgroup (they share the staged weights); a wave beyond the last match
-  // works on the last one again and does not store
-  const int m = min((int)blockIdx.x * 4 + wv, M - 1);
-  const bool store = (int)blockIdx.x * 4 + wv < M;
-  Tile f0, f1;
-  load_window_T<WW>(f0, win0 + (long)m * WW * 64, lane);
-  load_window_T<WW>(f1, win1 + (long)m * WW * 64, lane);
-  // 'self' (transformer.py:89-91): the same layer on each image by itself
-  encoder_layer<WW>(f0, f0, wpack, true, lnp, lds, ksum[wv], wv, lane);
-  encoder_layer<WW>(f1, f1, wpack, false, lnp, lds, ksum[wv], wv, lane);
-  // 'cross' (:92-94): feat0 from feat1, then feat1 from the UPDATED feat0
-  encoder_layer<WW>(f0, f1, wpack + kTfLayerHalf8, true, lnp + kTfLayerFloats, lds, ksum[wv], wv, lane);
-  encoder_layer<WW>(f1, f0, wpack + kTfLayerHalf8, false, lnp + kTfLayerFloats, lds, ksum[wv], wv, lane);
-  if (store) {
-    store_window_T<WW>(f0, out0 + (long)m * WW * 64, lane);
-    store_window_T<WW>(f1, out1 + (long)m * WW * 64, lane);
+  if ((int)blockIdx.x * NW >= M) return;                          // uniform: nothing left for this workgroup
+  // one wave per match; a wave beyond the last match works on the last one again (same values into the same places)
+  const int m = min((int)blockIdx.x * NW + wv, M - 1);
+  const long off = (long)m * WW * 64;
+  char* const ra = lds;
+  char* const rb = lds + kRegionBytes;
+  const half8* const la = reinterpret_cast<const half8*>(ra);
+  const half8* const lb = reinterpret_cast<const half8*>(rb);
+  // the four layer calls of a match: x <- layer(x, src), in place on the output windows after the first touch
+  const float* xin[4] = {win1 + off, win0 + off, out0 + off, out1 + off};
+  float* xout[4] = {out1 + off, out0 + off, out0 + off, out1 + off};
+  const float* src[4] = {win1 + off, win0 + off, out1 + off, out0 + off};
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    const half8* wl = wpack + (c >> 1) * kTfLayerHalf8;
+    const float* ln = lnp + (c >> 1) * kTfLayerFloats;
+    __syncthreads();                    // every wave is past the previous call's use of both regions (and its stores)
+    if ((c & 1) == 0) {                 // a new layer: q, merge, second MLP matrix -> region A
+      stage_frags_n<NW>(ra, wl + kTfFragQ * 64, 8, wv, lane);
+      stage_frags_n<NW>(ra + 8 * 1024, wl + kTfFragM * 64, 8, wv, lane);
+      stage_frags_n<NW>(ra + 16 * 1024, wl + kTfFrag2 * 64, 16, wv, lane);
+      stage_frags_n<NW>(ra + 32 * 1024, wl + (kTfFrags + kTfFragQ) * 64, 8, wv, lane);
+      stage_frags_n<NW>(ra + 40 * 1024, wl + (kTfFrags + kTfFragM) * 64, 8, wv, lane);
+      stage_frags_n<NW>(ra + 48 * 1024, wl + (kTfFrags + kTfFrag2) * 64, 16, wv, lane);
+    }
+    stage_frags_n<NW>(rb, wl + kTfFragK * 64, 16, wv, lane);                          // K, V hi
+    stage_frags_n<NW>(rb + 16 * 1024, wl + (kTfFrags + kTfFragK) * 64, 16, wv, lane);    // K, V lo
+    stage_wait();
+    KvState st;
+    kv_phase<WW>(src[c], lb, ksum[wv], st, lane);
+    __syncthreads();                    // every wave has read K, V: the first MLP matrix takes region B
+    stage_frags_n<NW>(rb, wl + kTfFrag1 * 64, 32, wv, lane);
+    stage_frags_n<NW>(rb + 32 * 1024, wl + (kTfFrags + kTfFrag1) * 64, 32, wv, lane);
+    stage_wait();
+    update_phase<WW>(xin[c], xout[c], st, ksum[wv], la, lb, ln, lane);
   }
 }
 
@@ -501,17 +489,18 @@ extern "C" int fm_fine_transformer(const float* win0, const float* win1, int m_m
   const half8* frag = (const half8*)packed;
   const float* ln = (const float*)((const char*)packed + 2 * (size_t)kTfLayerHalf8 * 16);
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = (m_max + 3) / 4;
+  constexpr int NW = 8;               // matches (waves) per workgroup: two waves per SIMD share the staged weights
+  const int blocks = (m_max + NW - 1) / NW;
   const int smem = 2 * kRegionBytes;
   static unsigned long long set49 = 0, set25 = 0;
   if (WW == 49) {
-    hipError_t e = ensure_dynamic_lds(&k_fine_tf<49>, smem, &set49);
+    hipError_t e = ensure_dynamic_lds(&k_fine_tf<49, NW>, smem, &set49);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_fine_tf<49>, dim3(blocks), dim3(256), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1);
+    hipLaunchKernelGGL((k_fine_tf<49, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1);
   } else {
-    hipError_t e = ensure_dynamic_lds(&k_fine_tf<25>, smem, &set25);
+    hipError_t e = ensure_dynamic_lds(&k_fine_tf<25, NW>, smem, &set25);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_fine_tf<25>, dim3(blocks), dim3(256), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1);
+    hipLaunchKernelGGL((k_fine_tf<25, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1);
   }
   return (int)hipGetLastError();
 }

@@ -234,7 +234,7 @@ int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, 
  * Fine-level context layers between the window crop and the fine matching (network/net.py:79-80): the reference's
  * LocalFeatureTransformer (network/module/transformer.py:34-57,78-96, attentions.py:19-46) in its default fine
  * configuration - d_model 64, 8 heads, layer_names ['self', 'cross'], linear attention, no masks - as ONE kernel,
- * one wave per match, activations in registers from the window load to the window store, float32-equivalent
+ * one wave per match working on 32-token slices kept in registers from their load to their store, float32-equivalent
  * products (hi/lo-split float16 MFMAs).  win0/win1, out0/out1 [dev] float32 [m_max, WW, 64], WW in {25, 49}; out may
  * alias win.  packed = fm_fine_tf_packed_bytes() bytes [dev] filled once per weight update by
  * fm_fine_tf_pack_weights(layer0, layer1, ...): each a HOST array of 10 DEVICE pointers in state-dict order -

@@ -672,7 +672,7 @@ def test_epipolar_errors_against_reference_fixture():
 # ------------------------------------------------------------------ fine context layers in HIP (8(f) row 1)
 @pytest.mark.parametrize("w", [7, 5])
 def test_fine_transformer_vs_oracle(w):
-    """fm_fine_transformer (one wave per match, activations in registers, hi/lo-split MFMAs) against the oracle's
+    """fm_fine_transformer (one wave per match, 32-token slices in registers, hi/lo-split MFMAs) against the oracle's
     restatement of the reference's LocalFeatureTransformer (pinned by net_tail_small) on seeded windows/weights."""
     ww, m = w * w, 37
     wts = synth.transformer_weights(77, 64, 2)
