@@ -280,8 +280,9 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
 
 // update phase: region A holds [Q 8 | M 8 | W2 16 hi, then the same lo], region B [W1 32 hi | 32 lo]
 template <int WW>
-__device__ __forceinline__ void update_phase(const float* xin, float* xout, const KvState& st, const float* ksum_lds,
-                                             const half8* la, const half8* lb, const float* __restrict__ ln, int lane) {
+__device__ __forceinline__ void update_phase(const float* xin, float* xout, bool store, const KvState& st,
+                                             const float* ksum_lds, const half8* la, const half8* lb,
+                                             const float* __restrict__ ln, int lane) {
   constexpr int NCT = (WW + 31) / 32;
   const int r = lane & 31, h = lane >> 5;
   const half8 *lal = la + 32 * 64, *lbl = lb + 32 * 64;
@@ -367,7 +368,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, cons
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int g = 0; g < 16; ++g) x[rt][g] += m2[rt][g];
-    store_slice<WW>(x, xout, ct, lane);
+    if (store) store_slice<WW>(x, xout, ct, lane);
   }
 }
 
@@ -389,8 +390,10 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = d_count ? min(d_count[0], m_max) : m_max;
   if ((int)blockIdx.x * NW >= M) return;                          // uniform: nothing left for this workgroup
-  // one wave per match; a wave beyond the last match works on the last one again (same values into the same places)
+  // one wave per match; a wave beyond the last match works on the last one again and stores nothing (the calls run
+  // in place: a second writer would feed the owner's later calls with already updated slices)
   const int m = min((int)blockIdx.x * NW + wv, M - 1);
+  const bool store = (int)blockIdx.x * NW + wv < M;
   const long off = (long)m * WW * 64;
   char* const ra = lds;
   char* const rb = lds + kRegionBytes;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
     stage_frags_n<NW>(rb, wl + kTfFrag1 * 64, 32, wv, lane);
     stage_frags_n<NW>(rb + 32 * 1024, wl + (kTfFrags + kTfFrag1) * 64, 32, wv, lane);
     stage_wait();
-    update_phase<WW>(xin[c], xout[c], st, ksum[wv], la, lb, ln, lane);
+    update_phase<WW>(xin[c], xout[c], store, st, ksum[wv], la, lb, ln, lane);
   }
 }
 

@@ -727,3 +727,21 @@ def test_coarse_transformer_vs_oracle(n, l, s, layers):
     assert torch.equal(a0, g0) and torch.equal(a1, g1)
     b0, b1 = tf(t0, t1)                      # grad mode: torch ops
     assert (b0.detach() - g0).abs().max().item() <= 5e-5 and (b1.detach() - g1).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("gain", [1e-3, 300.0])
+def test_coarse_transformer_operand_scales_follow_the_data(gain):
+    """The split products carry one power-of-two scale per token, taken from the data: token sets far below / above
+    unit magnitude (where a fixed float16 scale would flush or overflow) keep float32-level accuracy."""
+    layers = ['self', 'cross']
+    wts = synth.transformer_weights(93, 256, len(layers))
+    x0 = (gain * synth.normal(94, 1, (1, 70, 256))).astype(np.float32)
+    x1 = (gain * synth.normal(94, 2, (1, 45, 256))).astype(np.float32)
+    x1[0, 7] = 0.0                                                       # an all-zero token (scale falls back to 1)
+    r0, r1 = orc.local_feature_transformer(x0, x1, wts, 8, layers)
+    packed = ops.pack_coarse_transformer({k: torch.as_tensor(v) for k, v in wts.items()}, len(layers), DEV)
+    g0, g1 = ops.coarse_transformer(torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV), packed, layers)
+    for g, r in ((g0, r0), (g1, r1)):
+        assert torch.isfinite(g).all()
+        err = (g.cpu() - r).abs().max().item()
+        assert err <= 2e-5 * max(1.0, float(r.abs().max())), (err, float(r.abs().max()))
