@@ -240,6 +240,10 @@ int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, 
  * fm_fine_tf_pack_weights(layer0, layer1, ...): each a HOST array of 10 DEVICE pointers in state-dict order -
  * q_proj, k_proj, v_proj, merge .weight [64,64]; mlp.0.weight [128,128]; mlp.2.weight [64,128]; norm1.weight,
  * norm1.bias, norm2.weight, norm2.bias [64] - of layers.0 ('self') and layers.1 ('cross').
+ * Operand scales are fixed (activations x 2^8, weights x 2^12 in float16): window values, their projections and the
+ * MLP's hidden layer must stay below 255 in magnitude and weights below 16 (beyond that the result is inf / NaN, as
+ * float16 overflow dictates; LayerNorm-ed activations of a trained network are O(1)).  fm_coarse_transformer has no such
+ * limit (its scales follow the data).
  */
 size_t fm_fine_tf_packed_bytes(void);
 int fm_fine_tf_pack_weights(const float* const* layer0, const float* const* layer1, void* packed, void* stream);
