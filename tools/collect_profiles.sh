@@ -24,6 +24,9 @@ echo "write done"
 # (4) matrix-core utilisation of the sweeps (SQ block, one pass)
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python bench.py $PM > $O/sq.json 2> $O/sq.err
 echo "sq done"
+# (4b) the same counters in the regime where the matrix cores decide: the batch of 64 pairs
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/sq3 -- python bench.py --workload cfg3 --steps 4 --warmup 2 --skip-cpu --quick --streams 1 --pairs 1 --no-graph > $O/sq3.json 2> $O/sq3.err
+echo "sq3 done"
 # (5) the batch-of-64 workload (cfg3) and the 1024x1024 pair (cfg5): kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python bench.py --workload cfg3 --steps 20 --warmup 3 --skip-cpu --quick > $O/cfg3.json 2> $O/cfg3.err
 echo "cfg3 done"

@@ -8,7 +8,7 @@ committed under profiles/:
   profiles/<round>_bench_cfg2_serial_kernel_stats.csv    same step, one stream, eager (no overlap)
   profiles/<round>_bench_cfg3_kernel_stats.csv, ..._cfg5_...
   profiles/<round>_pmc_fetch_write_cfg2.json             FETCH_SIZE / WRITE_SIZE per launch and kernel (KiB)
-  profiles/<round>_pmc_sq_cfg2.csv                       matrix-core busy / wait fractions per kernel
+  profiles/<round>_pmc_sq_cfg2.csv, ..._cfg3.csv         matrix-core busy / wait fractions per kernel
   profiles/<round>_forward_features_kernel_stats.csv     rocprofv3 --stats of tools/time_matcher.py (net.forward tail)
   profiles/<round>_pmc_sq_forward_features.csv           the same counters for the context-layer kernels
   profiles/<round>_bench_lines.json                      the JSON lines the profiled commands printed
@@ -80,7 +80,8 @@ def main():
         print("wrote pmc_fetch_write")
 
     stats("ctx", f"{rnd}_forward_features_kernel_stats.csv")
-    for tag, out in (("sq", f"{rnd}_pmc_sq_cfg2.csv"), ("ctxsq", f"{rnd}_pmc_sq_forward_features.csv")):
+    for tag, out in (("sq", f"{rnd}_pmc_sq_cfg2.csv"), ("sq3", f"{rnd}_pmc_sq_cfg3.csv"),
+                     ("ctxsq", f"{rnd}_pmc_sq_forward_features.csv")):
         sq = counters(tag)
         if not sq:
             continue
