@@ -190,6 +190,24 @@ def time_kernels(pair):
     return t
 
 
+def copy_rate(nbytes, dev, iters=24):
+    """GB/s (read + write) of a plain device-to-device copy that moves `nbytes` in total: the practical ceiling of an
+    HBM-bound stream of that size on this GPU, next to the 8 TB/s datasheet figure the fractions are quoted against."""
+    n = max(1, int(nbytes) // 8)                       # float32 elements read (and as many written)
+    srcs = [torch.empty(n, device=dev).normal_() for _ in range(6)]      # 6 x ~48 MB: no single buffer stays hot
+    dst = torch.empty(n, device=dev)
+    for sbuf in srcs[:2]:
+        dst.copy_(sbuf)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        dst.copy_(srcs[i % len(srcs)])
+    e1.record()
+    torch.cuda.synchronize()
+    return 8.0 * n / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9
+
+
 def committed_traffic(workload):
     """Fabric/HBM bytes per launch of the max pass (the roofline kernel) from the committed rocprofv3 PMC passes of this
     round (profiles/r02_pmc_fetch_write_cfg2.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py
@@ -517,6 +535,7 @@ def main():
     crop_bytes = 2.0 * m_avg * wl["n"] * ww * cf * 4 * 2      # both images: read + write
     fine_bytes = 2.0 * m_avg * wl["n"] * ww * cf * 4 + 2.0 * m_avg * wl["n"] * 12
     traffic, traffic_src = committed_traffic(a.workload)
+    copy_gbs = copy_rate(crop_bytes, dev)
     out = {
         "metric": ("image-pairs/sec at 640x480 (coarse corr + dual-softmax mutual-NN + fine window refinement)"
                    if a.workload == "cfg2" else f"image-pairs/sec ({a.workload})")
@@ -557,7 +576,9 @@ def main():
             "fine_match": {"bound": "hbm", "kernel": f"k_fine<{a.window}>",
                            "achieved": round(fine_bytes / (tk["fine"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(fine_bytes / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "avg_ms": round(tk["fine"], 5), "algorithmic_bytes": fine_bytes}},
+                           "avg_ms": round(tk["fine"], 5), "algorithmic_bytes": fine_bytes},
+            "plain_copy": {"what": "torch device-to-device copy moving as many bytes as the window crop",
+                           "achieved": round(copy_gbs, 1), "unit": "GB/s", "frac": round(copy_gbs / HBM_PEAK_GBS, 4)}},
     }
     if world > 1:
         out["gather_ms"] = round(gather_ms, 4)
