@@ -300,6 +300,43 @@ def cpu_baseline(wl, window, seed, budget_s=10.0):
                       f"its window crop reads only the matched cells - cheaper than the reference's full F.unfold)"}
 
 
+def batched_rate(wl, window, dev, batch, nstreams, steps=240, nsets=6):
+    """Pairs/s of the same step with `batch` pairs per launch (the kernels take N > 1 natively) on `nstreams` streams:
+    what a server that groups requests gets - fewer, larger launches amortise the per-kernel ramp and tail."""
+    wb = dict(wl, n=batch)
+    pairs = []
+    for p in range(nsets):
+        pairs.append(Pair(wb, 5000 + 31 * p, window, dev, "peaky", share=pairs[p % nstreams] if p >= nstreams else None))
+    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    for i, p in enumerate(pairs):
+        with torch.cuda.stream(streams[i % nstreams]):
+            p.step()
+    torch.cuda.synchronize()
+    graphs = []
+    for i, p in enumerate(pairs):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=streams[i % nstreams]):
+            p.step()
+        graphs.append(g)
+
+    def run(i):
+        with torch.cuda.stream(streams[(i % nsets) % nstreams]):
+            graphs[i % nsets].replay()
+
+    for i in range(24):
+        run(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    with torch.cuda.stream(streams[0]):
+        ms = [p.last[0].read_count() for p in pairs]
+    assert min(ms) > 0
+    return batch * steps / dt
+
+
 def module_api_rate(wl, window, dev, iters=60):
     """Pairs/s through the drop-in modules (modules.CoarseMatching -> FinePreprocess(no context merge) ->
     FineMatching): the reference-shaped call with its host sync (read_count) and per-call allocations."""
@@ -404,6 +441,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--quick", action="store_true", help="skip the secondary lines (dense data, module API)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="diagnostic: pairs per launch (overrides the workload's batch; the JSON line is then not the metric's config)")
     ap.add_argument("--stages", default="all", choices=["all", "coarse", "fine"],
                     help="diagnostic: time only a part of the step (the JSON line is then not the metric)")
     a = ap.parse_args()
@@ -425,7 +464,10 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    wl = WORKLOADS[a.workload]
+    wl = dict(WORKLOADS[a.workload])
+    if a.batch > 0:
+        wl["n"] = a.batch
+        wl["label"] = f"batch of {a.batch}: " + wl["label"]
     # this rank's block of the global batch (world x n pairs per step)
     pair_lo, pair_hi = fdist.shard_range(world * wl["n"], rank, world)
     # enough distinct input sets to exceed the Infinity Cache several times over, not more (generating them
@@ -602,6 +644,15 @@ def main():
             del p
         except Exception as e:       # a secondary line must not take the headline down
             extra["borderline_data"] = {"error": repr(e)}
+        if a.workload == "cfg2" and a.batch == 0:
+            try:
+                extra["batched_launches"] = {
+                    "value": round(batched_rate(wl, a.window, dev, 4, 4), 2), "unit": "image-pairs/s",
+                    "pairs_per_launch": 4, "concurrent_streams": 4,
+                    "note": "the same step with 4 pairs per launch: not the metric's configuration (one pair per step), "
+                            "reported for servers that group requests"}
+            except Exception as e:
+                extra["batched_launches"] = {"error": repr(e)}
         try:
             extra["module_api"] = {"value": round(module_api_rate(wl, a.window, dev), 2), "unit": "image-pairs/s",
                                    "note": "modules.CoarseMatching -> window crop -> modules.FineMatching, one pair at a "
