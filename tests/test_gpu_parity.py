@@ -371,11 +371,12 @@ def test_properties_at_cfg3_size():
 
 # ------------------------------------------------------------------ row a8: net.forward after the backbone
 def test_matcher_tail_against_reference_fixture():
-    """Matcher.forward_features (network/net.py:66-83: coarse context layers on PyTorch-ROCm -> HIP coarse matching
-    -> HIP window crop fused with the context merge -> fine context layers -> HIP fine matching) against the
-    fixture the REFERENCE's own modules produced for the same seeded feature maps and weights.  The context
-    layers run in float32 on another device than the fixture's, which moves the descriptors by ~1e-6 relative:
-    the conf tolerance of this chain test is 1e-4 (guard band likewise), fine keypoints 2e-3 px."""
+    """Matcher.forward_features (network/net.py:66-83: HIP coarse context layers (fm_coarse_transformer, 8 layers,
+    d_model 256) -> HIP coarse matching -> HIP window crop fused with the context merge -> HIP fine context layers
+    (fm_fine_transformer) -> HIP fine matching) against the fixture the REFERENCE's own modules produced for the
+    same seeded feature maps and weights.  The context layers are float32-equivalent products in another summation
+    order than the fixture's, which moves the descriptors by ~1e-6 relative: the conf tolerance of this chain
+    test is 1e-4 (guard band likewise), fine keypoints 2e-3 px."""
     from featurematching_amd.matcher import Matcher
     g = load_golden("net_tail_small")
     inp = net_tail_inputs()
