@@ -29,6 +29,7 @@ struct SelArgs {
   int cap; int32_t* d_count;
   int* cell0; int* cell1;     // cell -> match index + 1 (for the cell-ordered window gathers)
   int* ties0; int* ties1;     // [0] = count, then the matches that lost their cell to an exactly tied match
+  int nblk, nsub;             // k_keep_emit: logical blocks of 256 (row, slot) pairs; blocks per workgroup
 };
 
 // one thread per (row, slot); a row's `slots` threads are adjacent lanes of one wave
@@ -88,17 +89,27 @@ __device__ __forceinline__ bool interior(int id, int hh, int ww, int bd) {
   return y >= bd && y < hh - bd && x >= bd && x < ww - bd;
 }
 
-// One workgroup = 256 (row, slot) pairs = 256/slots consecutive rows.  Workgroups take a TICKET (their logical
-// index in row order) so that a workgroup only ever waits for workgroups that have already started.
+// One logical block = 256 (row, slot) pairs = 256/slots consecutive rows; output offsets come from a look-back over the
+// totals of the blocks before it, in an order in which a workgroup only ever waits for workgroups that have started.
 __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
   __shared__ int s_ticket;
   __shared__ int sm[4];
   __shared__ int rowoff[64], rowcnt[64];
   __shared__ int s_kj[256];
   __shared__ float s_kc[256];
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&a.scal->ticket, 1);
-  __syncthreads();
-  const int blk = s_ticket;
+  // Up to 256 workgroups are all resident (a CU holds several): their launch index is an order in which a workgroup
+  // only ever waits for workgroups that can run.  Larger grids take tickets (returning atomics on ONE address:
+  // ~15 ns each, 146 us for the 9728 blocks of a 64-pair batch - the price of a deadlock-free order there).
+  int wg = blockIdx.x;
+  if (gridDim.x > 256) {
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.scal->ticket, 1);
+    __syncthreads();
+    wg = s_ticket;
+  }
+  for (int sub = 0; sub < a.nsub; ++sub) {
+  const int blk = wg * a.nsub + sub;
+  if (blk >= a.nblk) break;                       // uniform
+  if (sub) __syncthreads();                       // the shared arrays of the previous block have been read
   const int lane = threadIdx.x & 63;
   const long gid = (long)blk * 256 + threadIdx.x;
   const long grow = gid / a.slots;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
       if (lane >= d) incl += o;
     }
     if (threadIdx.x < rows_per_block) rowoff[threadIdx.x] = pre + incl - cntq;
-    if (blk == (int)gridDim.x - 1 && threadIdx.x == 63) {
+    if (blk == a.nblk - 1 && threadIdx.x == 63) {
       const int run = pre + incl;
       a.d_count[0] = run;
       // without the exact-screening pass an overflow of the sum kernels' candidate slots is final
@@ -174,9 +185,9 @@ __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
     }
   }
   __syncthreads();
-  if (b >= a.N || slot >= rowcnt[q]) return;
+  if (b >= a.N || slot >= rowcnt[q]) continue;
   const long o = (long)rowoff[q] + slot;
-  if (o >= a.cap) return;
+  if (o >= a.cap) continue;
   const int jj = s_kj[q * a.slots + slot];
   a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = jj;
   // cell -> match maps: with exact ties the largest match index keeps the cell, every other tied match
@@ -197,6 +208,7 @@ __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
   if (a.scale1) { s1x = a.scale_px * a.scale1[b * 2]; s1y = a.scale_px * a.scale1[b * 2 + 1]; }
   a.k0[o * 2] = (float)(i % a.w0c) * s0x; a.k0[o * 2 + 1] = (float)(i / a.w0c) * s0y;
   a.k1[o * 2] = (float)(jj % a.w1c) * s1x; a.k1[o * 2 + 1] = (float)(jj / a.w1c) * s1y;
+  }
 }
 
 hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
@@ -224,8 +236,11 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   a.cell0 = (int*)(base + w.cell0); a.cell1 = (int*)(base + w.cell1);
   a.ties0 = (int*)(base + w.ties0); a.ties1 = (int*)(base + w.ties1);
   const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
+  a.nblk = blocks; a.nsub = 1;
   hipLaunchKernelGGL(k_cand_conf, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_keep_emit, dim3(blocks), dim3(256), 0, st, a);
+  a.nblk = blocks;
+  a.nsub = 1;      // (4 blocks per ticket serialised the workgroups on each other's look-back: 41 ms at 64 pairs)
+  hipLaunchKernelGGL(k_keep_emit, dim3((blocks + a.nsub - 1) / a.nsub), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
