@@ -92,9 +92,13 @@ class CoarseMatching(nn.Module):
             mkpts1_c = torch.stack([j_ids % w1c, torch.div(j_ids, w1c, rounding_mode='floor')], dim=1) * scale1
         if not self.training:     # cell -> match maps for the cell-ordered window crop of FinePreprocess
             data['_fm_coarse'] = out['_coarse_buffers']
+        # :137-141.  Only the GT-padding sampler produces entries with mconf == 0; every predicted match has
+        # conf > thr > 0, so without it `mconf[mconf != 0]` is mconf itself - and the boolean indexing (a nonzero
+        # with its host sync, three launches) is skipped
+        padded = self.training and self.gt_pad_sampler
         data.update({'b_ids': b_ids, 'i_ids': i_ids, 'j_ids': j_ids,
                      'gt_mask': mconf == 0, 'm_bids': b_ids,
-                     'mkpts0_c': mkpts0_c, 'mkpts1_c': mkpts1_c, 'mconf': mconf[mconf != 0]})   # :137-141
+                     'mkpts0_c': mkpts0_c, 'mkpts1_c': mkpts1_c, 'mconf': mconf[mconf != 0] if padded else mconf})
 
 
 class FinePreprocess(nn.Module):
@@ -190,7 +194,14 @@ class FineMatching(nn.Module):
         self.mix_feat_1 = nn.Linear(ww, 1, bias=True)
 
     def _mix(self, lin):
-        return torch.cat([lin.weight.reshape(-1), lin.bias.reshape(-1)]).float().contiguous()
+        """[WW + 1] = weights then bias, cached until the layer changes (in-place updates bump the version counters)"""
+        key = (lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version)
+        cache = self.__dict__.setdefault('_mix_cache', {})
+        hit = cache.get(id(lin))
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]).float().contiguous())
+            cache[id(lin)] = hit
+        return hit[1]
 
     @torch.no_grad()
     def forward(self, feat_f0, feat_f1, data):
