@@ -585,7 +585,9 @@ def main():
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "int8 screening MFMA (rigorous margin) + exact float32 products for every entry that matters",
+        "dtype": "f32",
+        "dtype_note": "results are float32 (the reference's arithmetic type): int8 MFMA screening with a rigorous error "
+                      "margin decides which entries matter, every entry that does gets an exact float32 product",
         "data": "synthetic",
         "config": {"workload": f"{wl['label']}, {a.window}x{a.window} fine window, '{a.dist}' descriptors",
                    "pairs_per_step_per_gpu": pairs_per_step, "launch": "eager" if a.no_graph else "hipGraph replay",
