@@ -216,14 +216,18 @@ __device__ __forceinline__ void ctf_group(half8 (&wa)[P][NB][2], half8 (&bq)[2][
 
 // acc[i] += W[row block rb0 + i] . ACT over KS k-steps of 16; `frag` = the matrix's fragments, `hi` = LDS address of the
 // hi plane's first k-step (the lo plane LO bytes behind it)
-template <int NB, int KS, int LO>
+// (RB_HI: accumulators NB/2 .. NB-1 take row blocks rb0 + RB_HI + ..: two matrices of one fragment region in one pass)
+template <int NB, int KS, int LO, int RB_HI = 0>
 __device__ __forceinline__ void gemm_stage(const char* __restrict__ frag, int rb0, const void* hi, f32x16 (&acc)[NB], int lane) {
   constexpr int P = 16 / NB;     // k-steps in flight
   constexpr int G = KS / P;
   static_assert(KS % P == 0 && (P == 4 || P == 8) && G >= 2, "step count");
   const char* wn[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) wn[i] = frag + ((size_t)(rb0 + i) * KS * 128 + lane) * 16;
+  for (int i = 0; i < NB; ++i) {
+    const int rb = RB_HI ? rb0 + (i % (NB / 2)) + RB_HI * (i / (NB / 2)) : rb0 + i;
+    wn[i] = frag + ((size_t)rb * KS * 128 + lane) * 16;
+  }
   unsigned ba = (unsigned)(uintptr_t)hi + (unsigned)lane * 16u;      // this lane's (token, k half) slot of a k-step
   half8 wa[P][NB][2] = {}, bq[2][2] = {};
 #pragma unroll
@@ -345,29 +349,19 @@ __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
   const float* const hdr = reinterpret_cast<const float*>(a.w + kFragEnd);
   const bool tok_ok = tok0 + r < sg.L;
   const float S = sg.src_len, xi = xinv[r];
-  // this wave: heads 2 wv, 2 wv + 1 = output row blocks 2 wv, 2 wv + 1 of both projections
+  // this wave: heads 2 wv, 2 wv + 1 = output row blocks 2 wv, 2 wv + 1 of both projections, in ONE pass over the source
+  // planes (the fragments of Wv follow those of Wk: row blocks 8 .. 15 of the same region)
   {
-    f32x16 acc[2] = {};
-    gemm_stage<2, 16, kPlane>(a.w + kFragK, 2 * wv, xh, acc, lane);
-    const float f = hdr[kHdrWinv + 1] * xi;
+    f32x16 acc[4] = {};
+    gemm_stage<4, 16, kPlane, 8>(a.w + kFragK, 2 * wv, xh, acc, lane);
+    const float fk = hdr[kHdrWinv + 1] * xi, fv = hdr[kHdrWinv + 2] * xi;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int ch = 32 * (2 * wv + i) + (g & 3) + 8 * (g >> 2) + 4 * h;
-        kt[ch * kKtStride + r] = tok_ok ? elu1(acc[i][g] * f) : 0.f;       // padding tokens contribute nothing
-      }
-  }
-  {
-    f32x16 acc[2] = {};
-    gemm_stage<2, 16, kPlane>(a.w + kFragV, 2 * wv, xh, acc, lane);
-    const float f = hdr[kHdrWinv + 2] * xi;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int ch = 32 * (2 * wv + i) + (g & 3) + 8 * (g >> 2) + 4 * h;
-        vt[ch * kKtStride + r] = acc[i][g] * f / S;                          // values / S (attentions.py:41-42)
+        kt[ch * kKtStride + r] = tok_ok ? elu1(acc[i][g] * fk) : 0.f;       // padding tokens contribute nothing
+        vt[ch * kKtStride + r] = acc[2 + i][g] * fv / S;                     // values / S (attentions.py:41-42)
       }
   }
   __builtin_amdgcn_wave_barrier();        // the rows read below were written by this wave only
