@@ -22,14 +22,17 @@ int choose_splits(int N, int panels, int tiles, int target) {
   return s;
 }
 
-// column splits of the sparse sum kernel: one round of the chip's workgroup slots (its waves are bound by a chain of
-// memory round trips, which a second round would repeat); when the batch alone fills the chip a split covers up to
-// kUnitsPerSplit 32-column units, which amortises those round trips over more live units
+// column splits of the sparse sum kernel.  Its waves are bound by a chain of memory round trips and leave the CUs
+// they sit on mostly idle, so the target is HALF a round of the chip's workgroup slots: alone the kernel then takes
+// 24 instead of 19 us at one 640x480 pair, but with several pairs in flight the other half of the chip runs another
+// pair's max pass meanwhile (16.4 k -> 17.5 k pairs/s; 48 .. 128 workgroups measured the same, 192+ lower).  When the
+// batch alone fills the chip a split covers up to kUnitsPerSplit 32-column units, which amortises the round trips
+// over more live units.
 static int choose_splits_sparse(int N, int panels, int nunits, int* units_per_split) {
   constexpr int kUnitsPerSplitMax = kUnitsPerSplit;
-  int target = 256;
+  int target = 128;
 #ifdef FM_TUNE_ENV
-  if (const char* e = getenv("FM_TARGET_WGS_S")) target = atoi(e) > 0 ? atoi(e) : 256;
+  if (const char* e = getenv("FM_TARGET_WGS_S")) target = atoi(e) > 0 ? atoi(e) : 128;
 #endif
   int s = target / (N * panels > 0 ? N * panels : 1);
   const int smin = (nunits + kUnitsPerSplitMax - 1) / kUnitsPerSplitMax;
