@@ -114,7 +114,9 @@ def test_layout_query_is_consistent():
     assert 1 <= v[8] <= 32 and v[6] * v[8] <= 256                            # one round of the 256 CUs
     offs = v[10:37] + v[39:]
     assert all(o % 256 == 0 for o in offs)
-    assert v[37] * v[38] >= 150 and v[38] <= 16      # sparse sum kernel: splits x units per split cover Sp/32
+    # sparse sum kernel: splits x units per split cover Sp/32, at most 64 units per split, at most half a round of
+    # the chip's workgroup slots at one pair
+    assert v[37] * v[38] >= 150 and v[38] <= 64 and v[6] * v[37] <= 128
     n = C.c_size_t(0)
     lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n))
     assert offs[-1] == n.value
@@ -125,6 +127,16 @@ def test_ops_refuse_cpu_tensors():
     from featurematching_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.coarse_match(torch.zeros(1, 64, 64), torch.zeros(1, 64, 64), (8, 8), (8, 8), 8.0)
+    # the context-layer kernels likewise: the module keeps its torch ops for CPU tensors, the ops themselves refuse
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.coarse_transformer(torch.zeros(1, 40, 256), torch.zeros(1, 40, 256), torch.zeros(16, dtype=torch.uint8), ['self'])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.fine_transformer(torch.zeros(3, 49, 64), torch.zeros(3, 49, 64), torch.zeros(16, dtype=torch.uint8))
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    tf = LocalFeatureTransformer(dict(d_model=256, nhead=8, layer_names=['self', 'cross'], attention='linear')).eval()
+    with torch.no_grad():
+        a0, a1 = tf(torch.randn(1, 40, 256), torch.randn(1, 33, 256))       # CPU tensors: the torch layers
+    assert a0.shape == (1, 40, 256) and a1.shape == (1, 33, 256) and tf._hip_kind(a0, a1) is None
 
 
 def test_c_driver_under_address_sanitizer():
