@@ -17,6 +17,8 @@ FM_F32, FM_F16, FM_BF16 = 0, 1, 2     # enum fm_dtype
 FM_E_CAPACITY = -5
 FM_E_CANDIDATES = -6
 FM_E_RANGE = -7
+FM_E_DENSE = -8
+FM_MODE_EXACT_SCREENING, FM_MODE_DENSE = 1, 2      # `mode` bits of fm_coarse_match
 
 _lib = None
 
@@ -30,6 +32,7 @@ SIGNATURES = {
     "fm_strerror": (C.c_char_p, [_i]),
     "fm_default_cand_slots": (_i, [_f]),
     "fm_coarse_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
+    "fm_coarse_workspace_bytes_mode": (_i, [_i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "fm_coarse_match": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
                              _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "fm_coarse_match_dtype": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
@@ -37,6 +40,7 @@ SIGNATURES = {
     "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
     "fm_debug_launch_corr": (_i, [_p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "fm_debug_launch_sum_sparse": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "fm_debug_launch_prep": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fm_debug_launch_prep_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "fm_read_count": (_i, [_p, _i, C.POINTER(C.c_int32), _p]),

@@ -63,11 +63,13 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   const size_t nblk = (rows * slots + 255) / 256;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o = align256(o + bytes); return at; };
+  // ---- the common path ----
   w.zero_begin = o;
   w.cand_count = take(rows * 4);
+  w.ccand_count = take(cols * 4);
   w.cand_count_b = take(rows * 4);
+  w.ccand_count_b = take(cols * 4);
   w.dense_cnt = take((size_t)N * 4);
-  w.colbest = take(cols * 4);
   w.cell0 = take(rows * 4);
   w.cell1 = take(cols * 4);
   w.ties0 = take((kTieCap + 1) * 4);
@@ -77,23 +79,26 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.blocktot = take(nblk * 4);
   w.scalars = take(sizeof(Scalars));
   w.zero_end = o;
+  w.q0 = take(rows * C); w.q1 = take(cols * C);
+  w.sigimg = take((size_t)N * 2 * 4);
+  w.l1_0 = take(rows * 4); w.l1_1 = take(cols * 4);
+  w.bstat0 = take(rows / 32 * 16); w.bstat1 = take(cols / 32 * 16);
+  w.emarg = take((size_t)N * 4);
+  w.rowS = take(rows * w.splits_s * 4); w.colS = take(cols * w.panels * 4);
+  w.nmr = take(rows * 4); w.nmc = take(cols * 4);
+  w.umax = take(rows / 32 * (cols / N / 32) * 4);
+  w.cand_j = take(rows * slots * 4); w.cand_x = take(rows * slots * 4);
+  w.ccand_i = take(cols * slots * 4); w.ccand_x = take(cols * slots * 4);
+  w.common_total = o;
+  // ---- FM_MODE_DENSE / FM_MODE_EXACT_SCREENING / conf_matrix ----
   w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);
   w.hi1 = take(cols * C * 2); w.lo1 = take(cols * C * 2);
-  w.q0 = take(rows * C); w.q1 = take(cols * C);
-  w.sig0 = take(rows * 4); w.sig1 = take(cols * 4);
-  w.bsig0 = take(rows / 32 * 4); w.bsig1 = take(cols / 32 * 4);
-  w.l1_0 = take(rows * 4); w.l1_1 = take(cols * 4);
-  w.bl1_0 = take(rows / 32 * 4); w.bl1_1 = take(cols / 32 * 4);
-  w.emarg = take((size_t)N * 4);
   w.f16inv = take((size_t)N * 4);
-  w.rowS = take(rows * w.splits_s * 4); w.colS = take(cols * w.panels * 4);
   w.rowB = take(rows * w.splits * 4); w.colB = take(cols * w.panels * kColParts * 4);
-  w.nmr = take(rows * 4); w.nmc = take(cols * 4);
   w.rsum = take(rows * 4); w.csum = take(cols * 4);
   w.nmr2 = take(rows * 4); w.nmc2 = take(cols * 4);
-  w.umax = take(rows / 32 * (cols / N / 32) * 4);
-  w.cand_j = take(rows * slots * 4); w.cand_conf = take(rows * slots * 4); w.rowbest = take(rows * 4);
-  w.cand_j_b = take(rows * slots * 4); w.cand_conf_b = take(rows * slots * 4);
+  w.cand_j_b = take(rows * slots * 4); w.cand_x_b = take(rows * slots * 4);
+  w.ccand_i_b = take(cols * slots * 4); w.ccand_x_b = take(cols * slots * 4);
   w.total = o;
   return w;
 }
@@ -112,8 +117,9 @@ extern "C" const char* fm_strerror(int s) {
     case FM_E_UNSUPPORTED: return "unsupported configuration (C % 4 == 0 and C <= 256, Cf = 64, W in {5,7}, thr in (0,1))";
     case FM_E_WORKSPACE: return "workspace too small or not 256-byte aligned";
     case FM_E_CAPACITY: return "more matches than the output capacity";
-    case FM_E_CANDIDATES: return "a coarse row exceeded its candidate slots (raise cand_slots)";
-    case FM_E_RANGE: return "descriptor not finite or |x| >= 32768";
+    case FM_E_CANDIDATES: return "a coarse row or column exceeded its candidate slots (FM_MODE_EXACT_SCREENING, then more cand_slots)";
+    case FM_E_RANGE: return "descriptor not finite or |x| >= 32768, or similarities of several thousand (screening margin >= 2^60)";
+    case FM_E_DENSE: return "flat similarity in a sample: call again with FM_MODE_DENSE";
     default: return s > 0 ? hipGetErrorString((hipError_t)s) : "unknown fmatch status";
   }
 }
@@ -129,12 +135,23 @@ extern "C" int fm_default_cand_slots(float thr) {
 // a power of two in [4, 64]: a row's slots are adjacent lanes of one wave and k_keep_emit keeps 256/slots <= 64 rows
 static bool valid_slots(int s) { return s >= 4 && s <= 64 && (s & (s - 1)) == 0; }
 
-extern "C" int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t* bytes) {
+static bool needs_dense_region(int mode, bool want_conf) {
+  return want_conf || (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) != 0;
+}
+
+extern "C" int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int cand_slots, int mode, int want_conf_matrix,
+                                              size_t* bytes) {
   if (!bytes) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
-  *bytes = coarse_layout(N, L, S, C, cand_slots).total;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) return FM_E_UNSUPPORTED;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  *bytes = needs_dense_region(mode, want_conf_matrix != 0) ? w.total : w.common_total;
   return FM_OK;
+}
+
+extern "C" int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t* bytes) {
+  return fm_coarse_workspace_bytes_mode(N, L, S, C, cand_slots, FM_MODE_DENSE | FM_MODE_EXACT_SCREENING, 1, bytes);
 }
 
 static int check_coarse_shape(int N, int L, int S, int C, int cand_slots) {
@@ -145,42 +162,43 @@ static int check_coarse_shape(int N, int L, int S, int C, int cand_slots) {
 
 // Diagnostic: the workspace layout (ints then byte offsets), so that tests can inspect the
 // intermediate statistics of a run.  out[0..9] = N,L,S,C,Lp,Sp,panels,tiles,splits,slots;
-// out[10..] = cand_count, colbest, scalars, blocktot, hi0, lo0, hi1, lo1, q0, q1, sig0, sig1,
-// rowS, colS, rowB, colB, nmr, nmc, rsum, csum, cand_j, cand_conf, rowbest, umax, dense_cnt, rowmax_u,
-// colmax_u, splits_s, units_s, total  (40 values).
+// out[10..] = cand_count, ccand_count, scalars, blocktot, hi0, lo0, hi1, lo1, q0, q1, sigimg, l1_0,
+// rowS, colS, rowB, colB, nmr, nmc, rsum, csum, cand_j, cand_x, ccand_i, umax, dense_cnt, rowmax_u,
+// colmax_u, splits_s, units_s, total; out[40] = common_total (when n_out > 40)  (40 or 41 values).
 extern "C" int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out) {
   if (!out) return FM_E_NULL;
   if (n_out < 40) return FM_E_SHAPE;
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  const int64_t v[40] = {w.N, w.L, w.S, w.C, w.Lp, w.Sp, w.panels, w.tiles, w.splits, w.slots,
-                         (int64_t)w.cand_count, (int64_t)w.colbest, (int64_t)w.scalars, (int64_t)w.blocktot,
+  const int64_t v[41] = {w.N, w.L, w.S, w.C, w.Lp, w.Sp, w.panels, w.tiles, w.splits, w.slots,
+                         (int64_t)w.cand_count, (int64_t)w.ccand_count, (int64_t)w.scalars, (int64_t)w.blocktot,
                          (int64_t)w.hi0, (int64_t)w.lo0, (int64_t)w.hi1, (int64_t)w.lo1, (int64_t)w.q0,
-                         (int64_t)w.q1, (int64_t)w.sig0, (int64_t)w.sig1, (int64_t)w.rowS, (int64_t)w.colS,
+                         (int64_t)w.q1, (int64_t)w.sigimg, (int64_t)w.l1_0, (int64_t)w.rowS, (int64_t)w.colS,
                          (int64_t)w.rowB, (int64_t)w.colB, (int64_t)w.nmr, (int64_t)w.nmc, (int64_t)w.rsum,
-                         (int64_t)w.csum, (int64_t)w.cand_j, (int64_t)w.cand_conf, (int64_t)w.rowbest,
+                         (int64_t)w.csum, (int64_t)w.cand_j, (int64_t)w.cand_x, (int64_t)w.ccand_i,
                          (int64_t)w.umax, (int64_t)w.dense_cnt, (int64_t)w.rowmax_u, (int64_t)w.colmax_u,
-                         w.splits_s, w.units_s, (int64_t)w.total};
+                         w.splits_s, w.units_s, (int64_t)w.total, (int64_t)w.common_total};
   for (int i = 0; i < 40; ++i) out[i] = v[i];
+  if (n_out > 40) out[40] = v[40];
   return FM_OK;
 }
 
 extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S, int C, int h0c, int w0c,
                                int h1c, int w1c, float temperature, float thr, int border_rm, float scale_px,
                                const float* scale0, const float* scale1, void* workspace, size_t workspace_bytes,
-                               int cand_slots, int exact_screening, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                               int cand_slots, int mode, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
                                float* mkpts0_c, float* mkpts1_c, float* mconf, int cap, int32_t* d_count,
                                float* conf_matrix, void* stream) {
   return fm_coarse_match_dtype(feat0, feat1, FM_F32, N, L, S, C, h0c, w0c, h1c, w1c, temperature, thr, border_rm, scale_px,
-                               scale0, scale1, workspace, workspace_bytes, cand_slots, exact_screening, b_ids, i_ids,
+                               scale0, scale1, workspace, workspace_bytes, cand_slots, mode, b_ids, i_ids,
                                j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, conf_matrix, stream);
 }
 
 extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
                                      int h0c, int w0c, int h1c, int w1c, float temperature, float thr, int border_rm,
                                      float scale_px, const float* scale0, const float* scale1, void* workspace,
-                                     size_t workspace_bytes, int cand_slots, int exact_screening, int64_t* b_ids,
+                                     size_t workspace_bytes, int cand_slots, int mode, int64_t* b_ids,
                                      int64_t* i_ids, int64_t* j_ids, float* mkpts0_c, float* mkpts1_c, float* mconf,
                                      int cap, int32_t* d_count, float* conf_matrix, void* stream) {
   if (!feat0 || !feat1 || !workspace || !d_count) return FM_E_NULL;
@@ -189,38 +207,44 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) return FM_E_UNSUPPORTED;
+  const bool exact = (mode & FM_MODE_EXACT_SCREENING) != 0;
+  const bool dense = needs_dense_region(mode, conf_matrix != nullptr);      // exact screening and conf_matrix read the planes too
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return FM_E_WORKSPACE;
+  if (workspace_bytes < (dense ? w.total : w.common_total) || ((uintptr_t)workspace & 255)) return FM_E_WORKSPACE;
   char* base = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
   const float inv_ct = 1.0f / ((float)C * temperature);
 
-  // one dispatch: clear the per-call counters, split both images into float16 planes
+  // The common path is four launches: prep -> max pass -> sparse sum kernel -> assignment.
+  // one dispatch: clear the per-call counters, quantise both images (one int8 step per image), L1 norms
   hipError_t e = launch_prep(feat0, feat1, in_dtype, C, w, base, st);
   if (e != hipSuccess) return (int)e;
-  // max pass: row / column / unit maxima of the int8 screening product (atomicMax: no partials, no reduction kernel)
+  // max pass: row / column / unit maxima of the integer screening product (atomicMax: no partials, no reduction kernel)
   e = launch_max_i8(w, base, st);
   if (e != hipSuccess) return (int)e;
-  // sparse sum kernel: stabilisers, live units, exact terms of the few significant entries, candidates;
-  // flags the units with too many significant entries (flat similarity) for the dense kernel
-  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, st);
+  // sparse sum kernel: stabilisers, live units, exact terms of the few significant entries, candidates (listed per row
+  // and per column); flags the samples with too many significant entries per unit (flat similarity)
+  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, st);
   if (e != hipSuccess) return (int)e;
-  // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or the
-  // conf_matrix sweep will run); exits at once otherwise
-  e = launch_prep_f16(feat0, feat1, in_dtype, C, w, base, (exact_screening || conf_matrix) ? 1 : 0, st);
-  if (e != hipSuccess) return (int)e;
-  // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
-  // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
-  e = launch_corr(1, w, base, inv_ct, thr, st);
-  if (e != hipSuccess) return (int)e;
-  // The common path goes straight to the assignment (k_cand_conf folds the softmax denominators of its
-  // candidates from the partial sums itself).  The denominators / log-softmax offsets of EVERY row and column
-  // are only needed by the exact screening and by the dense conf_matrix:
-  if (exact_screening || conf_matrix) {
+  if (dense) {
+    // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or
+    // the conf_matrix sweep will run); exits at once otherwise
+    e = launch_prep_f16(feat0, feat1, in_dtype, C, w, base, (exact || conf_matrix) ? 1 : 0, st);
+    if (e != hipSuccess) return (int)e;
+    // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
+    // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
+    e = launch_corr(1, w, base, inv_ct, thr, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  // The assignment folds the softmax denominators of its candidates from the partial sums itself.  The
+  // denominators / log-softmax offsets of EVERY row and column are only needed by the exact screening and by the
+  // dense conf_matrix:
+  if (exact || conf_matrix) {
     e = launch_reduce(1, w, base, inv_ct, st);
     if (e != hipSuccess) return (int)e;
   }
-  if (exact_screening) {       // exits immediately unless the sum kernels' screening overflowed a row's slots
+  if (exact) {                 // exits immediately unless the sum kernels' screening overflowed a row's slots
     e = launch_corr(2, w, base, inv_ct, thr, st);
     if (e != hipSuccess) return (int)e;
   }
@@ -229,7 +253,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
     if (e != hipSuccess) return (int)e;
   }
   e = launch_select(w, base, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
-                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, exact_screening, st);
+                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, mode, st);
   return (int)e;
 }
 
@@ -269,8 +293,19 @@ extern "C" int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, c
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  return (int)launch_sum_sparse(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr,
+  return (int)launch_sum_sparse(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, 1,
                                 (hipStream_t)stream);
+}
+
+// Diagnostic: launch k_prep_split alone (it clears the per-call counters: run a complete fm_coarse_match afterwards
+// before anything reads the workspace's candidate lists again).
+extern "C" int fm_debug_launch_prep(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
+                                    int cand_slots, void* stream) {
+  if (!workspace || !feat0 || !feat1) return FM_E_NULL;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  return (int)launch_prep(feat0, feat1, FM_F32, C, w, (char*)workspace, (hipStream_t)stream);
 }
 
 // Diagnostic: launch the float16 plane kernel alone (force = 1: every sample; 0: the samples flagged for the dense
@@ -291,7 +326,7 @@ extern "C" int fm_debug_reset_counters(void* workspace, int N, int L, int S, int
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  hipError_t e = hipMemsetAsync((char*)workspace + w.cand_count, 0, w.colbest - w.cand_count, (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync((char*)workspace + w.cand_count, 0, w.cell0 - w.cand_count, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   return (int)hipMemsetAsync((char*)workspace + w.scalars, 0, sizeof(Scalars), (hipStream_t)stream);
 }
@@ -306,6 +341,7 @@ extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, vo
   if (e != hipSuccess) return (int)e;
   *m_out = h[0];
   if (h[1] & FM_DEV_RANGE) return FM_E_RANGE;
+  if (h[1] & FM_DEV_DENSE) return FM_E_DENSE;
   if (h[1] & FM_DEV_CANDIDATES) return FM_E_CANDIDATES;
   if (h[1] & FM_DEV_CAPACITY) return FM_E_CAPACITY;
   if (h[0] > cap) return FM_E_CAPACITY;

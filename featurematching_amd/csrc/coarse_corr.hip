@@ -73,8 +73,11 @@ struct CorrArgs {
   const int* dense_units; // their total (0: MODE 1 has nothing to do)
   const float* emarg;     // [N] log2-domain bound of |screening product - exact product| * k
   const float* f16inv;    // [N] 1 / (power-of-two scales of the two images' float16 planes): accumulator -> dot product
+  const float* sigimg;    // [N][2] int8 steps of the two images: unit maxima are integer screening products
   int* cand_count; int* cand_j; float* cand_x; unsigned* flags;
+  int* ccand_count; int* ccand_i; float* ccand_x;      // the same candidates listed per column (rows, dot products)
   int* cand_count_b; int* cand_j_b; float* cand_x_b;   // the dense kernel's candidate set (samples it redid)
+  int* ccand_count_b; int* ccand_i_b; float* ccand_x_b;
   float* conf;            // MODE 3: dense [N,L,S] output
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, slots;
   int pgroup;             // panels per XCD-locality group of the workgroup order
@@ -209,6 +212,11 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   int* const cand_count = dense_sample ? a.cand_count_b : a.cand_count;
   int* const cand_j = dense_sample ? a.cand_j_b : a.cand_j;
   float* const cand_x = dense_sample ? a.cand_x_b : a.cand_x;
+  int* const ccand_count = dense_sample ? a.ccand_count_b : a.ccand_count;
+  int* const ccand_i = dense_sample ? a.ccand_i_b : a.ccand_i;
+  float* const ccand_x = dense_sample ? a.ccand_x_b : a.ccand_x;
+  // unit maxima of the max pass are integer screening products: x~ = sigma_0 sigma_1 (q_i . q_j)
+  const float kss = SPARSE ? a.k * a.sigimg[b * 2] * a.sigimg[b * 2 + 1] : 0.f;
   const _Float16* planes1[2] = {a.hi1 + (long)b * a.Sp * C, a.lo1 + (long)b * a.Sp * C};   // fragment-major
   // Small per-workgroup tables live in their OWN static LDS objects, not in the dynamic tile ring: hipcc
   // orders every LDS access it can see against outstanding LDS-DMA writes it cannot tell apart from it -
@@ -362,10 +370,16 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     }
   };
 
+  // a candidate goes to its row's AND its column's slot list (k_select reads the row best from the one, the column
+  // best from the other)
   auto record_candidate = [&](long grow, int col, float x) {
+    const long gcol = (long)b * a.Sp + col;
     const int pos = atomicAdd(&cand_count[grow], 1);
+    const int cpos = atomicAdd(&ccand_count[gcol], 1);
     if (pos < a.slots) { cand_j[grow * a.slots + pos] = col; cand_x[grow * a.slots + pos] = x; }
-    else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
+    if (cpos < a.slots) { ccand_i[gcol * a.slots + cpos] = (int)(grow - (long)b * a.Lp); ccand_x[gcol * a.slots + cpos] = x; }
+    if (pos >= a.slots || cpos >= a.slots)
+      atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
   };
 
   // this lane's 16 row stabilisers (rows 8q + 4h + 0..3 of the wave's 32), four 16-byte LDS reads
@@ -527,7 +541,7 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
     }
     bool skip = false;
     if (SPARSE) {
-      const float top = __builtin_fmaf(um, a.k, emarg);             // >= k * (exact product), log2 domain
+      const float top = __builtin_fmaf(um, kss, emarg);             // >= k * (exact product), log2 domain
       const float cmax = wave_max64(t * kTileCols + (u & 1) * 32 + r < a.S ? nmc_u : -INFINITY);
       skip = __builtin_amdgcn_readfirstlane((int)((top + wmax_nmr < -kSkipLog2) && (top + cmax < -kSkipLog2)));
     }
@@ -578,9 +592,9 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   // Hand the parked candidates to the per-row slot lists: one entry per lane.  The slot reservation (a
   // global atomic with return, one memory round trip) is issued here and consumed after the row
   // reduction below, which hides most of its latency.
-  int q_pos = -1, q_key = 0;
+  int q_pos = -1, q_cpos = -1, q_key = 0;
   float q_x = 0.f;
-  long q_row = 0;
+  long q_row = 0, q_col = 0;
   if (SPARSE) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -589,13 +603,17 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
       q_key = qkey[lane];
       q_x = qx[lane];
       q_row = (long)b * a.Lp + wrow0 + (q_key & 31);
+      q_col = (long)b * a.Sp + (q_key >> 5);
       q_pos = atomicAdd(&cand_count[q_row], 1);
+      q_cpos = atomicAdd(&ccand_count[q_col], 1);
     }
   }
   auto commit_candidates = [&]() {
     if (SPARSE && q_pos >= 0) {
       if (q_pos < a.slots) { cand_j[q_row * a.slots + q_pos] = q_key >> 5; cand_x[q_row * a.slots + q_pos] = q_x; }
-      else atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
+      if (q_cpos < a.slots) { ccand_i[q_col * a.slots + q_cpos] = wrow0 + (q_key & 31); ccand_x[q_col * a.slots + q_cpos] = q_x; }
+      if (q_pos >= a.slots || q_cpos >= a.slots)
+        atomicOr(a.flags, MODE == 1 ? (unsigned)FM_INT_SCREEN_OVERFLOW : (unsigned)FM_DEV_CANDIDATES);
     }
   };
   if (MODE >= 2) { commit_candidates(); return; }
@@ -655,12 +673,16 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.rowmax_u = (unsigned*)(base + w.rowmax_u); a.colmax_u = (unsigned*)(base + w.colmax_u);
   a.dense_cnt = (const int*)(base + w.dense_cnt);
   a.cand_count_b = (int*)(base + w.cand_count_b); a.cand_j_b = (int*)(base + w.cand_j_b);
-  a.cand_x_b = (float*)(base + w.cand_conf_b);
+  a.cand_x_b = (float*)(base + w.cand_x_b);
+  a.ccand_count = (int*)(base + w.ccand_count); a.ccand_i = (int*)(base + w.ccand_i); a.ccand_x = (float*)(base + w.ccand_x);
+  a.ccand_count_b = (int*)(base + w.ccand_count_b); a.ccand_i_b = (int*)(base + w.ccand_i_b);
+  a.ccand_x_b = (float*)(base + w.ccand_x_b);
+  a.sigimg = (const float*)(base + w.sigimg);
   a.dense_units = &((const Scalars*)(base + w.scalars))->dense_units;
   a.umax = (float*)(base + w.umax); a.emarg = (const float*)(base + w.emarg);
   a.f16inv = (const float*)(base + w.f16inv);
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j);
-  a.cand_x = (float*)(base + w.cand_conf);   // raw dot product now, replaced by conf in k_cand_conf
+  a.cand_x = (float*)(base + w.cand_x);
   a.flags = (unsigned*)(base + w.scalars);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
   a.splits = mode ? w.splits : w.splits0; a.tiles_per_split = (w.tiles + a.splits - 1) / a.splits; a.slots = w.slots;

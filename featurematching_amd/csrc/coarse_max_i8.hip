@@ -5,15 +5,20 @@
 // maximum of every 32 x 32 unit (which units are alive) - so it runs on the int8 planes of k_prep_split:
 // v_mfma_i32_32x32x32_i8 does twice the k per instruction of the f16 form, the planes have half the bytes
 // (prologue, LDS-DMA, LDS reads all halve), and the quantisation error is bounded rigorously (fm_device.h).
-//   screening product  x~_ij = sigma_i * sigma_j * (q_i . q_j)   (exact integer dot, one step per descriptor)
-// Maxima are published with an order-preserving atomicMax (exact, order independent): no partial arrays and no
+//   screening product  x~_ij = sigma_0 * sigma_1 * (q_i . q_j)   (exact integer dot; ONE step per image)
+// Because the step is uniform per image, x~ is ordered like the integer dot product: the whole epilogue is integer
+// arithmetic on the accumulators - one v_max_i32 per register for the row maxima, a v_max3_i32 tree for the column
+// maxima, six DPP steps for the unit maximum - about 35 vector instructions per 32 x 32 unit against the 8 MFMAs
+// (256 cycles) that produce it.  (With one step per descriptor, as in round 2, every element needed convert + two
+// scalings + two float maxima: 130 instructions per unit, 2.5x the matrix cores' time.)
+// Maxima are published as biased integer codes with atomicMax (exact, order independent): no partial arrays and no
 // reduction kernel.
 //
 // Structure (as the dense sum kernel k_corr): one workgroup = 8 waves = a 256-row panel of image 0 x a range of
 // 64-column tiles of image 1; each wave keeps its 32 rows as A fragments in 32 VGPRs for the whole sweep; image-1
 // tiles (16 KiB at C = 256) stream through a 4-deep LDS ring by LDS-DMA (global_load_lds_dwordx4, 1 KiB fragment
 // block per instruction), handed over by counted vmcnt + raw s_barrier; B fragments are read ahead through
-// inline-asm ds_read_b128 + counted lgkmcnt.  The LDS footprint (64 KiB) and ~100 VGPRs leave room for two
+// inline-asm ds_read_b128 + counted lgkmcnt.  The LDS footprint (64 KiB) and < 100 VGPRs leave room for two
 // workgroups per CU.
 #include "fm_device.h"
 
@@ -24,7 +29,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct MaxArgs {
   const signed char* q0; const signed char* q1;
-  const float* sig0; const float* sig1;
   unsigned* rowmax_u; unsigned* colmax_u; float* umax;
   float* diag;            // diagnostic build: stamp buffer
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, pgroup;
@@ -34,24 +38,23 @@ __device__ __forceinline__ int xcd_remap_m(int bid, int n) {
   const int q = n >> 3, rem = n & 7, x = bid & 7, y = bid >> 3;
   return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + y;
 }
-template <int CTRL, int BANK>
-__device__ __forceinline__ float dpp_mov_m(float old, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
-                                                               CTRL, 0xf, BANK, false));
-}
-// max over the 32 lanes that share lane>>5, result in every lane of the half; DPP only
-__device__ __forceinline__ float half_max32(float v) {
-  v = fmaxf(v, dpp_mov_m<0xB1, 0xf>(v, v));
-  v = fmaxf(v, dpp_mov_m<0x4E, 0xf>(v, v));
-  { float t = dpp_mov_m<0x104, 0x5>(v, v); t = dpp_mov_m<0x114, 0xA>(t, v); v = fmaxf(v, t); }
-  v = fmaxf(v, dpp_mov_m<0x128, 0xf>(v, v));
-  { float p = v, q = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q)); v = fmaxf(p, q); }
+// max over the 32 lanes that share lane>>5; valid in lanes 16..31 / 48..63.  One v_max_i32 with a DPP operand per
+// step (hipcc keeps v_mov_b32_dpp + v_max apart when written with the update_dpp builtin): xor 1, xor 2, half mirror
+// and mirror reduce every row of 16 lanes, row_bcast:15 hands row 0's result to row 1 (and row 2's to row 3).
+// s_nop 1: the two wait states between a VALU write and a DPP read of the same register.
+__device__ __forceinline__ int half_max32_hi_i(int v) {
+  asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+               : "+v"(v));
   return v;
 }
-__device__ __forceinline__ float halves_max(float v) {
-  float p = v, q = v;
+__device__ __forceinline__ int halves_max_i(int v) {
+  int p = v, q = v;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
-  return fmaxf(p, q);
+  return max(p, q);
 }
 
 template <int C>
@@ -63,8 +66,7 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   constexpr int PER_WAVE = PIECES >= 8 ? PIECES / 8 : 1;   // (C = 64: the 8 waves bring the 4 blocks twice - harmless)
   constexpr int PF = KS8 < 4 ? KS8 : 4;             // B-fragment read-ahead
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float s_colred[2 * 8 * 64];            // per tile parity: the 8 waves' column maxima of 64 columns
-  __shared__ float s_meta[NBUF * 64];               // per ring slot: the quantisation steps of the tile's 64 columns
+  __shared__ unsigned s_colmax[2 * 64];             // per tile parity: q_encode'd column maxima of 64 columns (ds_max_u32)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -107,11 +109,6 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
                                        (__attribute__((address_space(3))) void*)(smem + buf * TILE_BYTES + blk * 1024),
                                        16, 0, 0);
     }
-    // the tile's 64 column steps travel the same way (4-byte LDS-DMA: no register carries a global load across
-    // the sweep - hipcc would order every such load against the tile prefetch with vmcnt(0))
-    if (wv == 0)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.sig1 + (long)b * a.Sp + t * kTileCols + lane),
-                                       (__attribute__((address_space(3))) void*)(s_meta + buf * 64), 4, 0, 0);
   };
 #pragma unroll
   for (int d = 0; d < NBUF - 1; ++d)
@@ -124,28 +121,16 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
   }
-  // the quantisation steps of this lane's 16 accumulator rows (rows 8q + 4h + 0..3 in registers 4q..4q+3): four
-  // 16-byte loads, in flight together with the A fragments and the first tiles.  Padded rows (>= L: zero
-  // descriptors) get NaN: their products then drop out of every maximum (v_max ignores NaN), no masks needed.
-  float sgA[16];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 v = *reinterpret_cast<const float4*>(a.sig0 + (long)b * a.Lp + wrow0 + 8 * q + 4 * h);
-    sgA[4 * q] = v.x; sgA[4 * q + 1] = v.y; sgA[4 * q + 2] = v.z; sgA[4 * q + 3] = v.w;
-  }
-  if (wrow0 + 32 > a.L) {
-#pragma unroll
-    for (int g = 0; g < 16; ++g)
-      if (wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) sgA[g] = __builtin_nanf("");
-  }
+  const unsigned colmax_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)s_colmax;
+  if (tid < 128) asm volatile("ds_write_b32 %0, %1" ::"v"(colmax_a + tid * 4), "v"(0u) : "memory");
 
-  float rstat[16];               // running maxima of (q_i . q_j) * sigma_j over the columns seen so far
+  int rstat[16];                 // running maxima of q_i . q_j over the columns this lane has seen
 #pragma unroll
-  for (int g = 0; g < 16; ++g) rstat[g] = -INFINITY;
+  for (int g = 0; g < 16; ++g) rstat[g] = kQMasked;
+  // padded rows (>= L: zero descriptors) must not win a column or unit maximum
+  const bool row_edge = wrow0 + 32 > a.L;       // wave-uniform
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned colred_a = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_colred;
-  const unsigned meta_a = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_meta;
   v16i acc;
   auto mfma_unit = [&](int u) {
     const unsigned base = lds0 + (((u >> 1) - t0) % NBUF) * TILE_BYTES + (u & 1) * (KS8 * 1024) + lane * 16;
@@ -183,13 +168,11 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(2 * PER_WAVE) : "memory");
     __builtin_amdgcn_s_barrier();
   };
-  tile_barrier(min(NBUF - 2, t1 - t0 - 1));     // first tile landed
+  tile_barrier(min(NBUF - 2, t1 - t0 - 1));     // first tile landed, column maxima cleared
   // name the registers loaded before the loop: hipcc then waits for them here and not (with vmcnt(0), i.e. also
   // for the tile prefetch) at their first use inside the loop
 #pragma unroll
   for (int ks = 0; ks < KS8; ++ks) asm volatile("" ::"v"(aq[ks]));
-#pragma unroll
-  for (int g = 0; g < 16; ++g) asm volatile("" ::"v"(sgA[g]));
 #ifdef FM_DIAG_CLOCK
   dg_pro = __builtin_amdgcn_s_memtime() - dg0;
 #endif
@@ -197,30 +180,29 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   for (int u = 2 * t0; u < 2 * t1; ++u) {
     const int t = u >> 1, par = (t - t0) & 1;
     if ((u & 1) == 0 && t + NBUF - 1 < t1) { DG_T0 stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF); DG_ADD(dg_stage) }   // refill the slot of tile t-1
-    float sB;                  // this lane's column step (inline asm: see k_corr on compiler-visible LDS accesses)
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sB) : "v"(meta_a + (((t - t0) % NBUF) * 64 + (u & 1) * 32 + r) * 4));
     { DG_T0 mfma_unit(u); asm volatile("" ::"v"(acc)); DG_ADD(dg_mfma) }
 #ifdef FM_DIAG_CLOCK
     const unsigned long long dg_e0 = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- epilogue: rows in registers, columns on lanes ----
+    // ---- epilogue: rows in registers, columns on lanes; integers only ----
     const int ucol0 = u * 32;
-    // padded columns (>= S: zero descriptors) get a NaN step: their products drop out of every maximum
-    if (ucol0 + r >= a.S) sB = __builtin_nanf("");
-    float cstat = -INFINITY;
+    if (row_edge || ucol0 + 32 > a.S) {              // padded rows (>= L) / columns (>= S) never count
+      const bool cok = ucol0 + r < a.S;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float rv = (float)acc[g] * sB;
-      rstat[g] = fmaxf(rstat[g], rv);
-      cstat = fmaxf(cstat, rv * sgA[g]);
+      for (int g = 0; g < 16; ++g)
+        if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) acc[g] = kQMasked;
     }
-    cstat = halves_max(cstat);
-    const float um = half_max32(cstat);                              // unit maximum (the halves are merged already)
-    if (lane == 0) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * nunits + u] = um;
-    if (h == 0) {
-      const unsigned ad = colred_a + (((par * 8 + wv) * 64 + (u & 1) * 32 + r) * 4);
-      asm volatile("ds_write_b32 %0, %1" ::"v"(ad), "v"(cstat) : "memory");
-    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) rstat[g] = max(rstat[g], acc[g]);
+    int c01 = max(max(acc[0], acc[1]), acc[2]), c23 = max(max(acc[3], acc[4]), acc[5]);
+    int c45 = max(max(acc[6], acc[7]), acc[8]), c67 = max(max(acc[9], acc[10]), acc[11]);
+    int c89 = max(max(acc[12], acc[13]), acc[14]);
+    int cstat = max(max(max(c01, c23), c45), max(max(c67, c89), acc[15]));
+    cstat = halves_max_i(cstat);                                     // this lane's column over the wave's 32 rows
+    if (h == 0)                                                       // the 8 waves' maxima of a column meet in LDS
+      asm volatile("ds_max_u32 %0, %1" ::"v"(colmax_a + (par * 64 + (u & 1) * 32 + r) * 4), "v"(q_encode(cstat)) : "memory");
+    const int um = half_max32_hi_i(cstat);                           // unit maximum (lanes 16..31, 48..63)
+    if (lane == 63) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * nunits + u] = (float)um;
 #ifdef FM_DIAG_CLOCK
     dg_epi += __builtin_amdgcn_s_memtime() - dg_e0;
 #endif
@@ -228,18 +210,14 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
       // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
       { DG_T0 tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1)); DG_ADD(dg_bar) }
       if (wv == (t & 7)) {
-        // every wave's column maxima of tile t are in LDS (their writes precede the barrier): this wave folds them
-        float pv[8];
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8)
-          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(pv[w8]) : "v"(colred_a + (par * 8 * 64 + lane) * 4), "i"(w8 * 256));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
-                     "+v"(pv[6]), "+v"(pv[7]));
-        float cv = pv[0];
-#pragma unroll
-        for (int w8 = 1; w8 < 8; ++w8) cv = fmaxf(cv, pv[w8]);
-        if (t * kTileCols + lane < a.S && cv > -INFINITY)
-          __hip_atomic_fetch_max(a.colmax_u + (long)b * a.Sp + t * kTileCols + lane, ord_encode(cv), __ATOMIC_RELAXED,
+        // every wave's column maxima of tile t are in LDS (their ds_max precede the barrier): this wave publishes them
+        // and clears the words for tile t+2 (whose first ds_max follows the next barrier, which this wave joins after
+        // its write has completed: tile_barrier waits lgkmcnt(0))
+        unsigned cv;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(colmax_a + (par * 64 + lane) * 4) : "memory");
+        asm volatile("ds_write_b32 %0, %1" ::"v"(colmax_a + (par * 64 + lane) * 4), "v"(0u) : "memory");
+        if (t * kTileCols + lane < a.S && cv != 0u)
+          __hip_atomic_fetch_max(a.colmax_u + (long)b * a.Sp + t * kTileCols + lane, cv, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -250,13 +228,13 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
 #endif
   // ---- row maxima of this workgroup's column range ----
 #pragma unroll
-  for (int g = 0; g < 16; ++g) rstat[g] = half_max32(rstat[g]) * sgA[g];
-  if (r == 0) {
+  for (int g = 0; g < 16; ++g) rstat[g] = half_max32_hi_i(rstat[g]);
+  if (r == 31) {
     unsigned* out = a.rowmax_u + (long)b * a.Lp + wrow0 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 16; ++g)
-      if (wrow0 + 4 * h + (g & 3) + 8 * (g >> 2) < a.L && rstat[g] > -INFINITY)
-        __hip_atomic_fetch_max(out + (g & 3) + 8 * (g >> 2), ord_encode(rstat[g]), __ATOMIC_RELAXED,
+      if (wrow0 + 4 * h + (g & 3) + 8 * (g >> 2) < a.L && rstat[g] > kQMasked)
+        __hip_atomic_fetch_max(out + (g & 3) + 8 * (g >> 2), q_encode(rstat[g]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifdef FM_DIAG_CLOCK
@@ -274,10 +252,9 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st) {
   MaxArgs a;
   a.q0 = (const signed char*)(base + w.q0); a.q1 = (const signed char*)(base + w.q1);
-  a.sig0 = (const float*)(base + w.sig0); a.sig1 = (const float*)(base + w.sig1);
   a.rowmax_u = (unsigned*)(base + w.rowmax_u); a.colmax_u = (unsigned*)(base + w.colmax_u);
   a.umax = (float*)(base + w.umax);
-  a.diag = (float*)(base + w.rowB);
+  a.diag = (float*)(base + w.rowB);      // (diagnostic builds run on a full-size workspace)
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
   a.splits = w.splits0; a.tiles_per_split = (w.tiles + a.splits - 1) / a.splits;
   {

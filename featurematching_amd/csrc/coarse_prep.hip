@@ -1,6 +1,6 @@
 // Coarse stage, kernels around the correlation sweeps:
-//   k_prep_split  : float32 descriptors -> int8 screening plane + block scales + L1 norms, and two float16
-//                   planes (hi, lo = x - hi)
+//   k_prep_split  : descriptors -> int8 screening plane (one step per image) + L1 norms, clipped mass, block maxima
+//   k_prep_f16    : two float16 planes (hi, lo = x - hi) for the samples the dense sum kernel redoes
 //   k_reduce_sums : partial sums of the sum kernels -> softmax denominators of every row / column
 //                   (exact screening and dense conf_matrix only)
 //
@@ -20,12 +20,12 @@ struct PrepArgs {
   const void* src0; const void* src1; int in_dtype;      // FM_F32 / FM_F16 / FM_BF16 rows [N, rows, c_in]
   _Float16* hi0; _Float16* lo0; _Float16* hi1; _Float16* lo1;      // k_prep_f16 only
   const int* dense_cnt; int force; float* f16inv;        // k_prep_f16: which samples need planes; 1 / (scale0 scale1)
-  const float* bsig0r; const float* bsig1r; int N;
+  const float4* bstat0r; const float4* bstat1r; int N;
   signed char* q0; signed char* q1;   // int8 screening planes (fragment-major for v_mfma_i32_32x32x32_i8)
-  float* sig0; float* sig1;           // quantisation step of every descriptor (row)
-  float* bsig0; float* bsig1;         // largest step per 32-row block
+  float* sigimg;                      // [N][2] the quantisation step of image 0 / image 1 of every sample
   float* l1_0; float* l1_1;           // L1 norm of every descriptor
-  float* bl1_0; float* bl1_1;         // largest L1 norm per 32-row block (+inf: the block holds a bad value)
+  float4* bstat0; float4* bstat1;     // per 32-row block: {largest L1 norm (+inf: the block holds a bad value), largest
+                                      // clipped L1 mass of a descriptor, largest |x|, 0}
   uint4* zero; int zero_vec;          // per-call counters to clear (uint4 units)
   int L, S, Lp, Sp, c_in, blocks0;    // blocks0 = workgroups that convert image 0
 };
@@ -39,18 +39,21 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 // C = padded channel count of the planes (64/128/256); c_in <= C = channels of the source rows,
 // the planes are zero beyond c_in (a dot product does not change under zero padding).
 //   All planes are FRAGMENT-major, one workgroup per 32-row block.
+//   int8 plane (the screening product of the max pass and the sparse sum kernel): q = clamp(rint(x / sigma), +-127)
+//   with ONE step sigma per IMAGE: the screening product sigma_0 sigma_1 (q_i . q_j) is then ordered like the integer
+//   dot product itself, so the max pass and the sparse kernel's screening stay in integer arithmetic (maxima, compares:
+//   one vector instruction per accumulator register instead of convert + two scalings + two float maxima), and identical
+//   descriptors get identical codes and margins wherever they sit, which keeps exact conf ties exact
+//   (coarse_matching_new.py:105-106 keeps all tied entries).  The step must not depend on a grid-wide reduction (that
+//   would be a kernel boundary): every workgroup derives it from the SAME kPrepSampleRows rows spread over the image,
+//   sigma = kPrepHeadroom * max|x| of that sample / 127.  Whatever exceeds 127 sigma elsewhere in the image is clipped
+//   and its L1 mass enters the error margin (fm_device.h): the bounds stay rigorous for any data, outliers only cost
+//   margin.  Element (row, k) lives at
+//     (((row/32 * KS8 + ks) * 2 + h) * 32 + row%32) * 16 + k%16   with 16-channel chunk k/16 = h*KS8 + ks,
+//   the 64 lanes of a v_mfma_i32_32x32x32_i8 operand fragment are one contiguous 1 KiB block per k-step.
 //   float16 planes (hi, lo = x - hi; the dense sum kernel's float32-equivalent product) are written by k_prep_f16
 //   below, only for the samples that need them: element (row, k) lives at
-//     (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8   with chunk q = k/8 = h*KSTEPS + ks,
-//   i.e. the 64 lanes (h, row%32) of a v_mfma_f32_32x32x16_f16 operand fragment are one contiguous 1 KiB block
-//   per (32-row block, k-step).
-//   int8 plane (the screening product of the max pass and the sparse sum kernel): q = rint(x / sigma) with one
-//   step sigma = max_k|x_k| / 127 per DESCRIPTOR - identical descriptors get identical codes, steps and error
-//   margins wherever they sit, which keeps exact conf ties exact (coarse_matching_new.py:105-106 keeps all tied
-//   entries); element (row, k) lives at
-//     (((row/32 * KS8 + ks) * 2 + h) * 32 + row%32) * 16 + k%16   with 16-channel chunk k/16 = h*KS8 + ks,
-//   the 64 lanes of a v_mfma_i32_32x32x32_i8 operand fragment again one contiguous 1 KiB block per k-step.
-//   The quantisation error is bounded rigorously from sigma and the descriptors' L1 norms (fm_device.h).
+//     (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8   with chunk q = k/8 = h*KSTEPS + ks.
 // A workgroup that sees a non-finite / out-of-range value reports +inf as its block L1 maximum; k_sum_sparse
 // turns that into FM_DEV_RANGE (the flag word itself is cleared by this kernel, so it cannot be set here).
 template <int C>
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
     const int lo_ = blockIdx.x * per, hi_ = min(lo_ + per, a.zero_vec);
     for (int k = lo_ + tid; k < hi_; k += 256) a.zero[k] = make_uint4(0u, 0u, 0u, 0u);
   }
-  __shared__ float sm[8][33];
+  __shared__ float sm[8][33], sm2[8][33];
+  __shared__ float wred[3][4];
   // ---------------- one 32-row block of image 0 or image 1 ----------------
   const bool img1 = (int)blockIdx.x >= a.blocks0;
   const long rb = img1 ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;   // row block over N*Lp/32 (N*Sp/32)
@@ -75,6 +79,36 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   const int local = (int)(rb * 32 - (long)b * rows_pad) + r;
   const long row_off = ((long)b * rows + local) * a.c_in;          // elements
   const void* const src = img1 ? a.src1 : a.src0;
+
+  // ---- the image's step: largest |x| over kPrepSampleRows rows spread evenly over the image (the same rows in every
+  // workgroup of the image: max is order independent, so all of them arrive at the same step).  <= 8 loads per
+  // thread, all in flight together and ahead of the block's own rows ----
+  float amax_s = 0.f;
+  {
+    const int ns = min(kPrepSampleRows, rows);
+    const int vpr = a.c_in >> 2;                       // 4-channel vectors per row (c_in % 4 == 0)
+    const int total = ns * vpr;                        // <= 32 * 64
+    float4 sv[8];
+    // (every workgroup starts at another row of the sample: 300 workgroups asking for the same lines at the same
+    // moment queue up on a few L2 channels)
+    const int rot = (int)((blockIdx.x * 5u) % (unsigned)ns) * vpr;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      int idx = p * 256 + tid;
+      sv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < total) {
+        idx += rot;
+        if (idx >= total) idx -= total;
+        const int t = idx / vpr, v = idx - t * vpr;
+        const long e = ((long)b * rows + (long)t * rows / ns) * a.c_in + v * 4;
+        if (a.in_dtype == FM_F32) sv[p] = *reinterpret_cast<const float4*>((const float*)src + e);
+        else sv[p] = half4_to_float4(*reinterpret_cast<const uint2*>((const unsigned short*)src + e), a.in_dtype);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      amax_s = fmaxf(amax_s, fmaxf(fmaxf(fabsf(sv[p].x), fabsf(sv[p].y)), fmaxf(fabsf(sv[p].z), fabsf(sv[p].w))));
+  }
   // Full float32 rows (the common hand-over): the 32 rows of this block are one contiguous span of the source -
   // copied to LDS with fully coalesced 16-byte loads (one row per wave instruction at C = 256) and read back in
   // the (row = lane, 8-channel chunk) order the fragment-major stores need.  Row pitch + 16 bytes: the 32 lanes
@@ -92,14 +126,23 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
       const float4 v = idx < valid4 ? span[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4*>(&tile[(idx / (C / 4)) * PITCH + (idx % (C / 4)) * 4]) = v;
     }
-    __syncthreads();
   }
-  float x[NCH][8];
-  float s1 = 0.f, amax = 0.f;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) amax_s = fmaxf(amax_s, __shfl_xor(amax_s, m));
+  if ((tid & 63) == 0) wred[0][tid >> 6] = amax_s;
+  __syncthreads();
+  amax_s = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3]));
+  // (a non-finite sample: some block reports the bad value below and the call fails; the step is irrelevant then)
+  const float sigma = amax_s < INFINITY ? amax_s * (kPrepHeadroom / 127.0f) : 1.0f;
+  const float inv_sigma = sigma > 0.f ? 1.0f / sigma : 0.f;
+  const float clip_at = 127.f * sigma;
+  if (tid == 0 && rb * 32 == (long)b * rows_pad) a.sigimg[b * 2 + (img1 ? 1 : 0)] = sigma;
+
+  float s1 = 0.f, amax = 0.f, clip = 0.f;
   bool bad = false;
 #pragma unroll
   for (int n = 0; n < NCH; ++n) {             // C/8 chunks of 8 channels, 8 per pass
-    const int q = n * 8 + (tid >> 5);
+    const int q = n * 8 + (tid >> 5);          // 8-channel chunk; 16-channel chunk q/2, byte half q&1
     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
     if (staged) {
       v0 = *reinterpret_cast<const float4*>(&tile[r * PITCH + q * 8]);
@@ -121,61 +164,44 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
       }
     }
     bad = bad || bad_value(v0) || bad_value(v1);
-    x[n][0] = v0.x; x[n][1] = v0.y; x[n][2] = v0.z; x[n][3] = v0.w;
-    x[n][4] = v1.x; x[n][5] = v1.y; x[n][6] = v1.z; x[n][7] = v1.w;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      s1 += fabsf(x[n][e]);
-      amax = fmaxf(amax, fabsf(x[n][e]));
-    }
-  }
-  // per-row maximum of |x| -> quantisation step; per-row L1 norms (a row's channels sit in 8 threads)
-  __shared__ float sm2[8][33];
-  sm[tid >> 5][r] = s1;
-  sm2[tid >> 5][r] = amax;
-  __syncthreads();
-  amax = sm2[0][r];
-#pragma unroll
-  for (int g = 1; g < 8; ++g) amax = fmaxf(amax, sm2[g][r]);
-  // (an all-zero row - padding - gets sigma = 0: it must not raise the image's largest step)
-  const float sigma = amax * (1.0f / 127.0f);
-  const float inv_sigma = amax > 0.f ? 1.0f / sigma : 0.f;
-#pragma unroll
-  for (int n = 0; n < NCH; ++n) {
-    const int q = n * 8 + (tid >> 5);          // 8-channel chunk; 16-channel chunk q/2, byte half q&1
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     int w0 = 0, w1 = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int v = (int)fminf(fmaxf(rintf(x[n][e] * inv_sigma), -127.f), 127.f);
-      const int u = (int)fminf(fmaxf(rintf(x[n][4 + e] * inv_sigma), -127.f), 127.f);
-      w0 |= (v & 0xff) << (8 * e);
-      w1 |= (u & 0xff) << (8 * e);
+    for (int e = 0; e < 8; ++e) {
+      const float ax = fabsf(x[e]);
+      s1 += ax;
+      amax = fmaxf(amax, ax);
+      clip += fmaxf(ax - clip_at, 0.f);
+      const int v = (int)fminf(fmaxf(rintf(x[e] * inv_sigma), -127.f), 127.f);
+      if (e < 4) w0 |= (v & 0xff) << (8 * e);
+      else w1 |= (v & 0xff) << (8 * (e - 4));
     }
     const int q16 = q >> 1;
     const int h = q16 / KS8, ks = q16 - h * KS8;
     const long off = (((rb * KS8 + ks) * 2 + h) * 32 + r) * 16 + (q & 1) * 8;
     *reinterpret_cast<int2*>(qp + off) = make_int2(w0, w1);
   }
-  float bl1 = 0.f, bsg = 0.f;
-  if (tid < 32) {
-    float t = 0.f;
+  // per-row L1 norm and clipped mass (a row's channels sit in 8 threads); block maxima
+  sm[tid >> 5][r] = s1;
+  sm2[tid >> 5][r] = clip;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) t += sm[g][tid];
-    (img1 ? a.l1_1 : a.l1_0)[rb * 32 + tid] = t;
-    (img1 ? a.sig1 : a.sig0)[rb * 32 + tid] = sigma;
-    bl1 = t;
-    bsg = sigma;
-  }
-  if (__any(bad)) bl1 = INFINITY;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { bl1 = fmaxf(bl1, __shfl_xor(bl1, m)); bsg = fmaxf(bsg, __shfl_xor(bsg, m)); }
-  __shared__ float wred[4];
-  if ((tid & 63) == 0) wred[tid >> 6] = bl1;
+  for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+  const bool anybad = __any(bad);
+  if ((tid & 63) == 0) { wred[1][tid >> 6] = amax; wred[2][tid >> 6] = anybad ? 1.f : 0.f; }
   __syncthreads();
-  if (tid == 0) {
-    const float m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-    (img1 ? a.bl1_1 : a.bl1_0)[rb] = m;
-    (img1 ? a.bsig1 : a.bsig0)[rb] = bsg;          // wave 0 holds the 32 rows' steps
+  if (tid < 32) {
+    float t = 0.f, ce = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { t += sm[g][tid]; ce += sm2[g][tid]; }
+    (img1 ? a.l1_1 : a.l1_0)[rb * 32 + tid] = t;
+    float bl1 = t, bce = ce;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) { bl1 = fmaxf(bl1, __shfl_xor(bl1, m)); bce = fmaxf(bce, __shfl_xor(bce, m)); }
+    if (tid == 0) {
+      const bool bb = wred[2][0] + wred[2][1] + wred[2][2] + wred[2][3] > 0.f;
+      (img1 ? a.bstat1 : a.bstat0)[rb] = make_float4(bb ? INFINITY : bl1, bce,
+                                                     fmaxf(fmaxf(wred[1][0], wred[1][1]), fmaxf(wred[1][2], wred[1][3])), 0.f);
+    }
   }
 }
 
@@ -196,17 +222,17 @@ __global__ __launch_bounds__(256) void k_prep_f16(PrepArgs a) {
   const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
   const int b = (int)(rb * 32 / rows_pad);
   if (!a.force && a.dense_cnt[b] == 0) return;                 // uniform
-  // largest |x| of both images of this sample (127 x the largest quantisation step of k_prep_split)
+  // largest |x| of both images of this sample (block maxima of k_prep_split)
   __shared__ float wred[2][4];
   float m0 = 0.f, m1 = 0.f;
-  for (int i = tid; i < a.Lp / 32; i += 256) m0 = fmaxf(m0, a.bsig0r[(long)b * (a.Lp / 32) + i]);
-  for (int i = tid; i < a.Sp / 32; i += 256) m1 = fmaxf(m1, a.bsig1r[(long)b * (a.Sp / 32) + i]);
+  for (int i = tid; i < a.Lp / 32; i += 256) m0 = fmaxf(m0, a.bstat0r[(long)b * (a.Lp / 32) + i].z);
+  for (int i = tid; i < a.Sp / 32; i += 256) m1 = fmaxf(m1, a.bstat1r[(long)b * (a.Sp / 32) + i].z);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, m)); m1 = fmaxf(m1, __shfl_xor(m1, m)); }
   if ((tid & 63) == 0) { wred[0][tid >> 6] = m0; wred[1][tid >> 6] = m1; }
   __syncthreads();
-  m0 = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3])) * 127.f;
-  m1 = fmaxf(fmaxf(wred[1][0], wred[1][1]), fmaxf(wred[1][2], wred[1][3])) * 127.f;
+  m0 = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3]));
+  m1 = fmaxf(fmaxf(wred[1][0], wred[1][1]), fmaxf(wred[1][2], wred[1][3]));
   auto pow2_scale = [](float amax) {        // 2^k with amax * 2^k in [2^13, 2^14); 1 for an all-zero (or bad) image
     if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
     int e;
@@ -262,15 +288,14 @@ static void fill_prep_args(PrepArgs& a, const void* feat0, const void* feat1, in
   a.hi0 = (_Float16*)(base + w.hi0); a.lo0 = (_Float16*)(base + w.lo0);
   a.hi1 = (_Float16*)(base + w.hi1); a.lo1 = (_Float16*)(base + w.lo1);
   a.q0 = (signed char*)(base + w.q0); a.q1 = (signed char*)(base + w.q1);
-  a.sig0 = (float*)(base + w.sig0); a.sig1 = (float*)(base + w.sig1);
-  a.bsig0 = (float*)(base + w.bsig0); a.bsig1 = (float*)(base + w.bsig1);
+  a.sigimg = (float*)(base + w.sigimg);
   a.l1_0 = (float*)(base + w.l1_0); a.l1_1 = (float*)(base + w.l1_1);
-  a.bl1_0 = (float*)(base + w.bl1_0); a.bl1_1 = (float*)(base + w.bl1_1);
+  a.bstat0 = (float4*)(base + w.bstat0); a.bstat1 = (float4*)(base + w.bstat1);
   a.zero = (uint4*)(base + w.zero_begin); a.zero_vec = (int)((w.zero_end - w.zero_begin) / 16);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.c_in = c_in;
   a.blocks0 = (int)((long)w.N * w.Lp / 32);
   a.dense_cnt = (const int*)(base + w.dense_cnt); a.force = 0; a.f16inv = (float*)(base + w.f16inv);
-  a.bsig0r = (const float*)(base + w.bsig0); a.bsig1r = (const float*)(base + w.bsig1); a.N = w.N;
+  a.bstat0r = (const float4*)(base + w.bstat0); a.bstat1r = (const float4*)(base + w.bstat1); a.N = w.N;
 }
 
 hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
@@ -316,6 +341,7 @@ __global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ r
                                                      const float* __restrict__ nm_r, const float* __restrict__ nm_c,
                                                      float* __restrict__ nm2_r, float* __restrict__ nm2_c,
                                                      int* __restrict__ cand_count, int* __restrict__ cand_count_b,
+                                                     int* __restrict__ ccand_count, int* __restrict__ ccand_count_b,
                                                      const int* __restrict__ dense_cnt, const Scalars* __restrict__ scal) {
   const int side = blockIdx.z;
   const int b = blockIdx.y;
@@ -350,7 +376,11 @@ __global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ r
   const long gi = (long)b * len + idx;
   (side ? nm2_c : nm2_r)[gi] = (side ? nm_c : nm_r)[gi] - __log2f(v);
   // the sum kernels overflowed some row's candidate slots: the exact screening sweep refills the lists from scratch
-  if (side == 0 && (scal->flags & FM_INT_SCREEN_OVERFLOW)) (dense ? cand_count_b : cand_count)[gi] = 0;
+  // (both listings of the candidates: per row and per column)
+  if (scal->flags & FM_INT_SCREEN_OVERFLOW) {
+    if (side == 0) (dense ? cand_count_b : cand_count)[gi] = 0;
+    else (dense ? ccand_count_b : ccand_count)[gi] = 0;
+  }
 }
 
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st) {
@@ -362,6 +392,7 @@ hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, 
                      (float*)(base + w.csum), w.Lp, w.Sp, w.splits_s, w.splits, w.panels,
                      (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
                      (float*)(base + w.nmc2), (int*)(base + w.cand_count), (int*)(base + w.cand_count_b),
+                     (int*)(base + w.ccand_count), (int*)(base + w.ccand_count_b),
                      (const int*)(base + w.dense_cnt), (const Scalars*)(base + w.scalars));
   return hipGetLastError();
 }

@@ -1,7 +1,9 @@
-// Coarse stage, sparse assignment on the candidate list of the sum kernels:
-//   k_cand_conf : float32 conf of every candidate from its dot product, best conf per row / column
-//   k_keep_emit : threshold + mutual nearest neighbour + border, a row's matches sorted by j, deterministic
-//                 prefix offsets (ticket-ordered look-back over the workgroup totals) -> outputs in (b, i, j) order
+// Coarse stage, sparse assignment on the candidate lists of the sum kernels - ONE kernel:
+//   float32 conf of every candidate from its dot product and the softmax denominators (folded from the partial sums
+//   on the spot), best conf of its row (the row's candidates sit in adjacent lanes) and of its column (the column's
+//   candidates, listed per column by the sum kernels, are re-evaluated with the same arithmetic - no grid-wide pass),
+//   threshold + mutual nearest neighbour + border, a row's matches sorted by j, deterministic prefix offsets
+//   (ticket-ordered look-back over the workgroup totals) -> outputs in (b, i, j) order.
 //
 // Follows network/utils/coarse_matching_new.py:99-141.  Every entry of the L x S matrix
 // that is not a candidate has conf <= thr, so it can neither pass :99 nor beat a surviving
@@ -16,10 +18,11 @@ struct SelArgs {
   const float* rowS; const float* colS;   // partial sums of the sparse sum kernel: rows [N][splits_s][Lp], columns [N][panels][Sp]
   const float* rowB; const float* colB;   // ... of the dense sum kernel (valid when it had units): rows [N][splits][Lp]
   int exact;                              // exact screening ran: its overflow is then FM_DEV_CANDIDATES already
-  const int* cand_count; const int* cand_j; float* cand_conf;          // the sparse sum kernel's candidates
-  const int* cand_count_b; const int* cand_j_b; float* cand_conf_b;    // the dense one's (samples with dense_cnt > 0)
+  const int* cand_count; const int* cand_j; const float* cand_x;          // the sparse sum kernel's candidates, per row
+  const int* ccand_count; const int* ccand_i; const float* ccand_x;       // ... the same entries per column
+  const int* cand_count_b; const int* cand_j_b; const float* cand_x_b;    // the dense one's (samples with dense_cnt > 0)
+  const int* ccand_count_b; const int* ccand_i_b; const float* ccand_x_b;
   const int* dense_cnt;
-  float* rowbest; unsigned* colbest;
   int* blocktot; Scalars* scal;
   int N, L, S, C, Lp, Sp, splits, splits_s, panels, slots;
   int h0c, w0c, h1c, w1c, border;
@@ -29,59 +32,8 @@ struct SelArgs {
   int cap; int32_t* d_count;
   int* cell0; int* cell1;     // cell -> match index + 1 (for the cell-ordered window gathers)
   int* ties0; int* ties1;     // [0] = count, then the matches that lost their cell to an exactly tied match
-  int nblk, nsub;             // k_keep_emit: logical blocks of 256 (row, slot) pairs; blocks per workgroup
+  int nblk;                   // logical blocks of 256 (row, slot) pairs
 };
-
-// one thread per (row, slot); a row's `slots` threads are adjacent lanes of one wave
-__global__ __launch_bounds__(256) void k_cand_conf(SelArgs a) {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long grow = gid / a.slots;                 // b*Lp + i
-  const int slot = (int)(gid - grow * a.slots);
-  const int b = (int)(grow / a.Lp);
-  const int i = (int)(grow - (long)b * a.Lp);
-  float conf = 0.f;
-  // a sample is handled by ONE sum kernel: the dense one redid it if the sparse one flagged any of its units
-  const bool dense = b < a.N && a.dense_cnt[b] > 0;
-  const int* cand_count = dense ? a.cand_count_b : a.cand_count;
-  const int* cand_j = dense ? a.cand_j_b : a.cand_j;
-  float* cand_conf = dense ? a.cand_conf_b : a.cand_conf;
-  const int cnt = (b < a.N && i < a.L) ? min(cand_count[grow], a.slots) : 0;
-  if (slot < cnt) {
-    const int j = cand_j[grow * a.slots + slot];
-    // the dot product the sum kernel produced for this entry: the same number that entered the row
-    // and column sums, so numerator and denominator are consistent (as in the reference's softmax)
-    const float x = cand_conf[grow * a.slots + slot];
-    // softmax denominators of this row and this column, folded from pass B's partials in a fixed order
-    // (all loads independent: one round trip; no separate reduction kernel on the common path)
-    float rs = 0.f, cs = 0.f;
-    auto fold = [](const float* p, int n, long pitch) {       // 8 loads in flight, added in index order
-      float t = 0.f;
-      for (int q0 = 0; q0 < n; q0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (q0 + q < n) ? p[(long)(q0 + q) * pitch] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += v[q];
-      }
-      return t;
-    };
-    if (dense) {
-      rs = fold(a.rowB + (long)b * a.splits * a.Lp + i, a.splits, a.Lp);
-      cs = fold(a.colB + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
-    } else {
-      rs = fold(a.rowS + (long)b * a.splits_s * a.Lp + i, a.splits_s, a.Lp);
-      cs = fold(a.colS + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
-    }
-    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmr[grow])) / rs;
-    const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, a.k, a.nmc[(long)b * a.Sp + j])) / cs;
-    conf = pr * pc;
-    cand_conf[grow * a.slots + slot] = conf;
-    atomicMax(&a.colbest[(long)b * a.Sp + j], __float_as_uint(conf));
-  }
-  float best = conf;
-  for (int m = 1; m < a.slots; m <<= 1) best = fmaxf(best, __shfl_xor(best, m));
-  if (slot == 0 && b < a.N) a.rowbest[grow] = best;
-}
 
 __device__ __forceinline__ bool interior(int id, int hh, int ww, int bd) {
   if (bd <= 0) return true;
@@ -89,48 +41,91 @@ __device__ __forceinline__ bool interior(int id, int hh, int ww, int bd) {
   return y >= bd && y < hh - bd && x >= bd && x < ww - bd;
 }
 
-// One logical block = 256 (row, slot) pairs = 256/slots consecutive rows; output offsets come from a look-back over the
-// totals of the blocks before it, in an order in which a workgroup only ever waits for workgroups that have started.
-__global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
+// n partial sums `pitch` floats apart, 8 loads in flight, added in index order (the order is part of the result:
+// every thread that needs a denominator folds it the same way, so equal inputs give equal bits)
+__device__ __forceinline__ float fold_partials(const float* p, int n, long pitch) {
+  float t = 0.f;
+  for (int q0 = 0; q0 < n; q0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (q0 + q < n) ? p[(long)(q0 + q) * pitch] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += v[q];
+  }
+  return t;
+}
+
+// conf of an entry from the dot product the sum kernel produced for it - the same number that entered the row and
+// the column sum, so numerator and denominator are consistent (as in the reference's softmax, :68)
+__device__ __forceinline__ float entry_conf(float x, float k, float nmr, float rs, float nmc, float cs) {
+#pragma clang fp contract(off)
+  const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x, k, nmr)) / rs;
+  const float pc = __builtin_amdgcn_exp2f(__builtin_fmaf(x, k, nmc)) / cs;
+  return pr * pc;
+}
+
+// One logical block = 256 (row, slot) pairs = 256/slots consecutive rows; a row's `slots` threads are adjacent lanes of
+// one wave.  Output offsets come from a look-back over the totals of the blocks before it, in TICKET order: a
+// workgroup only ever waits for workgroups that have started (no assumption on dispatch order or residency).  The
+// ticket (a returning atomic on one address) is requested first and consumed after the candidate loads, so its round
+// trip hides behind them.
+__global__ __launch_bounds__(256) void k_select(SelArgs a) {
   __shared__ int s_ticket;
   __shared__ int sm[4];
   __shared__ int rowoff[64], rowcnt[64];
   __shared__ int s_kj[256];
   __shared__ float s_kc[256];
-  // Up to 256 workgroups are all resident (a CU holds several): their launch index is an order in which a workgroup
-  // only ever waits for workgroups that can run.  Larger grids take tickets (returning atomics on ONE address:
-  // ~15 ns each, 146 us for the 9728 blocks of a 64-pair batch - the price of a deadlock-free order there).
-  int wg = blockIdx.x;
-  if (gridDim.x > 256) {
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.scal->ticket, 1);
-    __syncthreads();
-    wg = s_ticket;
-  }
-  for (int sub = 0; sub < a.nsub; ++sub) {
-  const int blk = wg * a.nsub + sub;
-  if (blk >= a.nblk) break;                       // uniform
-  if (sub) __syncthreads();                       // the shared arrays of the previous block have been read
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&a.scal->ticket, 1);
+  __syncthreads();
+  const int blk = s_ticket;
   const int lane = threadIdx.x & 63;
   const long gid = (long)blk * 256 + threadIdx.x;
-  const long grow = gid / a.slots;
+  const long grow = gid / a.slots;                 // b*Lp + i
   const int slot = (int)(gid - grow * a.slots);
   const int b = (int)(grow / a.Lp);
   const int i = (int)(grow - (long)b * a.Lp);
+  // a sample is handled by ONE sum kernel: the dense one redid it if the sparse one flagged any of its units
   const bool dense = b < a.N && a.dense_cnt[b] > 0;
   const int* cand_count = dense ? a.cand_count_b : a.cand_count;
   const int* cand_j = dense ? a.cand_j_b : a.cand_j;
-  const float* cand_conf = dense ? a.cand_conf_b : a.cand_conf;
+  const float* cand_x = dense ? a.cand_x_b : a.cand_x;
+  const int* ccand_count = dense ? a.ccand_count_b : a.ccand_count;
+  const int* ccand_i = dense ? a.ccand_i_b : a.ccand_i;
+  const float* ccand_x = dense ? a.ccand_x_b : a.ccand_x;
+  const float* rowP = dense ? a.rowB : a.rowS;
+  const float* colP = dense ? a.colB : a.colS;
+  const int rparts = dense ? a.splits : a.splits_s;
   const int cnt = (b < a.N && i < a.L) ? min(cand_count[grow], a.slots) : 0;
   bool keep = false;
   int j = 0x7fffffff;
-  float conf = 0.f;
+  float conf = 0.f, colbest = 0.f;
   if (slot < cnt) {
     j = cand_j[grow * a.slots + slot];
-    conf = cand_conf[grow * a.slots + slot];
-    keep = conf > a.thr && conf == a.rowbest[grow] &&
-           __float_as_uint(conf) == a.colbest[(long)b * a.Sp + j] &&
-           interior(i, a.h0c, a.w0c, a.border) && interior(j, a.h1c, a.w1c, a.border);
+    const float x = cand_x[grow * a.slots + slot];
+    const long gcol = (long)b * a.Sp + j;
+    // softmax denominators of this row and this column, folded from the sum kernels' partials in a fixed order
+    // (all loads independent: one round trip)
+    const float rs = fold_partials(rowP + (long)b * rparts * a.Lp + i, rparts, a.Lp);
+    const float cs = fold_partials(colP + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
+    const float nmc = a.nmc[gcol];
+    conf = entry_conf(x, a.k, a.nmr[grow], rs, nmc, cs);
+    // best conf of the column: its candidates (this one among them), each with its own row's denominator
+    const int ccnt = min(ccand_count[gcol], a.slots);
+    for (int t = 0; t < ccnt; ++t) {
+      const int i2 = ccand_i[gcol * a.slots + t];
+      float c2 = conf;
+      if (i2 != i) {
+        const float rs2 = fold_partials(rowP + (long)b * rparts * a.Lp + i2, rparts, a.Lp);
+        c2 = entry_conf(ccand_x[gcol * a.slots + t], a.k, a.nmr[(long)b * a.Lp + i2], rs2, nmc, cs);
+      }
+      colbest = fmaxf(colbest, c2);
+    }
   }
+  float rowbest = conf;
+  for (int m = 1; m < a.slots; m <<= 1) rowbest = fmaxf(rowbest, __shfl_xor(rowbest, m));
+  if (slot < cnt)
+    keep = conf > a.thr && conf == rowbest && conf == colbest &&
+           interior(i, a.h0c, a.w0c, a.border) && interior(j, a.h1c, a.w1c, a.border);
   // rank among the row's kept entries by ascending j (torch.where order, :109)
   const int kj = keep ? j : 0x7fffffff;
   int rank = 0, nkeep = 0;
@@ -152,7 +147,7 @@ __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
   const int total = sm[0] + sm[1] + sm[2] + sm[3];
   if (threadIdx.x == 0)
     __hip_atomic_store(&a.blocktot[blk], total | (int)0x40000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // exclusive prefix of the totals of the workgroups before this one (fixed order of integer adds)
+  // exclusive prefix of the totals of the blocks before this one (fixed order of integer adds)
   int pre = 0;
   for (int k = threadIdx.x; k < blk; k += 256) {
     int v;
@@ -181,13 +176,13 @@ __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
       // without the exact-screening pass an overflow of the sum kernels' candidate slots is final
       unsigned fl = a.scal->flags;
       if (!a.exact && (fl & (unsigned)FM_INT_SCREEN_OVERFLOW)) fl |= (unsigned)FM_DEV_CANDIDATES;
-      a.d_count[1] = (int)((fl & 7u) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
+      a.d_count[1] = (int)((fl & 15u & ~(unsigned)FM_DEV_CAPACITY) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
     }
   }
   __syncthreads();
-  if (b >= a.N || slot >= rowcnt[q]) continue;
+  if (b >= a.N || slot >= rowcnt[q]) return;
   const long o = (long)rowoff[q] + slot;
-  if (o >= a.cap) continue;
+  if (o >= a.cap) return;
   const int jj = s_kj[q * a.slots + slot];
   a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = jj;
   // cell -> match maps: with exact ties the largest match index keeps the cell, every other tied match
@@ -208,24 +203,27 @@ __global__ __launch_bounds__(256) void k_keep_emit(SelArgs a) {
   if (a.scale1) { s1x = a.scale_px * a.scale1[b * 2]; s1y = a.scale_px * a.scale1[b * 2 + 1]; }
   a.k0[o * 2] = (float)(i % a.w0c) * s0x; a.k0[o * 2 + 1] = (float)(i / a.w0c) * s0y;
   a.k1[o * 2] = (float)(jj % a.w1c) * s1x; a.k1[o * 2 + 1] = (float)(jj / a.w1c) * s1y;
-  }
 }
 
 hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
                          int h1c, int w1c, float inv_ct, float thr, int border, float scale_px,
                          const float* scale0, const float* scale1, int64_t* b_ids, int64_t* i_ids,
                          int64_t* j_ids, float* k0, float* k1, float* mconf, int cap, int32_t* d_count,
-                         int exact_screening, hipStream_t st) {
+                         int mode, hipStream_t st) {
   SelArgs a;
-  a.exact = exact_screening;
+  a.exact = (mode & FM_MODE_EXACT_SCREENING) ? 1 : 0;
   a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
   a.rowS = (const float*)(base + w.rowS); a.colS = (const float*)(base + w.colS);
   a.rowB = (const float*)(base + w.rowB); a.colB = (const float*)(base + w.colB);
   a.cand_count = (const int*)(base + w.cand_count); a.cand_j = (const int*)(base + w.cand_j);
-  a.cand_conf = (float*)(base + w.cand_conf); a.rowbest = (float*)(base + w.rowbest);
+  a.cand_x = (const float*)(base + w.cand_x);
+  a.ccand_count = (const int*)(base + w.ccand_count); a.ccand_i = (const int*)(base + w.ccand_i);
+  a.ccand_x = (const float*)(base + w.ccand_x);
   a.cand_count_b = (const int*)(base + w.cand_count_b); a.cand_j_b = (const int*)(base + w.cand_j_b);
-  a.cand_conf_b = (float*)(base + w.cand_conf_b); a.dense_cnt = (const int*)(base + w.dense_cnt);
-  a.colbest = (unsigned*)(base + w.colbest);
+  a.cand_x_b = (const float*)(base + w.cand_x_b);
+  a.ccand_count_b = (const int*)(base + w.ccand_count_b); a.ccand_i_b = (const int*)(base + w.ccand_i_b);
+  a.ccand_x_b = (const float*)(base + w.ccand_x_b);
+  a.dense_cnt = (const int*)(base + w.dense_cnt);
   a.blocktot = (int*)(base + w.blocktot);
   a.scal = (Scalars*)(base + w.scalars);
   a.N = w.N; a.L = w.L; a.S = w.S; a.C = w.C; a.Lp = w.Lp; a.Sp = w.Sp; a.splits = w.splits; a.splits_s = w.splits_s; a.panels = w.panels;
@@ -236,11 +234,8 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   a.cell0 = (int*)(base + w.cell0); a.cell1 = (int*)(base + w.cell1);
   a.ties0 = (int*)(base + w.ties0); a.ties1 = (int*)(base + w.ties1);
   const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
-  a.nblk = blocks; a.nsub = 1;
-  hipLaunchKernelGGL(k_cand_conf, dim3(blocks), dim3(256), 0, st, a);
   a.nblk = blocks;
-  a.nsub = 1;      // (4 blocks per ticket serialised the workgroups on each other's look-back: 41 ms at 64 pairs)
-  hipLaunchKernelGGL(k_keep_emit, dim3((blocks + a.nsub - 1) / a.nsub), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_select, dim3(blocks), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

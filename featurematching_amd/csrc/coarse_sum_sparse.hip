@@ -15,9 +15,9 @@
 //                  candidate list - the same number in numerator and denominator of conf, as in the reference.
 //   * significant, many per unit (flat similarity: untrained network, repetitive texture) : the unit's SAMPLE is
 //                  flagged for the dense sum kernel (k_corr<C,1>: float32-equivalent hi/lo product on the matrix
-//                  cores for all 1024 entries of every live unit), which runs next, redoes that sample and exits at
-//                  once when no sample is flagged.  A sample is handled by ONE of the two kernels: their float32
-//                  products agree to ~1e-7 but not bit for bit, and coarse_matching_new.py:105-106 keeps exactly
+//                  cores for all 1024 entries of every live unit), which redoes that sample when the call runs with
+//                  FM_MODE_DENSE; without it the call reports FM_E_DENSE and the caller repeats it with the flag.
+//                  A sample is handled by ONE of the two kernels: their float32 products agree to ~1e-7 but not bit for bit, and coarse_matching_new.py:105-106 keeps exactly
 //                  tied entries (conf == row max == column max), so identical descriptors must see one arithmetic.
 //
 // Structure: a workgroup = 8 INDEPENDENT waves = 8 row blocks (32 rows) x one range of <= 16 column units; no
@@ -42,17 +42,18 @@ constexpr int kSparseQueue = 64;      // candidates a wave parks in LDS (one per
 struct SparseArgs {
   const signed char* q0; const signed char* q1;       // int8 screening planes (k_prep_split)
   const void* src0; const void* src1; int c_in, in_dtype;   // the caller's descriptors [N,L,c_in] / [N,S,c_in]
-  const unsigned* rowmax_u; const unsigned* colmax_u;  // max pass: ord_encode'd maxima of the screening product
-  const float* sig0; const float* sig1;                // quantisation step per descriptor
-  const float* bsig0; const float* bsig1;              // ... largest per 32-row block
-  const float* l1_0; const float* l1_1; const float* bl1_0; const float* bl1_1;   // L1 norms, their block maxima
-  const float* umax;
+  const unsigned* rowmax_u; const unsigned* colmax_u;  // max pass: q_encode'd maxima of the integer screening product
+  const float* sigimg;                                 // [N][2] quantisation step of image 0 / image 1
+  const float* l1_0; const float* l1_1;                // L1 norms
+  const float4* bstat0; const float4* bstat1;          // per 32-row block: {largest L1 norm, largest clipped L1 mass, ..}
+  const float* umax;                                   // unit maxima of the integer screening product
   float* nmr; float* nmc; float* emarg;                // written here: stabilisers, pair margin
   float* rowS; float* colS;                            // partial sums [N][splits][Lp], [N][panels][Sp]
   int* dense_cnt; Scalars* scal;                       // [N] units per sample left to the dense kernel
   float* diag;                                         // diagnostic build: stamp buffer
-  int* cand_count; int* cand_j; float* cand_x;
-  int L, S, Lp, Sp, panels, splits, units_s, slots, pgroup;
+  int* cand_count; int* cand_j; float* cand_x;         // candidates per row: columns, exact dot products
+  int* ccand_count; int* ccand_i; float* ccand_x;      // the same candidates per column: rows, exact dot products
+  int L, S, Lp, Sp, panels, splits, units_s, slots, pgroup, dense_enabled;
   float k, lt, inv_ct, cpad;
 };
 
@@ -79,6 +80,14 @@ __device__ __forceinline__ float wave_reduce64(float v) {
   return v;
 }
 
+// Integer significance threshold: an entry with integer screening product q can matter for a row / column whose
+// -stabiliser*log2e is nm iff  kss q + emu + nm > -kSkipLog2  <=>  q > (-kSkipLog2 - emu - nm) / kss.
+// floor() - 1 absorbs the float roundings of the quotient (a lower threshold only lets more entries through).
+__device__ __forceinline__ int sig_threshold(float nm, float emu, float inv_kss) {
+  const float t = floorf((-kSkipLog2 - emu - nm) * inv_kss) - 1.f;
+  return (int)fminf(fmaxf(t, -1.0e9f), 1.0e9f);       // (NaN -> -1e9: everything significant)
+}
+
 template <int C>
 __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   constexpr int KS8 = C / 32;           // k-steps of v_mfma_i32_32x32x32_i8
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   const int panel = pg * a.pgroup + (kk - split * pcount);
   const int nunits = a.Sp / 32;
   const int u0 = split * a.units_s;
-  const int U = max(0, min(a.units_s, nunits - u0));          // units of this workgroup's range (<= 16)
+  const int U = max(0, min(a.units_s, nunits - u0));          // units of this workgroup's range (<= 64)
   const int rb = panel * 8 + wv;                              // this wave's row block
   const int wrow0 = rb * 32;
 #ifdef FM_DIAG_CLOCK       // diagnostic build only: shader-clock stamps per phase of every wave (tools/diag_sparse.py)
@@ -113,63 +122,53 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 #define DIAG_STAMP(i)
 #endif
 
-  __shared__ __attribute__((aligned(16))) float s_nmr[8][32];
-  __shared__ __attribute__((aligned(16))) float s_sgr[8][32];      // the quantisation steps of the 8 waves' rows
+  __shared__ __attribute__((aligned(16))) int s_tr[8][32];         // integer significance thresholds of the 8 waves' rows
   __shared__ float s_cmax[kUnitsPerSplit];
   __shared__ int s_hot[8];
-  // dynamic LDS, sized for the range: column stabilisers [U*32], column steps [U*32], then the 8 waves' column
+  // dynamic LDS, sized for the range: column stabilisers [U*32], column thresholds [U*32], then the 8 waves' column
   // accumulators [8][U*32]
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float* s_nmc = s_dyn;
-  float* s_sgc = s_dyn + a.units_s * 32;
+  int* s_tc = reinterpret_cast<int*>(s_dyn + a.units_s * 32);
   float* s_colacc = s_dyn + 2 * a.units_s * 32;
   const int cpitch = a.units_s * 32;
   __shared__ int s_list[8][LIST];              // (unit << 10) | (row in wave << 5) | column in unit
   __shared__ int s_qkey[8][kSparseQueue];
   __shared__ float s_qx[8][kSparseQueue];
 
-  // ---- everything the decisions below depend on is requested at once (one memory round trip): the block norm
-  // maxima, this wave's row statistics, the range's column statistics, the unit maxima and, speculatively, the
-  // wave's A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7; one contiguous 1 KiB block per k-step of the
-  // fragment-major plane of k_prep_split) ----
-  float sigA_max, l1A_max, sigB_max, l1B_max;     // image maxima of the block scales / L1 norms (every wave folds them itself)
-  {
-    // eight predicated loads per lane in flight (a plain strided loop waits for every load before the next)
-    auto lane_max = [&](const float* p, int n) {
-      float m = 0.f;
-      for (int base = 0; base < n; base += 512) {
-        float v[8];
+  // ---- everything the decisions below depend on is requested at once (ONE memory round trip: every load below is
+  // issued before the first use of any of them; indices are clamped instead of predicated so that no load sits behind
+  // a branch): the images' steps, the block statistics, this wave's row statistics, the range's column statistics,
+  // the unit maxima and the wave's A fragments (lane (r,h): row r, k = h*C/2 + 8*ks + 0..7; one contiguous 1 KiB
+  // block per k-step of the fragment-major plane of k_prep_split) ----
+  constexpr int CSETS = kUnitsPerSplit * 32 / 512;      // column sets per thread: the range has <= 2048 columns
+  const float sig0 = a.sigimg[b * 2], sig1 = a.sigimg[b * 2 + 1];
+  const int nb0 = a.Lp / 32;
+  const float4* bs0 = a.bstat0 + (long)b * nb0;
+  const float4* bs1 = a.bstat1 + (long)b * nunits;
+  float4 st0[8], st1[8];           // lane: blocks lane + 64 q (a repeated block does not change a maximum)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const int i = base + q * 64 + lane; v[q] = i < n ? p[i] : 0.f; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) m = fmaxf(m, v[q]);
-      }
-      return m;
-    };
-    sigA_max = lane_max(a.bsig0 + (long)b * (a.Lp / 32), a.Lp / 32);
-    l1A_max = lane_max(a.bl1_0 + (long)b * (a.Lp / 32), a.Lp / 32);
-    sigB_max = lane_max(a.bsig1 + (long)b * nunits, nunits);
-    l1B_max = lane_max(a.bl1_1 + (long)b * nunits, nunits);
+  for (int q = 0; q < 8; ++q) {
+    st0[q] = bs0[min(q * 64 + lane, nb0 - 1)];
+    st1[q] = bs1[min(q * 64 + lane, nunits - 1)];
   }
   const long gi = (long)b * a.Lp + wrow0 + r;
   const unsigned rmax_u = a.rowmax_u[gi];
   const float rl1 = a.l1_0[gi];
-  const float rsig = a.sig0[gi];
-  const float sA = a.bsig0[(long)b * (a.Lp / 32) + rb];          // largest step of this wave's rows
-  const float bl1A = a.bl1_0[(long)b * (a.Lp / 32) + rb];
-  // (the first 512 columns of the range here; a longer range - large batches only - fetches the rest below)
-  unsigned cmax_u = 0u;
-  float cl1 = 0.f, csig = 0.f;
-  if (tid < U * 32) {
-    cmax_u = a.colmax_u[(long)b * a.Sp + u0 * 32 + tid]; cl1 = a.l1_1[(long)b * a.Sp + u0 * 32 + tid];
-    csig = a.sig1[(long)b * a.Sp + u0 * 32 + tid];
+  const float bl1A = bs0[rb].x;                                   // largest L1 norm of this wave's rows
+  unsigned cmax_u[CSETS];
+  float cl1[CSETS], cbl1[CSETS];
+#pragma unroll
+  for (int k = 0; k < CSETS; ++k) {
+    const int c = min(tid + 512 * k, max(U * 32 - 1, 0));
+    cmax_u[k] = a.colmax_u[(long)b * a.Sp + u0 * 32 + c];
+    cl1[k] = a.l1_1[(long)b * a.Sp + u0 * 32 + c];
+    cbl1[k] = bs1[min(u0 + (c >> 5), nunits - 1)].x;              // largest L1 norm of the column's unit
   }
-  float um = -INFINITY, sB_lane = 0.f, bl1B_lane = 0.f;     // lane u: unit u0 + u of this wave's row block
-  if (lane < U) {
-    um = a.umax[((long)b * (a.Lp / 32) + rb) * nunits + u0 + lane];
-    sB_lane = a.bsig1[(long)b * nunits + u0 + lane];               // largest step of the unit's columns
-    bl1B_lane = a.bl1_1[(long)b * nunits + u0 + lane];
-  }
+  // lane u: unit u0 + u of this wave's row block
+  const int ul_c = min(lane, max(U - 1, 0));
+  float um = a.umax[((long)b * (a.Lp / 32) + rb) * nunits + min(u0 + ul_c, nunits - 1)];
+  const float bl1B_lane = bs1[min(u0 + ul_c, nunits - 1)].x;      // largest L1 norm of the unit's columns
   v4i aq[KS8];
   {
     const signed char* src = a.q0 + (((long)b * a.Lp + wrow0) / 32 * KS8 * 64 + lane) * 16;
@@ -178,36 +177,55 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   }
   for (int c = lane; c < U * 32; c += 64) s_colacc[wv * cpitch + c] = 0.f;
 
-  sigA_max = wave_reduce64<false>(sigA_max);
+  float l1A_max = 0.f, l1B_max = 0.f, clipA = 0.f, clipB = 0.f;     // image maxima (every wave folds them itself)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    l1A_max = fmaxf(l1A_max, st0[q].x); clipA = fmaxf(clipA, st0[q].y);
+    l1B_max = fmaxf(l1B_max, st1[q].x); clipB = fmaxf(clipB, st1[q].y);
+  }
+  for (int i = 512 + lane; i < nb0; i += 64) { const float4 v = bs0[i]; l1A_max = fmaxf(l1A_max, v.x); clipA = fmaxf(clipA, v.y); }
+  for (int i = 512 + lane; i < nunits; i += 64) { const float4 v = bs1[i]; l1B_max = fmaxf(l1B_max, v.x); clipB = fmaxf(clipB, v.y); }
   l1A_max = wave_reduce64<false>(l1A_max);
-  sigB_max = wave_reduce64<false>(sigB_max);
+  clipA = wave_reduce64<false>(clipA);
   l1B_max = wave_reduce64<false>(l1B_max);
+  clipB = wave_reduce64<false>(clipB);
+  if (lane >= U) um = -INFINITY;
+  const float ss = sig0 * sig1;                    // integer screening product -> raw dot-product units
+  const float kss = a.k * ss;                      // ... -> log2-domain similarity
+  const bool screen_ok = kss > 1e-30f && kss < 1e30f;   // (an all-zero sample image: nothing to screen with)
+  const float inv_kss = screen_ok ? 1.0f / kss : 0.f;
   DIAG_STAMP(1)
   if (panel == 0 && split == 0 && tid == 0) {
-    const float emarg = margin_log2(q8_margin_raw(sigA_max, l1A_max, sigB_max, l1B_max, a.cpad), a.inv_ct);
+    const float emarg = margin_log2(q8_margin_raw(sig0, l1A_max, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
     a.emarg[b] = emarg;
     // a prep workgroup that met NaN/Inf/|x| >= 32768 reported +inf; descriptors so large that the screening margin
     // alone could overflow exp2 (similarities of several thousand) are out of range as well
     if (!(l1A_max < INFINITY) || !(l1B_max < INFINITY) || !(emarg < 60.f)) atomicOr(&a.scal->flags, (unsigned)FM_DEV_RANGE);
   }
 
-  // ---- stabilisers: this wave's 32 rows, the workgroup's column range ----
+  // ---- stabilisers and integer thresholds: this wave's 32 rows, the workgroup's column range ----
   // lanes 0..31 (and their mirror 32..63): -stabiliser*log2e of row wrow0 + r
-  const float nm_lane = neg_stabiliser_log2(ord_decode(rmax_u), q8_margin_raw(rsig, rl1, sigB_max, l1B_max, a.cpad), a.inv_ct);
+  const float nm_lane = neg_stabiliser_log2(ss * q_decode(rmax_u),
+                                            q8_margin_raw(sig0, rl1, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
+  // margin of any entry of this row block (its largest L1 norm against the other image's largest)
+  const float emu_rows = margin_log2(q8_margin_raw(sig0, bl1A, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
   if (h == 0) {
-    s_nmr[wv][r] = nm_lane;
-    s_sgr[wv][r] = rsig;
+    s_tr[wv][r] = sig_threshold(nm_lane, emu_rows, inv_kss);
     if (split == 0) a.nmr[gi] = nm_lane;
   }
   // padded rows (>= L) never contribute: keep them out of the wave's largest stabiliser
   const float wmax_nmr = wave_reduce64<false>(wrow0 + r < a.L ? nm_lane : -INFINITY);
-  for (int c = tid; c < U * 32; c += 512) {
-    const long gj = (long)b * a.Sp + u0 * 32 + c;
-    if (c >= 512) { cmax_u = a.colmax_u[gj]; cl1 = a.l1_1[gj]; csig = a.sig1[gj]; }
-    const float nm = neg_stabiliser_log2(ord_decode(cmax_u), q8_margin_raw(csig, cl1, sigA_max, l1A_max, a.cpad), a.inv_ct);
-    s_nmc[c] = nm;
-    s_sgc[c] = csig;
-    if (panel == 0) a.nmc[gj] = nm;
+#pragma unroll
+  for (int k = 0; k < CSETS; ++k) {
+    const int c = tid + 512 * k;
+    if (c < U * 32) {
+      const long gj = (long)b * a.Sp + u0 * 32 + c;
+      const float nm = neg_stabiliser_log2(ss * q_decode(cmax_u[k]),
+                                           q8_margin_raw(sig0, l1A_max, clipA, sig1, cl1[k], clipB, a.cpad), a.inv_ct);
+      s_nmc[c] = nm;
+      s_tc[c] = sig_threshold(nm, margin_log2(q8_margin_raw(sig0, l1A_max, clipA, sig1, cbl1[k], clipB, a.cpad), a.inv_ct), inv_kss);
+      if (panel == 0) a.nmc[gj] = nm;
+    }
   }
   __syncthreads();
   for (int u = wv; u < U; u += 8) {
@@ -218,11 +236,11 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 
   // ---- which of this wave's units are alive (same bound as the dense kernel's block-sparse skip) ----
   // lane u: log2-domain bound of k * |screening product - exact product| over unit u of this wave's row block
-  const float emu_lane = margin_log2(q8_margin_raw(sA, bl1A, sB_lane, bl1B_lane, a.cpad), a.inv_ct);
+  const float emu_lane = margin_log2(q8_margin_raw(sig0, bl1A, clipA, sig1, bl1B_lane, clipB, a.cpad), a.inv_ct);
   bool hot = false;
   if (lane < U && wrow0 < a.L) {
-    const float top = __builtin_fmaf(um, a.k, emu_lane);          // >= k * (exact product), log2 domain
-    hot = !((top + wmax_nmr < -kSkipLog2) && (top + s_cmax[lane] < -kSkipLog2));
+    const float top = __builtin_fmaf(um, kss, emu_lane);          // >= k * (exact product), log2 domain
+    hot = !screen_ok || !((top + wmax_nmr < -kSkipLog2) && (top + s_cmax[lane] < -kSkipLog2));
   }
   unsigned long long mask = __ballot(hot);          // wave-uniform
   if (lane == 0) s_hot[wv] = __builtin_popcountll(mask);
@@ -231,7 +249,9 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 #pragma unroll
   for (int w8 = 0; w8 < 8; ++w8) tot += s_hot[w8];
   unsigned long long dmask = 0;  // units left to the dense kernel
-  if (tot * 2 > 8 * U) {         // more than half of the block is alive: flat similarity, a matrix-core job
+  // more than half of a block of >= 64 units is alive: flat similarity, a matrix-core job (a small block - a tiny
+  // image, a one-unit split - is cheap to sweep whatever is alive, and truly flat units still overflow kMaxExact below)
+  if ((tot * 2 > 8 * U && 8 * U >= 64) || !screen_ok) {
     dmask = mask;
     mask = 0;
   }
@@ -244,9 +264,17 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 #endif
   if (mask) {
     const bool row_edge = (wrow0 + 32 > a.L);
+    // this lane's 16 row thresholds (rows 8q + 4h + 0..3 of the wave's 32): loop invariant, four 16-byte LDS reads
+    int trr[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 t4 = *reinterpret_cast<const int4*>(&s_tr[wv][8 * q + 4 * h]);
+      trr[4 * q] = t4.x; trr[4 * q + 1] = t4.y; trr[4 * q + 2] = t4.z; trr[4 * q + 3] = t4.w;
+    }
 
-    // B fragments of two units: while one feeds the MFMA chain the next one's 8 KiB are already in flight
-    v4i bq0[KS8], bq1[KS8];
+    // B fragments of three units: while one feeds the MFMA chain the next two units' 16 KiB are in flight (a unit's
+    // 8 KiB come from L2 or beyond: with one unit of read-ahead every unit waited for its fragments)
+    v4i bq0[KS8], bq1[KS8], bq2[KS8];
     auto load_b = [&](v4i (&bq)[KS8], int ul) {
       const signed char* src = a.q1 + (((long)b * nunits + u0 + ul) * KS8 * 64 + lane) * 16;
 #pragma unroll
@@ -259,65 +287,63 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
       for (int g = 0; g < 16; ++g) acc[g] = 0;
 #pragma unroll
       for (int ks = 0; ks < KS8; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks], acc, 0, 0, 0);
-      // this unit's margin (lane ul holds it)
-      const float emu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emu_lane), ul));
-      const float ksj = a.k * s_sgc[ul * 32 + r];      // this lane's column: integer dot * sigma_i * ksj = k x~
-      const float sig_thr = -kSkipLog2 - emu;          // the margin turns k x~ into an upper bound of k x
-      float xf[16];
-#pragma unroll
-      for (int g = 0; g < 16; ++g) xf[g] = (float)acc[g] * ksj;
       if (row_edge || ucol0 + 32 > a.S) {              // padded rows (>= L) / columns (>= S) never count
         const bool cok = ucol0 + r < a.S;
 #pragma unroll
         for (int g = 0; g < 16; ++g)
-          if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) xf[g] = -INFINITY;
+          if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) acc[g] = kQMasked;
       }
-      // significance: k x~ + margin within 2^32 of the row's or the column's stabiliser.  One compare per
-      // accumulator register writes the wave's mask straight to scalar registers; the (rare) significant
-      // entries are parked at once, in (register, lane) order, and taken back if the unit turns out to have
-      // too many of them (flat similarity: the dense kernel's job).
-      const float nmc_l = s_nmc[ul * 32 + r];
+      // significance: the integer product beats the row's or the column's threshold (k x~ + margin within 2^32 of
+      // that stabiliser).  Two integer instructions per accumulator register write the wave's mask straight to
+      // scalar registers; the (rare) significant entries are parked at once, in (register, lane) order, and taken
+      // back if the unit turns out to have too many of them (flat similarity: the dense kernel's job).
+      const int tcl = s_tc[ul * 32 + r];
       const int nlist0 = nlist;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {      // this lane's rows 8q + 4h + 0..3 of the wave's 32: one 16-byte LDS read
-        const float4 nm4 = *reinterpret_cast<const float4*>(&s_nmr[wv][8 * q + 4 * h]);
-        const float4 sg4 = *reinterpret_cast<const float4*>(&s_sgr[wv][8 * q + 4 * h]);
-        const float nm[4] = {nm4.x, nm4.y, nm4.z, nm4.w};
-        const float sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float tr = __builtin_fmaf(xf[4 * q + e], sg[e], nm[e]);
-          const float tc = __builtin_fmaf(xf[4 * q + e], sg[e], nmc_l);
-          unsigned long long m = __ballot(fmaxf(tr, tc) > sig_thr);
-          while (m) {                    // wave-uniform, usually not entered
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const int rl = e + 8 * q + 4 * (l >> 5);
-            if (lane == 0 && nlist < LIST) s_list[wv][nlist] = (ul << 10) | (rl << 5) | (l & 31);
-            ++nlist;
-          }
+      for (int g = 0; g < 16; ++g) {
+        unsigned long long m = __ballot(acc[g] > min(trr[g], tcl));
+        while (m) {                    // wave-uniform, usually not entered
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const int rl = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+          if (lane == 0 && nlist < LIST) s_list[wv][nlist] = (ul << 10) | (rl << 5) | (l & 31);
+          ++nlist;
         }
       }
       if (nlist - nlist0 > kMaxExact || nlist > LIST) { nlist = nlist0; dmask |= 1ull << ul; }
     };
-    load_b(bq0, __builtin_ctzll(mask));
+    // the unit after next (or `cur` again when there is none: the prefetch is UNCONDITIONAL - behind a branch hipcc has
+    // to assume the shorter path at the join and waits vmcnt(0) in front of the MFMA chain, i.e. for the prefetch it
+    // has just issued; measured 2.5k cycles per unit instead of ~1k)
+    auto after_next = [](unsigned long long m, int cur) {
+      const unsigned long long m2 = m & (m - 1);
+      return m2 ? __builtin_ctzll(m2) : (m ? __builtin_ctzll(m) : cur);
+    };
+    {
+      const int first = __builtin_ctzll(mask);
+      load_b(bq0, first);
+      const unsigned long long m1 = mask & (mask - 1);
+      load_b(bq1, m1 ? __builtin_ctzll(m1) : first);
+    }
 #ifdef FM_DIAG_CLOCK
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DIAG_STAMP(3)
 #endif
-    // The prefetch is UNCONDITIONAL (with no unit left it re-reads the current one): behind a branch hipcc has to
-    // assume the shorter path at the join and waits vmcnt(0) in front of the MFMA chain - i.e. for the prefetch it
-    // has just issued (measured: 2.5k cycles per unit instead of ~1k).
     while (mask) {
       const int ua = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      load_b(bq1, mask ? __builtin_ctzll(mask) : ua);
+      mask &= mask - 1;                              // bq1 holds ctz(mask) now
+      load_b(bq2, after_next(mask, ua));
       unit(bq0, ua);
       if (!mask) break;
       const int ub = __builtin_ctzll(mask);
       mask &= mask - 1;
-      load_b(bq0, mask ? __builtin_ctzll(mask) : ub);
+      load_b(bq0, after_next(mask, ub));
       unit(bq1, ub);
+      if (!mask) break;
+      const int uc = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      load_b(bq1, after_next(mask, uc));
+      unit(bq2, uc);
     }
   }
 
@@ -326,6 +352,16 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   float racc = 0.f;              // lanes 0..31: sum_j exp2(k x - m^) of row wrow0 + lane over this range
   int qn = 0;                    // parked candidates (wave-uniform)
   DIAG_STAMP(4)
+  // a candidate goes to its row's AND its column's slot list (k_select takes the row best from the one, the column
+  // best from the other, without a grid-wide pass in between)
+  auto record = [&](int rl, int col, float x) {
+    const long grow = (long)b * a.Lp + wrow0 + rl, gcol = (long)b * a.Sp + col;
+    const int pos = atomicAdd(&a.cand_count[grow], 1);
+    const int cpos = atomicAdd(&a.ccand_count[gcol], 1);
+    if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = col; a.cand_x[grow * a.slots + pos] = x; }
+    if (cpos < a.slots) { a.ccand_i[gcol * a.slots + cpos] = wrow0 + rl; a.ccand_x[gcol * a.slots + cpos] = x; }
+    if (pos >= a.slots || cpos >= a.slots) atomicOr(&a.scal->flags, (unsigned)FM_INT_SCREEN_OVERFLOW);
+  };
   constexpr int EB = 8;          // entries per batch: 16 row loads per lane in flight
   for (int e0 = 0; e0 < nlist; e0 += EB) {
     int key[EB];
@@ -370,11 +406,8 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
         const int col = (u0 + ul) * 32 + cl;
         if (qn < kSparseQueue) {
           if (lane == 0) { s_qkey[wv][qn] = (col << 5) | rl; s_qx[wv][qn] = x[q]; }
-        } else if (lane == 0) {                         // queue full: straight to the row's slot list
-          const long grow = (long)b * a.Lp + wrow0 + rl;
-          const int pos = atomicAdd(&a.cand_count[grow], 1);
-          if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = col; a.cand_x[grow * a.slots + pos] = x[q]; }
-          else atomicOr(&a.scal->flags, (unsigned)FM_INT_SCREEN_OVERFLOW);
+        } else if (lane == 0) {                         // queue full: straight to the slot lists
+          record(rl, col, x[q]);
         }
         ++qn;
       }
@@ -388,10 +421,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     const int nq = min(qn, kSparseQueue);
     if (lane < nq) {
       const int key = s_qkey[wv][lane];
-      const long grow = (long)b * a.Lp + wrow0 + (key & 31);
-      const int pos = atomicAdd(&a.cand_count[grow], 1);
-      if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = key >> 5; a.cand_x[grow * a.slots + pos] = s_qx[wv][lane]; }
-      else atomicOr(&a.scal->flags, (unsigned)FM_INT_SCREEN_OVERFLOW);
+      record(key & 31, key >> 5, s_qx[wv][lane]);
     }
   }
   // ---- the workgroup's dense-unit count (one atomic per workgroup) and its column partial: the 8 waves'
@@ -402,7 +432,11 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     int nd = 0;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) nd += s_hot[w8];
-    if (nd) { atomicAdd(&a.dense_cnt[b], nd); atomicAdd(&a.scal->dense_units, nd); }
+    if (nd) {
+      atomicAdd(&a.dense_cnt[b], nd);
+      atomicAdd(&a.scal->dense_units, nd);
+      if (!a.dense_enabled) atomicOr(&a.scal->flags, (unsigned)FM_DEV_DENSE);   // nobody will redo this sample
+    }
   }
   float* co = a.colS + ((long)b * a.panels + panel) * a.Sp + u0 * 32;
   for (int c = tid; c < U * 32; c += 512) {
@@ -425,24 +459,24 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 }
 
 hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                             float inv_ct, float thr, hipStream_t st) {
+                             float inv_ct, float thr, int dense_enabled, hipStream_t st) {
   SparseArgs a;
   a.in_dtype = in_dtype;
   a.q0 = (const signed char*)(base + w.q0); a.q1 = (const signed char*)(base + w.q1);
   a.src0 = feat0; a.src1 = feat1; a.c_in = c_in;
   a.rowmax_u = (const unsigned*)(base + w.rowmax_u); a.colmax_u = (const unsigned*)(base + w.colmax_u);
-  a.sig0 = (const float*)(base + w.sig0); a.sig1 = (const float*)(base + w.sig1);
-  a.bsig0 = (const float*)(base + w.bsig0); a.bsig1 = (const float*)(base + w.bsig1);
+  a.sigimg = (const float*)(base + w.sigimg);
   a.l1_0 = (const float*)(base + w.l1_0); a.l1_1 = (const float*)(base + w.l1_1);
-  a.bl1_0 = (const float*)(base + w.bl1_0); a.bl1_1 = (const float*)(base + w.bl1_1);
+  a.bstat0 = (const float4*)(base + w.bstat0); a.bstat1 = (const float4*)(base + w.bstat1);
   a.umax = (const float*)(base + w.umax);
   a.nmr = (float*)(base + w.nmr); a.nmc = (float*)(base + w.nmc); a.emarg = (float*)(base + w.emarg);
   a.rowS = (float*)(base + w.rowS); a.colS = (float*)(base + w.colS);
   a.dense_cnt = (int*)(base + w.dense_cnt); a.scal = (Scalars*)(base + w.scalars);
-  a.diag = (float*)(base + w.rowB);
-  a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j); a.cand_x = (float*)(base + w.cand_conf);
+  a.diag = (float*)(base + w.rowB);      // (diagnostic builds run on a full-size workspace)
+  a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j); a.cand_x = (float*)(base + w.cand_x);
+  a.ccand_count = (int*)(base + w.ccand_count); a.ccand_i = (int*)(base + w.ccand_i); a.ccand_x = (float*)(base + w.ccand_x);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.splits = w.splits_s; a.units_s = w.units_s;
-  a.slots = w.slots;
+  a.slots = w.slots; a.dense_enabled = dense_enabled;
   {
     const int blocks_all = w.N * a.splits * w.panels;
     const float share = fmaxf(1.f, (float)blocks_all / 8.f);

@@ -26,17 +26,31 @@ __device__ __forceinline__ float4 half4_to_float4(uint2 p, int dtype) {
                      half_bits_to_float(p.y & 0xffffu, dtype), half_bits_to_float(p.y >> 16, dtype));
 }
 
-// Error of the int8 screening product against the exact one (raw dot-product units).  With a = sigma_a q_a + da,
-// |da_k| <= sigma_a / 2 (k_prep_split: q = rint(a / sigma), sigma = block max / 127) and likewise for b:
-//   a.b - sigma_a sigma_b (q_a.q_b) = da.b + (a - da).db
-//   |...| <= (sigma_a / 2) ||b||_1 + (sigma_b / 2) (||a||_1 + C sigma_a / 2).
-// The factor 1.0001 covers the float roundings of x / sigma, of sigma_a sigma_b and of the scaled accumulator
-// (each ~1e-7 relative against terms of the same form).  Pass block / image maxima of sigma and of the L1 norms to
-// bound a whole row, unit or pair.
-__device__ __forceinline__ float q8_margin_raw(float sig_a, float l1_a, float sig_b, float l1_b, float cpad) {
+// Error of the int8 screening product against the exact one (raw dot-product units).  k_prep_split quantises each
+// IMAGE with ONE step: q = clamp(rint(a / sigma), -127, 127).  With a = sigma q + da, |da_k| <= sigma / 2 + e_k where
+// e_k = max(|a_k| - 127 sigma, 0) is what the clamp cut off (zero unless the step, estimated from a sample of the
+// image's rows, turned out too small for an outlier), and likewise for b:
+//   a.b - sigma_a sigma_b (q_a.q_b) = da.b + (sigma_a q_a).db
+//   |da.b|            <= (sigma_a / 2) ||b||_1 + ||e_a||_1 max|b_k|,   max|b_k| <= 127 sigma_b + ||e_b||_1
+//   |(sigma_a q_a).db| <= (sigma_b / 2) (||a||_1 + C sigma_a / 2) + 127 sigma_a ||e_b||_1
+// clip_a / clip_b = upper bounds of ||e_a||_1 / ||e_b||_1 (the images' largest: a clipped element widens every margin
+// of its image, which keeps the margin separable into a row and a column part).  The factor 1.0001 covers the float
+// roundings of x / sigma, of sigma_a sigma_b and of the scaled accumulator (each ~1e-7 relative against terms of the
+// same form).  Pass block / image maxima of the L1 norms to bound a whole row, unit or pair.
+__device__ __forceinline__ float q8_margin_raw(float sig_a, float l1_a, float clip_a, float sig_b, float l1_b, float clip_b,
+                                               float cpad) {
 #pragma clang fp contract(off)
-  return (0.5f * sig_a * l1_b + 0.5f * sig_b * (l1_a + 0.5f * cpad * sig_a)) * 1.0001f;
+  const float clip = clip_a * (127.f * sig_b + clip_b) + 127.f * sig_a * clip_b;
+  return (0.5f * sig_a * l1_b + 0.5f * sig_b * (l1_a + 0.5f * cpad * sig_a) + clip) * 1.0001f;
 }
+
+// Row / column / unit maxima of the integer screening product q_a.q_b travel as biased unsigned codes: larger
+// product <=> larger code, every code of a real product is > 0 (|q.q| <= 127^2 * 256 < 2^23), so zero-initialised
+// memory is "nothing recorded yet" under atomicMax - exact and order independent.
+constexpr int kQBias = 0x40000000;
+constexpr int kQMasked = -kQBias;          // accumulator value of padded rows / columns: code 0
+__device__ __forceinline__ unsigned q_encode(int q) { return (unsigned)(q + kQBias); }
+__device__ __forceinline__ float q_decode(unsigned c) { return (float)((int)c - kQBias); }   // c == 0 -> -2^30 (never the maximum of a real row)
 
 // -stabiliser * log2(e) of a row / column whose largest screening product is `raw`, E = its margin in raw units
 // (network/utils/coarse_matching_new.py:64-68: sim = raw / (C T)).  The stabiliser is the LOWER bound

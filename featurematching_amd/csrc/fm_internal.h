@@ -17,7 +17,10 @@ constexpr int kUnitsPerSplit = 64; // 32-column units one workgroup of the spars
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kSkipLog2 = 32.f;    // terms more than 2^32 below every stabiliser are negligible (see coarse_sum_sparse.hip)
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
-constexpr unsigned FM_INT_SCREEN_OVERFLOW = 8u;
+constexpr unsigned FM_INT_SCREEN_OVERFLOW = 16u;
+constexpr int kPrepSampleRows = 32;  // rows of an image every k_prep_split workgroup samples for the image's int8 step
+constexpr float kPrepHeadroom = 1.5f; // step = headroom * (largest |x| of the sample) / 127: what lies beyond is clipped
+                                      // and accounted for in the screening margins (fm_device.h)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // descriptor channels the kernels are instantiated for; smaller C is zero-padded by k_prep_split
@@ -25,40 +28,48 @@ inline int padded_channels(int c) { return c <= 64 ? 64 : (c <= 128 ? 128 : 256)
 inline bool valid_channels(int c) { return c >= 4 && c <= 256 && c % 4 == 0; }
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-// Device workspace of the coarse stage; all offsets in bytes from the base.
+// Device workspace of the coarse stage; all offsets in bytes from the base.  The regions the common path uses come
+// first (`common_total` bytes); the float16 planes, the dense sum kernel's partials and candidate set and the
+// softmax denominators of every row / column follow and are needed only with FM_MODE_DENSE / FM_MODE_EXACT_SCREENING /
+// a conf_matrix request.
 struct CoarseWs {
   int N, L, S, C, Lp, Sp, panels, tiles, splits, slots;
   int splits0;                                // column splits of the max pass (its own grid size)
   int splits_s, units_s;                      // sparse sum kernel: column splits and 32-column units per split
   // zeroed on every call (contiguous, starts at the base)
-  size_t zero_begin, cand_count, cand_count_b, colbest, dense_cnt, scalars, zero_end;
-                                              // cand_count / cand_count_b: candidates per row found by the sparse /
-                                              // the dense sum kernel; dense_cnt [N]: units of a sample the sparse
-                                              // kernel left to the dense one (> 0: the dense kernel redoes the sample)
+  size_t zero_begin, cand_count, ccand_count, cand_count_b, ccand_count_b, dense_cnt, scalars, zero_end;
+                                              // cand_count / ccand_count: candidates per row / per column found by the
+                                              // sparse sum kernel (the same entries, listed from both sides); *_b: by
+                                              // the dense one; dense_cnt [N]: units of a sample the sparse kernel left
+                                              // to the dense one (> 0: the dense kernel redoes the sample)
   size_t cell0, cell1;                        // (zeroed) match index + 1 of every image-0 / image-1 cell
   size_t ties0, ties1;                        // (zeroed) [0] = count, [1..kTieCap] = matches that lost their cell to an
                                               // exactly tied match (the cell-ordered gathers pick them up)
-  size_t rowmax_u, colmax_u;                  // (zeroed) order-preserving uint code of the row / column maxima of the
-                                              // f16 product (max pass: atomicMax, exact and order independent)
-  size_t blocktot;                            // (zeroed) k_keep_emit: matches per workgroup | published flag
-  // float16 planes
-  size_t hi0, lo0, hi1, lo1;
+  size_t rowmax_u, colmax_u;                  // (zeroed) q_encode'd row / column maxima of the integer screening
+                                              // product (max pass: atomicMax, exact and order independent)
+  size_t blocktot;                            // (zeroed) k_select: matches per workgroup | published flag
   // per-row / per-column statistics
   size_t q0, q1;                              // int8 screening planes
-  size_t sig0, sig1, bsig0, bsig1;            // quantisation step per descriptor, largest step per 32-row block
-  size_t l1_0, l1_1, bl1_0, bl1_1;            // L1 norm per descriptor, largest L1 norm per 32-row block
+  size_t sigimg;                              // [N][2] the int8 step of image 0 / image 1 of every sample
+  size_t l1_0, l1_1;                          // L1 norm per descriptor
+  size_t bstat0, bstat1;                      // float4 per 32-row block: {largest L1 norm (+inf: a bad value), largest
+                                              // clipped L1 mass sum_k max(|x_k| - 127 sigma, 0), largest |x|, 0}
   size_t emarg;                               // [N] log2-domain bound of k * |screening product - exact product|
-  size_t f16inv;                              // [N] 1 / (power-of-two scales of the two images' float16 planes)
   size_t rowS, colS;                          // partial sum-exp of the sparse sum kernel: rows [N][splits_s][Lp],
                                               // columns [N][panels][Sp]
+  size_t nmr, nmc;                            // -stabiliser*log2e per row / column
+  size_t umax;                                // unit maxima [N][Lp/32][Sp/32] of the integer screening product (as float)
+  size_t cand_j, cand_x;                      // candidate columns and exact dot products per row (sparse kernel's set)
+  size_t ccand_i, ccand_x;                    // the same candidates listed per column: rows, dot products
+  size_t common_total;
+  // ---- dense / exact-screening / conf_matrix only ----
+  size_t hi0, lo0, hi1, lo1;                  // float16 planes
+  size_t f16inv;                              // [N] 1 / (power-of-two scales of the two images' float16 planes)
   size_t rowB, colB;                          // partial sum-exp of the dense sum kernel: rows [N][splits][Lp],
                                               // columns [N][panels][Sp] (one partial per workgroup)
-  size_t nmr, nmc;                            // -stabiliser*log2e per row / column
   size_t rsum, csum;                          // softmax denominators per row / column
   size_t nmr2, nmc2;                          // nmr - log2(rsum), nmc - log2(csum): log-softmax offsets
-  size_t umax;                                // unit maxima [N][Lp/32][Sp/32] of the max pass
-  size_t cand_j, cand_conf, rowbest;          // candidate columns, exact conf, best conf per row (sparse kernel's set)
-  size_t cand_j_b, cand_conf_b;               // ... the dense kernel's set (used for the samples it redid)
+  size_t cand_j_b, cand_x_b, ccand_i_b, ccand_x_b;   // ... the dense kernel's candidate set (samples it redid)
   size_t total;
 };
 
@@ -69,7 +80,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots);
 struct Scalars {          // lives at ws.scalars (zeroed per call)
   unsigned flags;         // FM_DEV_* bits
   int dense_units;        // 32x32 units the sparse sum kernel left to the dense one (0: that kernel exits at once)
-  int ticket;             // k_keep_emit: next logical workgroup index
+  int ticket;             // k_select: next logical workgroup index
 };
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
@@ -84,9 +95,9 @@ hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, 
 hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,
                          float scale_px, const float* scale0, const float* scale1,
                          int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* k0, float* k1,
-                         float* mconf, int cap, int32_t* d_count, int exact_screening, hipStream_t st);
+                         float* mconf, int cap, int32_t* d_count, int mode, hipStream_t st);
 hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                             float inv_ct, float thr, hipStream_t st);
+                             float inv_ct, float thr, int dense_enabled, hipStream_t st);
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, device) instead of on every launch: the
 // attribute call costs tens of host microseconds, which an eager (non-graph) caller would pay per step.

@@ -91,13 +91,15 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        thr: float = 0.2, border_rm: int = 2, temperature: float = 0.1,
                        scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
-                       conf_matrix: bool = False, exact_screening: bool = False) -> CoarseBuffers:
+                       conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
-    the up-cast tensors).  exact_screening adds the two kernels that
-    re-screen the candidates with exact softmax denominators (needed for nearly flat similarity rows;
-    without it such rows report FM_E_CANDIDATES through read_count)."""
+    the up-cast tensors).  The common path is four launches (prep, int8 max pass, sparse sum kernel, assignment);
+    `dense` (FM_MODE_DENSE) adds the float16 planes and the dense sum kernel for samples with flat similarity (without
+    it such samples report FM_E_DENSE through read_count), `exact_screening` (FM_MODE_EXACT_SCREENING) the two kernels
+    that re-screen the candidates with exact softmax denominators (without it rows / columns that overflow their
+    candidate slots report FM_E_CANDIDATES)."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -112,8 +114,10 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
         cap = n * min(l, s)
     if cand_slots is None:
         cand_slots = lib.fm_default_cand_slots(float(thr))
+    mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0)
     nbytes = C.c_size_t(0)
-    _lib.check(lib.fm_coarse_workspace_bytes(n, l, s, c, cand_slots, C.byref(nbytes)), "fm_coarse_workspace_bytes")
+    _lib.check(lib.fm_coarse_workspace_bytes_mode(n, l, s, c, cand_slots, mode, int(bool(conf_matrix)), C.byref(nbytes)),
+               "fm_coarse_workspace_bytes_mode")
     ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
     ws_ptr = C.c_void_p(ws.data_ptr() + off)
@@ -128,7 +132,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
     st = lib.fm_coarse_match_dtype(_ptr(f0), _ptr(f1), _DTYPES[f0.dtype], n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
                              int(hw1_c[1]), float(temperature), float(thr), int(border_rm), float(scale_px),
-                             _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots, int(bool(exact_screening)),
+                             _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots, mode,
                              _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids), _ptr(out.mkpts0_c),
                              _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), _ptr(out.conf_matrix),
                              _stream(dev))
@@ -138,25 +142,30 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     return out
 
 
-# Shapes / thresholds whose candidate screening overflowed once start later calls with the exact screening pass
-# switched on (flat similarity rows - an untrained network, a tiny thr - would otherwise pay for the coarse stage
-# twice on every forward).
+# Shapes / thresholds whose candidate screening overflowed once (or whose similarity was flat once) start later calls
+# with the exact screening pass (the dense sum kernel) switched on: flat similarity - an untrained network, a tiny
+# thr, textureless images - would otherwise pay for the coarse stage twice on every forward.
 _NEEDS_EXACT_SCREENING = set()
+_NEEDS_DENSE = set()
 
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
-                 scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None) -> dict:
+                 scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None,
+                 dense: Optional[bool] = None) -> dict:
     """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
-    N*min(L,S)), with the exact screening pass, then with more candidate slots when the device reports
-    the corresponding overflow.  exact_screening=None: on when conf_matrix is requested (that path already runs
-    the denominator reduction the exact screening needs, and it is the training / untrained-network mode in which
-    flat rows occur) or when this shape needed it before."""
+    N*min(L,S)), with the dense sum kernel (FM_E_DENSE), with the exact screening pass, then with more candidate
+    slots when the device reports the corresponding condition.  exact_screening=None: on when conf_matrix is
+    requested (that path already runs the denominator reduction the exact screening needs, and it is the training /
+    untrained-network mode in which flat rows occur) or when this shape needed it before; dense=None likewise."""
     lib = _lib.load()
     key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
     if exact_screening is None:
         exact_screening = bool(conf_matrix) or key in _NEEDS_EXACT_SCREENING
-    kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening))
-    for _ in range(6):
+    if dense is None:
+        dense = key in _NEEDS_DENSE
+    kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening),
+              dense=bool(dense))
+    for _ in range(7):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
                                  scale0, scale1, conf_matrix=conf_matrix, **kw)
         try:
@@ -164,6 +173,10 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
         except _lib.FMatchError as e:
             if e.status == _lib.FM_E_CAPACITY:
                 kw['cap'] = int(e.required)
+                continue
+            if e.status == _lib.FM_E_DENSE and not kw['dense']:
+                kw['dense'] = True
+                _NEEDS_DENSE.add(key)
                 continue
             if e.status == _lib.FM_E_CANDIDATES and not kw['exact_screening']:
                 kw['exact_screening'] = True

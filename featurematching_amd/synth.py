@@ -67,7 +67,11 @@ def permutation(seed: int, stream: int, n: int) -> np.ndarray:
     return np.argsort(hash_u64(seed, stream, n), kind="stable").astype(np.int64)
 
 
-DISTRIBUTIONS = {"peaky": (4.0, 0.4), "borderline": (1.0, 1.0)}
+# name -> (gain, noise); "mixed" = "peaky" with a fraction of near-zero cells (textureless regions: descriptors
+# scaled by MIXED_SCALE) chosen independently in both images, so some partners of good cells are missing and the
+# affected rows / columns have flat similarity
+DISTRIBUTIONS = {"peaky": (4.0, 0.4), "borderline": (1.0, 1.0), "mixed": (4.0, 0.4)}
+MIXED_FRACTION, MIXED_SCALE = 0.2, 1e-3
 
 
 def coarse_descriptors(seed: int, n: int, l: int, c: int, dist: str = "peaky"):
@@ -81,6 +85,9 @@ def coarse_descriptors(seed: int, n: int, l: int, c: int, dist: str = "peaky"):
         perm = permutation(seed + b, 3, l)
         f0[b] = g * z0
         f1[b] = f0[b][perm] + np.float32(sigma) * z1
+        if dist == "mixed":
+            f0[b][uniform(seed + b, 6, l) < MIXED_FRACTION] *= np.float32(MIXED_SCALE)
+            f1[b][uniform(seed + b, 7, l) < MIXED_FRACTION] *= np.float32(MIXED_SCALE)
     return f0, f1
 
 

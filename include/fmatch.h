@@ -42,10 +42,20 @@ enum fm_status {
   FM_E_UNSUPPORTED = -3, /* C > 256 or C % 4 != 0, Cf != 64, W not in {5,7}, thr <= 0 ... */
   FM_E_WORKSPACE = -4,   /* workspace too small / misaligned */
   FM_E_CAPACITY = -5,    /* (device status) more matches than `cap`; M_out = required */
-  FM_E_CANDIDATES = -6,  /* (device status) a row produced more than cand_slots candidates: call again with
-                            exact_screening = 1 (then with more cand_slots if it persists) */
-  FM_E_RANGE = -7        /* (device status) descriptor not finite or |x| >= 32768 */
+  FM_E_CANDIDATES = -6,  /* (device status) a row or column produced more than cand_slots candidates: call again
+                            with mode | FM_MODE_EXACT_SCREENING (then with more cand_slots if it persists) */
+  FM_E_RANGE = -7,       /* (device status) a descriptor is not finite or has |x| >= 32768, or the similarities are so
+                            large (several thousand: |f0||f1| / (C*temperature)) that the int8 screening margin alone,
+                            2^60 in the log2 domain, could overflow the float32 exponentials */
+  FM_E_DENSE = -8        /* (device status) a sample's similarity is flat (more significant entries per 32 x 32 unit
+                            than the sparse sum kernel resolves: an untrained network, textureless images); its result
+                            is incomplete: call again with mode | FM_MODE_DENSE */
 };
+
+/* `mode` bits of fm_coarse_match / fm_coarse_workspace_bytes_mode (0 = the common path: 4 launches) */
+#define FM_MODE_EXACT_SCREENING 1 /* two more kernels re-screen the candidates with the exact softmax denominators */
+#define FM_MODE_DENSE 2           /* float16 planes + the dense sum kernel (float32-equivalent product on the matrix
+                                     cores) for the samples the sparse sum kernel flags; both exit at once otherwise */
 
 /* element type of the coarse descriptors handed to fm_coarse_match_dtype */
 enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
@@ -54,6 +64,7 @@ enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
 #define FM_DEV_CAPACITY 1
 #define FM_DEV_CANDIDATES 2
 #define FM_DEV_RANGE 4
+#define FM_DEV_DENSE 8
 
 int fm_version(void);
 const char* fm_strerror(int status);
@@ -63,8 +74,12 @@ const char* fm_strerror(int status);
  * default adds head-room for the float16 screening margin. */
 int fm_default_cand_slots(float thr);
 
-/* Bytes of device workspace fm_coarse_match needs (256-byte aligned base). */
+/* Bytes of device workspace fm_coarse_match needs (256-byte aligned base): fm_coarse_workspace_bytes for any mode and a
+ * conf_matrix request, fm_coarse_workspace_bytes_mode for the given mode bits (want_conf_matrix != 0: as with
+ * FM_MODE_DENSE | FM_MODE_EXACT_SCREENING); the common path (mode 0) needs about a quarter of the full size. */
 int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t* bytes);
+int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int cand_slots, int mode, int want_conf_matrix,
+                                   size_t* bytes);
 
 /*
  * Coarse stage (coarse_matching_new.py:43-143, eval mode).
@@ -78,17 +93,20 @@ int fm_coarse_workspace_bytes(int N, int L, int S, int C, int cand_slots, size_t
  *   b_ids,i_ids,j_ids int64[cap]; mkpts0_c,mkpts1_c float32[cap,2] (x,y px);
  *   mconf float32[cap]; d_count int32[2] = {M, status bits}.
  *   conf_matrix: optional [dev] float32 [N,L,S] (data['conf_matrix'], :70) or NULL.
- *   exact_screening: 0 = candidates are screened in the sum sweep against lower bounds of the row /
- *   column maxima (enough for dual-softmax-trained descriptors; rows with nearly flat similarity - an
- *   untrained network, a tiny thr - can overflow their cand_slots: FM_E_CANDIDATES);  1 = two more
- *   kernels repeat the screening with the exact softmax denominators, decided on the device (they exit at
- *   once when the first screening sufficed), after which at most 1/thr entries of a row can be candidates.
+ *   mode (the former exact_screening flag, same values for 0 / 1): 0 = the common path - prep, int8 max pass,
+ *   sparse sum kernel, assignment: candidates are screened in the sum sweep against lower bounds of the row / column
+ *   maxima, which is enough for dual-softmax-trained descriptors; flat similarity reports FM_E_DENSE (a whole sample
+ *   has no peaks) or FM_E_CANDIDATES (single rows overflow their cand_slots) through the status word.
+ *   FM_MODE_DENSE adds the float16 planes and the dense sum kernel for flagged samples, FM_MODE_EXACT_SCREENING
+ *   (implies FM_MODE_DENSE) two more kernels that repeat the screening with the exact softmax denominators, after
+ *   which at most 1/thr entries of a row can be candidates; all of them are decided on the device and exit at once
+ *   when not needed.  A conf_matrix request implies both.
  */
 int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S, int C,
                     int h0c, int w0c, int h1c, int w1c,
                     float temperature, float thr, int border_rm, float scale_px,
                     const float* scale0, const float* scale1,
-                    void* workspace, size_t workspace_bytes, int cand_slots, int exact_screening,
+                    void* workspace, size_t workspace_bytes, int cand_slots, int mode,
                     int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
                     float* mkpts0_c, float* mkpts1_c, float* mconf,
                     int cap, int32_t* d_count, float* conf_matrix, void* stream);
@@ -105,7 +123,7 @@ int fm_coarse_match_dtype(const void* feat0, const void* feat1, int in_dtype, in
                           int h0c, int w0c, int h1c, int w1c,
                           float temperature, float thr, int border_rm, float scale_px,
                           const float* scale0, const float* scale1,
-                          void* workspace, size_t workspace_bytes, int cand_slots, int exact_screening,
+                          void* workspace, size_t workspace_bytes, int cand_slots, int mode,
                           int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
                           float* mkpts0_c, float* mkpts1_c, float* mconf,
                           int cap, int32_t* d_count, float* conf_matrix, void* stream);
@@ -119,11 +137,14 @@ int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* 
  * 1 = dense sum kernel, 2 = exact screening sweep; fm_debug_launch_sum_sparse: the sparse sum kernel) on a
  * workspace filled by a previous fm_coarse_match of the same shapes and inputs / zero the candidate counters
  * and scalars so that the sum kernels can run again; used by bench.py to bracket the dominant kernels with
- * events on their own stream. */
+ * events on their own stream.  Modes 1 / 2 and fm_debug_launch_prep_f16 need a full-size workspace
+ * (fm_coarse_workspace_bytes). */
 int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_slots,
                          float temperature, float thr, int mode, void* stream);
 int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
                                int C, int cand_slots, float temperature, float thr, void* stream);   /* float32 rows */
+int fm_debug_launch_prep(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
+                         int cand_slots, void* stream);      /* k_prep_split alone; clears the per-call counters */
 int fm_debug_launch_prep_f16(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
                              int cand_slots, int force, void* stream);
 int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream);

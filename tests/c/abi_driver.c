@@ -30,12 +30,14 @@ static __typeof__(fm_version)* p_fm_version;
 static __typeof__(fm_strerror)* p_fm_strerror;
 static __typeof__(fm_default_cand_slots)* p_fm_default_cand_slots;
 static __typeof__(fm_coarse_workspace_bytes)* p_fm_coarse_workspace_bytes;
+static __typeof__(fm_coarse_workspace_bytes_mode)* p_fm_coarse_workspace_bytes_mode;
 static __typeof__(fm_coarse_match)* p_fm_coarse_match;
 static __typeof__(fm_coarse_match_dtype)* p_fm_coarse_match_dtype;
 static __typeof__(fm_debug_coarse_layout)* p_fm_debug_coarse_layout;
 static __typeof__(fm_debug_launch_corr)* p_fm_debug_launch_corr;
 static __typeof__(fm_debug_launch_sum_sparse)* p_fm_debug_launch_sum_sparse;
 static __typeof__(fm_debug_launch_prep_f16)* p_fm_debug_launch_prep_f16;
+static __typeof__(fm_debug_launch_prep)* p_fm_debug_launch_prep;
 static __typeof__(fm_debug_reset_counters)* p_fm_debug_reset_counters;
 static __typeof__(fm_coarse_tf_packed_bytes)* p_fm_coarse_tf_packed_bytes;
 static __typeof__(fm_coarse_tf_workspace_bytes)* p_fm_coarse_tf_workspace_bytes;
@@ -55,9 +57,9 @@ int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s libfmatch_hip.so\n", argv[0]); return 2; }
   void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
-  RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes);
+  RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes); RESOLVE(fm_coarse_workspace_bytes_mode);
   RESOLVE(fm_coarse_match); RESOLVE(fm_coarse_match_dtype); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
-  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
+  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
@@ -65,7 +67,7 @@ int main(int argc, char** argv) {
   RESOLVE(fm_coarse_transformer);
 
   EXPECT(p_fm_version(), FM_VERSION);
-  for (int s = FM_E_RANGE; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
+  for (int s = FM_E_DENSE; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
   EXPECT(strcmp(p_fm_strerror(-99), "unknown fmatch status"), 0);
   EXPECT(p_fm_default_cand_slots(0.2f), 8);
   EXPECT(p_fm_default_cand_slots(0.0f), 64);
@@ -75,6 +77,15 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, &bytes), FM_OK);
   EXPECT(bytes > 10u * 1000 * 1000 && bytes < 80u * 1000 * 1000, 1);
   EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, NULL), FM_E_NULL);
+  size_t common = 0, full = bytes;
+  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, &common), FM_OK);
+  EXPECT(common > 2u * 1000 * 1000 && common <= 8u * 1000 * 1000 && common < full, 1);
+  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, FM_MODE_DENSE, 0, &bytes), FM_OK);
+  EXPECT(bytes == full, 1);
+  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 1, &bytes), FM_OK);
+  EXPECT(bytes == full, 1);
+  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 8, 0, &bytes), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, NULL), FM_E_NULL);
   EXPECT(p_fm_coarse_workspace_bytes(0, 4800, 4800, 256, 8, &bytes), FM_E_SHAPE);
   EXPECT(p_fm_coarse_workspace_bytes(1, -1, 4800, 256, 8, &bytes), FM_E_SHAPE);
   EXPECT(p_fm_coarse_workspace_bytes(1, 4800, 0, 256, 8, &bytes), FM_E_SHAPE);
@@ -112,6 +123,13 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.0f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 5, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 16, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 4, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);   /* unknown mode bit */
+  {   /* a workspace sized for the common path is refused when the call needs the dense regions */
+    size_t small = 0;
+    EXPECT(p_fm_coarse_workspace_bytes_mode(1, 64, 64, 64, 8, 0, 0, &small), FM_OK);
+    EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, small, 8, FM_MODE_DENSE, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
+    EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, small, 8, 0, one, one, one, one, one, one, 64, cnt, (float*)one, NULL), FM_E_WORKSPACE);
+  }
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, odd, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
   EXPECT(p_fm_coarse_match_dtype(one, one, 7, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match_dtype(NULL, one, FM_F16, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_NULL);
@@ -131,6 +149,8 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_debug_launch_sum_sparse(one, NULL, one, 1, 64, 64, 64, 8, 0.1f, 0.2f, NULL), FM_E_NULL);
   EXPECT(p_fm_debug_launch_sum_sparse(one, one, one, 1, 64, 64, 64, 16 + 1, 0.1f, 0.2f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_debug_launch_prep_f16(one, one, NULL, 1, 64, 64, 64, 8, 1, NULL), FM_E_NULL);
+  EXPECT(p_fm_debug_launch_prep(one, NULL, one, 1, 64, 64, 64, 8, NULL), FM_E_NULL);
+  EXPECT(p_fm_debug_launch_prep(one, one, one, 1, 64, 64, 63, 8, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_debug_launch_prep_f16(one, one, one, 1, 64, 64, 64, 64 + 1, 1, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_debug_reset_counters(NULL, 1, 64, 64, 64, 8, NULL), FM_E_NULL);
   EXPECT(p_fm_debug_reset_counters(one, 1, 64, 0, 64, 8, NULL), FM_E_SHAPE);

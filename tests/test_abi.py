@@ -31,7 +31,7 @@ def test_version_and_messages():
     lib = _lib.load()
     assert lib.fm_version() == 100
     assert lib.fm_strerror(0) == b"ok"
-    for code in range(-7, 0):
+    for code in range(-8, 0):
         assert lib.fm_strerror(code) not in (b"", b"unknown fmatch status")
     assert lib.fm_default_cand_slots(0.2) == 8
     assert lib.fm_default_cand_slots(0.05) == 32
@@ -43,7 +43,17 @@ def test_workspace_query_and_argument_checks():
     n = C.c_size_t(0)
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n)) == 0
     per_pair = n.value
-    assert 10e6 < per_pair < 60e6          # 4 float16 planes (9.96 MB) + partial statistics
+    assert 10e6 < per_pair < 60e6          # any mode: 4 float16 planes (9.96 MB) + both candidate sets + statistics
+    # the common path (mode 0: prep, max pass, sparse sum kernel, assignment) needs neither the float16 planes nor the
+    # dense kernel's partials and candidate set
+    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, C.byref(n)) == 0
+    assert 2.4e6 < n.value <= 8e6          # 2 int8 planes (2.47 MB) + statistics, partial sums, candidate lists
+    common = n.value
+    for mode, conf in ((1, 0), (2, 0), (3, 0), (0, 1)):
+        assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, mode, conf, C.byref(n)) == 0
+        assert n.value == per_pair > common
+    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 4, 0, C.byref(n)) == -3      # unknown mode bit
+    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, None) == -1
     assert lib.fm_coarse_workspace_bytes(64, 4800, 4800, 256, 8, C.byref(n)) == 0
     assert n.value < 64 * per_pair * 1.2
     assert lib.fm_coarse_workspace_bytes(1, 4800, 4800, 102, 8, C.byref(n)) == -3     # C % 4 != 0

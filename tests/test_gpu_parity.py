@@ -199,6 +199,9 @@ def test_flat_rows_take_the_exact_screening_pass():
     t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
     with pytest.raises(_lib.FMatchError) as e:
         ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0).read_count()
+    assert e.value.status in (_lib.FM_E_DENSE, _lib.FM_E_CANDIDATES)      # flat units / overflowing slots, whichever is met first
+    with pytest.raises(_lib.FMatchError) as e:
+        ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0, dense=True).read_count()
     assert e.value.status == _lib.FM_E_CANDIDATES
     buf = ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0, exact_screening=True)
     assert buf.read_count() == ref['i_ids'].shape[0]
@@ -218,12 +221,14 @@ def test_flat_rows_with_conf_matrix_run_the_coarse_stage_once(monkeypatch):
     out = ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0, conf_matrix=True)
     assert calls == [True]
     _assert_coarse(out, ref)
-    # and a shape that overflowed once starts with the exact screening the next time
+    # and a shape that overflowed once starts with the exact screening (and the dense sum kernel) the next time
     calls.clear()
     ops._NEEDS_EXACT_SCREENING.clear()
+    ops._NEEDS_DENSE.clear()
     ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
+    n_first = len(calls)
     ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
-    assert calls == [False, True, True]
+    assert 2 <= n_first <= 3 and calls[0] is False and calls[n_first - 1] is True and calls[n_first:] == [True]
 
 
 def test_non_finite_input_is_reported():
@@ -535,7 +540,8 @@ def test_cell_ordered_gather_equals_list_ordered_gather(w):
     f1[1, 70] = vc
     f0[1, 60] = f0[1, 61] = vc + 0.4 * synth.normal(71, 14, (64,))            # two image-0 cells -> one image-1 cell
     t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
-    buf = ops.coarse_match_async(t0, t1, (hc, wc), (hc, wc), 8.0, border_rm=0)
+    # (cells without a partner have flat similarity rows: the dense sum kernel's job, FM_MODE_DENSE)
+    buf = ops.coarse_match_async(t0, t1, (hc, wc), (hc, wc), 8.0, border_rm=0, dense=True)
     m = buf.read_count()
     o = buf.sliced(m)
     pairs0 = list(zip(o['b_ids'].tolist(), o['i_ids'].tolist()))
@@ -562,7 +568,7 @@ def test_fused_crop_and_context_merge(name, dist):
     hc, wc = c['hw_c']
     dw, db, mw, mb = (torch.as_tensor(a, device=DEV) for a in synth.merge_weights(c['cfg']['seed'], c['cfg']['c'], 64))
     fc0, fc1 = torch.as_tensor(c['f0'], device=DEV), torch.as_tensor(c['f1'], device=DEV)
-    buf = ops.coarse_match_async(fc0, fc1, c['hw_c'], c['hw_c'], 8.0)
+    buf = ops.coarse_match_async(fc0, fc1, c['hw_c'], c['hw_c'], 8.0, dense=(dist == "borderline"))
     m = buf.read_count()
     o = buf.sliced(m)
     assert np.array_equal(o['i_ids'].cpu().numpy(), g['i_ids']) and np.array_equal(o['j_ids'].cpu().numpy(), g['j_ids'])
@@ -627,7 +633,7 @@ def test_pair_gather_equals_two_single_gathers(w):
     f1[:, perm[:k]] = f0[:, :k] + 0.4 * synth.normal(81, 4, (2, k, 64))
     f1[0, perm[k]] = f1[0, perm[0]]                                  # tie: cell 0 of image 0 -> two cells of image 1
     t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
-    buf = ops.coarse_match_async(t0, t1, (h0, w0), (h1, w1), 8.0, border_rm=0)
+    buf = ops.coarse_match_async(t0, t1, (h0, w0), (h1, w1), 8.0, border_rm=0, dense=True)
     m = buf.read_count()
     o = buf.sliced(m)
     assert m > 100

@@ -35,7 +35,7 @@ def main():
     for name in ("fm_debug_launch_corr",):
         res, args = _lib.SIGNATURES[name]
         getattr(v, name).restype, getattr(v, name).argtypes = res, args
-    buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap)
+    buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)     # full-size workspace
     torch.cuda.synchronize()
     ws = buf.workspace
     off = (-ws.data_ptr()) % 256

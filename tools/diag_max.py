@@ -34,7 +34,7 @@ def main():
     v = C.CDLL(os.path.abspath(a.lib))
     res, args = _lib.SIGNATURES["fm_debug_launch_corr"]
     v.fm_debug_launch_corr.restype, v.fm_debug_launch_corr.argtypes = res, args
-    buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap)
+    buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)     # full-size workspace
     torch.cuda.synchronize()
     ws = buf.workspace
     off = (-ws.data_ptr()) % 256

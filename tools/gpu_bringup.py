@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT)
 from featurematching_amd import _lib, ops, synth  # noqa: E402
 from oracle import matcher_ref as orc  # noqa: E402  (checker only)
 
-NAMES = ["cand_count", "colbest", "scalars", "blocktot", "hi0", "lo0", "hi1", "lo1", "q0", "q1", "sig0",
-         "sig1", "rowS", "colS", "rowB", "colB", "nmr", "nmc", "rsum", "csum", "cand_j", "cand_conf", "rowbest",
+NAMES = ["cand_count", "ccand_count", "scalars", "blocktot", "hi0", "lo0", "hi1", "lo1", "q0", "q1", "sigimg",
+         "l1_0", "rowS", "colS", "rowB", "colB", "nmr", "nmc", "rsum", "csum", "cand_j", "cand_x", "ccand_i",
          "umax", "dense_cnt", "rowmax_u", "colmax_u", "splits_s", "units_s", "total"]
 
 
@@ -45,7 +45,7 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     s = f1.shape[1]
     dev = torch.device("cuda:0")
     t0, t1 = torch.as_tensor(f0, device=dev), torch.as_tensor(f1, device=dev)
-    buf = ops.coarse_match_async(t0, t1, hw_c0, hw_c1, 8.0, thr, border, temp)
+    buf = ops.coarse_match_async(t0, t1, hw_c0, hw_c1, 8.0, thr, border, temp, dense=True)
     torch.cuda.synchronize()
     slots = _lib.load().fm_default_cand_slots(thr)
     lay = layout(n, l, s, c, slots)
@@ -92,20 +92,21 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
 
     q0 = unfrag8(view(ws, base, lay["q0"], n * Lp * cp, torch.int8), Lp).astype(np.float64)
     q1 = unfrag8(view(ws, base, lay["q1"], n * Sp * cp, torch.int8), Sp).astype(np.float64)
-    sig0 = view(ws, base, lay["sig0"], n * Lp, torch.float32).reshape(n, Lp)
-    sig1 = view(ws, base, lay["sig1"], n * Sp, torch.float32).reshape(n, Sp)
-    eq0 = (np.abs(q0[:, :l] * sig0[:, :l, None] - f0) / np.maximum(sig0[:, :l, None], 1e-30)).max()
-    eq1 = (np.abs(q1[:, :s] * sig1[:, :s, None] - f1) / np.maximum(sig1[:, :s, None], 1e-30)).max()
-    print(f"   int8 planes: |x - sigma q| / sigma max {eq0:.4f} / {eq1:.4f} (must be <= 0.5); |q| max {np.abs(q0).max():.0f}")
+    sig = view(ws, base, lay["sigimg"], n * 2, torch.float32).reshape(n, 2).astype(np.float64)
+    # one step per image; what the clamp at +-127 cut off is accounted for in the margins (fm_device.h)
+    clip0 = np.maximum(np.abs(f0) - 127 * sig[:, 0, None, None], 0).sum(2)
+    clip1 = np.maximum(np.abs(f1) - 127 * sig[:, 1, None, None], 0).sum(2)
+    eq0 = ((np.abs(q0[:, :l] * sig[:, 0, None, None] - f0) - np.maximum(np.abs(f0) - 127 * sig[:, 0, None, None], 0)) / np.maximum(sig[:, 0, None, None], 1e-30)).max()
+    eq1 = ((np.abs(q1[:, :s] * sig[:, 1, None, None] - f1) - np.maximum(np.abs(f1) - 127 * sig[:, 1, None, None], 0)) / np.maximum(sig[:, 1, None, None], 1e-30)).max()
+    print(f"   int8 planes: steps {sig.tolist()}  (|x - sigma q| - clipped) / sigma max {eq0:.4f} / {eq1:.4f} (must be <= 0.5); "
+          f"|q| max {np.abs(q0).max():.0f}/{np.abs(q1).max():.0f}; clipped L1 max {clip0.max():.3g}/{clip1.max():.3g}")
     ok &= eq0 <= 0.5001 and eq1 <= 0.5001
 
-    def ord_decode(u):                  # fm_device.h: order-preserving uint code -> float (0 = nothing recorded)
-        u = u.astype(np.uint32)
-        bits = np.where(u & np.uint32(0x80000000), u & np.uint32(0x7fffffff), ~u)
-        return np.where(u == 0, np.float32(0), bits.view(np.float32))
+    def q_decode(u):                    # fm_device.h: biased integer code -> integer screening product
+        return u.astype(np.int64) - 0x40000000
 
-    rowA = ord_decode(view(ws, base, lay["rowmax_u"], n * Lp, torch.int32)).reshape(n, Lp)
-    colA = ord_decode(view(ws, base, lay["colmax_u"], n * Sp, torch.int32)).reshape(n, Sp)
+    rowA = q_decode(view(ws, base, lay["rowmax_u"], n * Lp, torch.int32)).reshape(n, Lp) * (sig[:, 0] * sig[:, 1])[:, None]
+    colA = q_decode(view(ws, base, lay["colmax_u"], n * Sp, torch.int32)).reshape(n, Sp) * (sig[:, 0] * sig[:, 1])[:, None]
     nmr = view(ws, base, lay["nmr"], n * Lp, torch.float32).reshape(n, Lp)
     nmc = view(ws, base, lay["nmc"], n * Sp, torch.float32).reshape(n, Sp)
     # softmax denominators = the sum pass's partials folded (k_cand_conf does the same for its candidates;
@@ -123,16 +124,11 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
             rsum[bb], csum[bb] = rB[bb], cB[bb]
     ccount = view(ws, base, lay["cand_count"], n * Lp, torch.int32).reshape(n, Lp).copy()
     cand_j = view(ws, base, lay["cand_j"], n * Lp * slots, torch.int32).reshape(n, Lp, slots).copy()
-    o_b = lay["cand_j"] + (lay["rowbest"] - lay["cand_conf"]) + n * Lp * 4        # cand_j_b follows rowbest
-    o_b = (o_b + 255) // 256 * 256
-    cnt_b = view(ws, base, lay["cand_count"] + (n * Lp * 4 + 255) // 256 * 256, n * Lp, torch.int32).reshape(n, Lp)
-    cj_b = view(ws, base, lay["rowbest"] + (n * Lp * 4 + 255) // 256 * 256, n * Lp * slots, torch.int32).reshape(n, Lp, slots)
-    for bb in range(n):
-        if dcnt[bb] > 0:
-            ccount[bb], cand_j[bb] = cnt_b[bb], cj_b[bb]
+    # (the dense kernel's candidate set lives behind the common region; the superset check below looks at the sparse
+    # kernel's set and skips the samples the dense kernel redid)
     log2e = 1.4426950408889634
     for b in range(n):
-        dot_hi = (q0[b, :l] * sig0[b, :l, None]) @ (q1[b, :s] * sig1[b, :s, None]).T      # the screening product
+        dot_hi = (q0[b, :l] @ q1[b, :s].T) * (sig[b, 0] * sig[b, 1])      # the screening product
         dot = f0[b].astype(np.float64) @ f1[b].astype(np.float64).T
         sim = dot * inv_ct
         ea = np.abs(rowA[b, :l] - dot_hi.max(1)).max() / max(1.0, np.abs(dot_hi).max())
@@ -157,7 +153,7 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
         pc = np.exp(sim - sim.max(0, keepdims=True)); pc /= pc.sum(0, keepdims=True)
         conf = pr * pc
         need = np.argwhere(conf > thr)
-        missing = [(i, j) for i, j in need if j not in cand_j[b, i, :min(ccount[b, i], slots)]]
+        missing = [] if dcnt[b] > 0 else [(i, j) for i, j in need if j not in cand_j[b, i, :min(ccount[b, i], slots)]]
         print(f"   [b={b}] candidates: {int(ccount[b, :l].sum())} listed, max/row {ccount[b, :l].max()}, "
               f"{len(need)} needed, {len(missing)} missing")
         ok &= not missing

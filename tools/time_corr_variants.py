@@ -46,7 +46,7 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     print(f"workload {a.workload} dist {a.dist}: N={p.n} L={p.l} C={p.c}")
     for path in ["<shipped>"] + a.libs:
-        buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap)   # fresh, correct workspace
+        buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)     # full-size workspace   # fresh, correct workspace
         torch.cuda.synchronize()
         ptr = C.c_void_p(buf.workspace.data_ptr() + ((-buf.workspace.data_ptr()) % 256))
         v = lib
