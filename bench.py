@@ -52,7 +52,7 @@ class Pair:
     """Device-resident inputs of one batch of pairs plus the launch of one step on them.  The window
     buffers belong to the stream the pair runs on (`share`: pairs of one stream run one after the other)."""
 
-    def __init__(self, wl, seed, window, dev, dist, share=None, device_data=False):
+    def __init__(self, wl, seed, window, dev, dist, share=None, device_data=False, layout="nchw", fine_path="maps"):
         sh = synth.config_shapes(wl)
         self.seed, self.dist, self.wl = seed, dist, wl
         self.n, self.l, self.c = wl["n"], sh["l"], wl["c"]
@@ -78,16 +78,23 @@ class Pair:
                 self.f1[torch.rand(self.n, self.l, device=dev, generator=g) < synth.MIXED_FRACTION] *= synth.MIXED_SCALE
             self.ff0 = torch.randn(self.n, wl["cf"], sh["hf"], sh["wf"], device=dev, generator=g)
             self.ff1 = torch.randn(self.n, wl["cf"], sh["hf"], sh["wf"], device=dev, generator=g)
+        self.layout, self.fine_path = layout, fine_path
+        if layout == "nhwc":      # channels-last storage of the same logical [N,Cf,Hf,Wf] maps
+            self.ff0 = self.ff0.contiguous(memory_format=torch.channels_last)
+            self.ff1 = self.ff1.contiguous(memory_format=torch.channels_last)
         w0, b0, w1, b1 = synth.mix_weights(seed, window * window)
         self.mix = (w0, b0, w1, b1)
         self.mix0 = torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=dev)
         self.mix1 = torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=dev)
         self.cap = self.n * self.l
-        if share is None:
+        self.win0 = self.win1 = self.scratch = None
+        if share is not None:
+            self.win0, self.win1, self.scratch = share.win0, share.win1, share.scratch
+        elif fine_path == "windows":
             self.win0 = torch.empty(self.cap, window * window, wl["cf"], device=dev)
             self.win1 = torch.empty_like(self.win0)
-        else:
-            self.win0, self.win1 = share.win0, share.win1
+        elif layout == "nchw":    # channels-last copies of both maps (fm_fine_match_maps makes them per call)
+            self.scratch = torch.empty(2 * self.ff0.numel() * 4, dtype=torch.uint8, device=dev)
         self.last = None
         self.gather = "cells"    # cells | list (see ops.gather_windows)
         self.dense = dist != "peaky"     # flat similarity needs the dense sum kernel (FM_MODE_DENSE); the common path is 4 launches
@@ -108,14 +115,26 @@ class Pair:
         if self.stages == "coarse" and self.last is not None:
             self.last = (buf,) + self.last[1:]
             return self.last
-        self.crop(buf)
-        k0, k1 = self.fine(buf)
+        if self.fine_path == "maps":
+            k0, k1 = self.fine_maps(buf)
+        else:
+            self.crop(buf)
+            k0, k1 = self.fine(buf)
         self.last = (buf, k0, k1)
         return self.last
 
+    def fine_maps(self, buf):
+        """window crop + fine stage from the maps in one call (no window tensors)"""
+        return ops.fine_match_maps(self.ff0, self.ff1, buf.b_ids, buf.i_ids, buf.j_ids, self.window, 4, self.hw_c[1],
+                                   self.hw_c[1], self.mix0, self.mix1, buf.mkpts0_c, buf.mkpts1_c,
+                                   self.hw_i[0] / self.hw_f[0], count=buf.count, scratch=self.scratch)
+
     def crop(self, buf):
         w = self.window
-        if self.gather == "cells":      # both images' crops in one launch, cell order
+        if self.layout == "nhwc":       # channels-last maps: one list-ordered copy kernel per image
+            ops.gather_windows(self.ff0, buf.b_ids, buf.i_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win0)
+            ops.gather_windows(self.ff1, buf.b_ids, buf.j_ids, w, 4, self.hw_c[1], count=buf.count, out=self.win1)
+        elif self.gather == "cells":    # both images' crops in one launch, cell order
             ops.gather_windows_pair(self.ff0, self.ff1, buf.b_ids, buf.i_ids, buf.j_ids, w, 4, self.hw_c, self.hw_c,
                                     buf.cell_maps(), count=buf.count, out0=self.win0, out1=self.win1)
         else:                           # "list": one list-ordered launch per image
@@ -205,8 +224,12 @@ def time_kernels(pair):
     pair.step()
     torch.cuda.synchronize()
     buf = pair.last[0]
-    t["crop"] = _events(lambda: pair.crop(buf))
-    t["fine"] = _events(lambda: pair.fine(buf))
+    if pair.fine_path == "maps":
+        t["crop"] = 0.0
+        t["fine"] = _events(lambda: pair.fine_maps(buf), group=3)      # (NCHW: the two transposes + the fused kernel)
+    else:
+        t["crop"] = _events(lambda: pair.crop(buf), group=3 if pair.layout == "nhwc" else 6)
+        t["fine"] = _events(lambda: pair.fine(buf))
     pair.stages = keep
     return t
 
@@ -361,7 +384,7 @@ def cpu_baseline(wl, window, seed, budget_s=18.0):
                       f"the same pair"}
 
 
-def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, check=True):
+def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, check=True, layout="nchw", fine_path="maps"):
     """Pairs/s of the same step for another workload / distribution / pairs per launch: `nsets` resident input sets
     (generated on the device) cycled through on `nstreams` streams by hipGraph replay, `steps` timed steps.  Returns
     (pairs/s, verification of the first input set's last step against the oracle, matches per pair)."""
@@ -369,7 +392,7 @@ def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, chec
     pairs = []
     for p in range(nsets):
         pairs.append(Pair(wb, 5000 + 31 * p, window, dev, dist, share=pairs[p % nstreams] if p >= nstreams else None,
-                          device_data=True))
+                          device_data=True, layout=layout, fine_path=fine_path))
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     for i, p in enumerate(pairs):
         with torch.cuda.stream(streams[i % nstreams]):
@@ -505,6 +528,10 @@ def main():
                     help="distinct resident input sets cycled through (12 x 59 MB of inputs: far beyond the 256 MB "
                          "Infinity Cache, so every step reads its inputs from HBM)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps are spread over")
+    ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc"],
+                    help="storage of the fine maps: nchw = the reference's contiguous [N,Cf,Hf,Wf]; nhwc = channels-last")
+    ap.add_argument("--fine-path", default="maps", choices=["windows", "maps"],
+                    help="windows = window crop -> fine kernel; maps = crop + fine from the maps in one call (fm_fine_match_maps)")
     ap.add_argument("--reps", type=int, default=0,
                     help="repetitions of the timed K-step region (0 = enough for >= 120 ms of GPU work, at least 3)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
@@ -548,7 +575,7 @@ def main():
     pairs = []
     for p in range(npairs):      # pair p runs on stream p % nstreams and shares that stream's window buffers
         pairs.append(Pair(wl, 1000 * (rank + 1) + 17 * p, a.window, dev, a.dist,
-                          share=pairs[p % nstreams] if p >= nstreams else None))
+                          share=pairs[p % nstreams] if p >= nstreams else None, layout=a.layout, fine_path=a.fine_path))
 
     # Steps are independent pairs: consecutive steps go round-robin to `--streams` HIP streams so that
     # the (mostly latency-bound, small-grid) kernels of different pairs overlap on the chip.  Every input
@@ -677,7 +704,9 @@ def main():
     fine_bytes = 2.0 * m_avg * wl["n"] * ww * cf * 4 + 2.0 * m_avg * wl["n"] * 12
     traffic, traffic_src = committed_traffic(a.workload)
     copy_gbs = copy_rate(crop_bytes, dev)
-    launches = 4 + (2 if pairs[0].dense else 0) + 2
+    maps_path = pairs[0].fine_path == "maps"
+    launches = 4 + (2 if pairs[0].dense else 0) + ((3 if a.layout == "nchw" else 1) if maps_path else (3 if a.layout == "nhwc" else 2))
+    map_bytes = 2.0 * wl["n"] * cf * 4 * sh0["hf"] * sh0["wf"]           # both fine maps
     out = {
         "metric": ("image-pairs/sec at 640x480 (coarse corr + dual-softmax mutual-NN + fine window refinement)"
                    if a.workload == "cfg2" else f"image-pairs/sec ({a.workload})")
@@ -728,18 +757,30 @@ def main():
                      "coarse_stage": {"avg_ms": round(tk["coarse"], 5),
                                       "what": "one fm_coarse_match call (all launches with their in-stream gaps, one stream)",
                                       "assignment_and_gaps_ms": round(tk["coarse"] - t_corr - tk["prep"], 5)}},
-        "roofline_aux": {
-            "window_crop": {"bound": "hbm", "kernel": "k_gather_cellorder64 (both images, one launch)",
+        "roofline_aux": ({
+            "fine_from_maps": {"bound": "hbm",
+                               "kernel": ("2 x k_nchw_to_nhwc64 + " if a.layout == "nchw" else "") + f"k_fine_maps<{a.window}> (window crop + fine stage, no window tensors)",
+                               # SURVEY 8(d) fine-kernel bytes (the window bytes, read once) + for NCHW maps the transposes' read + write
+                               "algorithmic_bytes": fine_bytes + (2.0 * map_bytes if a.layout == "nchw" else 0.0),
+                               "achieved": round((fine_bytes + (2.0 * map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round((fine_bytes + (2.0 * map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "avg_ms": round(tk["fine"], 5)}} if maps_path else {
+            "window_crop": {"bound": "hbm", "kernel": "k_gather_cellorder64 (both images, one launch)" if a.layout == "nchw"
+                                                      else f"2 x k_gather_nhwc64<{a.window}> (channels-last maps: 16-byte-chunk copy)",
                             "achieved": round(crop_bytes / (tk["crop"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(crop_bytes / (tk["crop"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "avg_ms": round(tk["crop"], 5), "algorithmic_bytes": crop_bytes},
             "fine_match": {"bound": "hbm", "kernel": f"k_fine<{a.window}>",
                            "achieved": round(fine_bytes / (tk["fine"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(fine_bytes / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "avg_ms": round(tk["fine"], 5), "algorithmic_bytes": fine_bytes},
+                           "avg_ms": round(tk["fine"], 5), "algorithmic_bytes": fine_bytes}}) | {
             "plain_copy": {"what": "torch device-to-device copy moving as many bytes as the window crop",
                            "achieved": round(copy_gbs, 1), "unit": "GB/s", "frac": round(copy_gbs / HBM_PEAK_GBS, 4)}},
     }
+    out["config"]["fine_maps_layout"] = a.layout
+    out["config"]["fine_path"] = ("fm_fine_match_maps (crop + fine from the maps)" if maps_path
+                                  else "window crop -> fm_fine_match")
     if world > 1:
         out["gather_ms"] = round(gather_ms, 4)
         out["gathered_records"] = gathered
@@ -842,6 +883,38 @@ def extras(a, wl, dev, streams, flops):
             return {"value": round(rate, 2), "unit": "image-pairs/s", "verified": ver["ok"] if ver else None,
                     "verification": ver, "matches_per_pair": round(m_pp, 1), "workload": w5["label"]}
         guarded("cfg5", cfg5_line)
+
+        def cl_line():
+            """channels-last fine maps: the crop as a 16-byte-chunk copy, and crop + fine from the maps in one kernel"""
+            res = {}
+            with torch.cuda.stream(streams[0]):
+                p = Pair(wl, 8888, a.window, dev, "peaky", device_data=True, layout="nhwc", fine_path="windows")
+                p.step()
+                torch.cuda.synchronize()
+                m = p.last[0].read_count()
+                tw = time_kernels(p)
+                wb = 2.0 * m * a.window * a.window * wl["cf"] * 4
+                res["window_crop"] = {"kernel": f"2 x k_gather_nhwc64<{a.window}>", "avg_ms": round(tw["crop"], 5),
+                                      "algorithmic_bytes": 2 * wb, "achieved_GBs": round(2 * wb / (tw["crop"] * 1e-3) / 1e9, 1),
+                                      "frac_of_8TBs": round(2 * wb / (tw["crop"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                p.fine_path = "maps"
+                p.step()
+                torch.cuda.synchronize()
+                tm = time_kernels(p)
+                res["fine_from_maps"] = {"kernel": f"k_fine_maps<{a.window}>", "avg_ms": round(tm["fine"], 5),
+                                         "algorithmic_bytes": wb + m * 24.0,
+                                         "achieved_GBs": round((wb + m * 24.0) / (tm["fine"] * 1e-3) / 1e9, 1),
+                                         "frac_of_8TBs": round((wb + m * 24.0) / (tm["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "window bytes read once (from the maps), 12 bytes written per keypoint; "
+                                                 "crop + fine_match on the same maps move 3x the window bytes"}
+                del p
+            rate, ver, m_pp = stream_rate(wl, a.window, dev, "peaky", 1, 4, steps=600, nsets=8, layout="nhwc", fine_path="maps")
+            res.update({"value": round(rate, 2), "unit": "image-pairs/s", "verified": ver["ok"] if ver else None,
+                        "verification": ver, "launches_per_step": 5,
+                        "note": "the metric's step with channels-last fine maps (what a backbone that keeps its [B,H,W,C] "
+                                "activations hands over): coarse stage (4 launches) + k_fine_maps; 4 streams"})
+            return res
+        guarded("channels_last_maps", cl_line)
 
         guarded("batched_launches", lambda: {
             "value": round(stream_rate(wl, a.window, dev, "peaky", 4, 4, steps=240, nsets=6, check=False)[0], 2),

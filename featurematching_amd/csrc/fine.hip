@@ -426,6 +426,38 @@ __device__ __forceinline__ void soft_argmax(float sim, int pos, bool on, int lan
   }
 }
 
+// the arithmetic of one match once both windows sit in registers (lane = channel, f[r] = window position r)
+template <int W>
+__device__ __forceinline__ void fine_core(const float (&f0)[W * W], const float (&f1)[W * W], int lane,
+                                          const float* __restrict__ mix0, const float* __restrict__ mix1, float k0x,
+                                          float k0y, float k1x, float k1y, float scale_f, float* __restrict__ out0,
+                                          float* __restrict__ out1) {
+  constexpr int WW = W * W;
+  constexpr int CF = 64;
+  float q0 = mix0[WW], q1 = mix1[WW];
+#pragma unroll
+  for (int r = 0; r < WW; ++r) { q0 = __builtin_fmaf(mix0[r], f0[r], q0); q1 = __builtin_fmaf(mix1[r], f1[r], q1); }
+
+#ifdef FM_ABL_F_NOCOMPUTE     // timing-only: loads and one store, no correlation / soft-argmax
+  if (q0 + q1 == 1.2345e-30f) out0[0] = q0;
+  return;
+#endif
+  const float inv_sqrt_c = 1.0f / sqrtf((float)CF);
+  constexpr int NP = WW > 32 ? 64 : 32;      // butterfly width
+  float p[NP];
+#pragma unroll
+  for (int r = 0; r < NP; ++r) p[r] = r < WW ? q0 * f1[r] : 0.f;
+  const float sim0 = transpose_reduce<NP>(p, lane);
+#pragma unroll
+  for (int r = 0; r < NP; ++r) p[r] = r < WW ? q1 * f0[r] : 0.f;
+  const float sim1 = transpose_reduce<NP>(p, lane);
+
+  const int pos = tr_index<NP>(lane);
+  const bool on = pos < WW && lane < NP;
+  soft_argmax<W>(sim0, pos, on, lane, inv_sqrt_c, scale_f, k0x, k0y, out0);
+  soft_argmax<W>(sim1, pos, on, lane, inv_sqrt_c, scale_f, k1x, k1y, out1);
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_fine(const float* __restrict__ win0, const float* __restrict__ win1, int m_max,
                                               const int32_t* __restrict__ d_count, const float* __restrict__ mix0,
@@ -444,28 +476,148 @@ __global__ __launch_bounds__(256) void k_fine(const float* __restrict__ win0, co
   // read-once data: non-temporal loads keep the windows from displacing the fine maps in L2 (-2 us per pair)
 #pragma unroll
   for (int r = 0; r < WW; ++r) { f0[r] = __builtin_nontemporal_load(p0 + r * CF); f1[r] = __builtin_nontemporal_load(p1 + r * CF); }
-  float q0 = mix0[WW], q1 = mix1[WW];
-#pragma unroll
-  for (int r = 0; r < WW; ++r) { q0 = __builtin_fmaf(mix0[r], f0[r], q0); q1 = __builtin_fmaf(mix1[r], f1[r], q1); }
+  fine_core<W>(f0, f1, lane, mix0, mix1, kc0[m * 2], kc0[m * 2 + 1], kc1[m * 2], kc1[m * 2 + 1], scale_f,
+               out0 + (long)m * 3, out1 + (long)m * 3);
+}
 
-#ifdef FM_ABL_F_NOCOMPUTE     // timing-only: loads and one store, no correlation / soft-argmax
-  if (q0 + q1 == 1.2345e-30f) out0[(long)m * 3] = q0;
-  return;
-#endif
-  const float inv_sqrt_c = 1.0f / sqrtf((float)CF);
-  constexpr int NP = WW > 32 ? 64 : 32;      // butterfly width
-  float p[NP];
+// ----------------------------------------------------------------------------------------
+// Channels-last maps: storage [N, Hf, Wf, 64] of the logical [N, 64, Hf, Wf] tensor (layout 1).  A window row is
+// W x 256 contiguous bytes there - ten cache lines at W = 5 instead of the 64 x 20-byte runs of the NCHW layout - so
+//   * the crop is a plain copy in 16-byte chunks (the output window [WW][64] is the W row segments one after the
+//     other), one wave per window, every load of the window in flight before the first store;
+//   * the fine stage can take its windows straight from the maps: k_fine_maps reads position r of both windows as one
+//     coalesced 256-byte wave load each (exactly the loads k_fine issues on a window tensor) and the window tensors
+//     (48 MB written and read back per 640x480 pair) never exist.  Matches are visited in list order, an XCD a
+//     contiguous range: image-0 windows then walk the map in raster order, image-1 windows land wherever their partner
+//     is - at ten full lines per window that costs nothing extra.
+//   * NCHW maps get there through k_nchw_to_nhwc64 (a tiled transpose through LDS, both sides coalesced) into a
+//     caller-provided scratch buffer.
+// ----------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_gather_nhwc64(const float* __restrict__ feat, int Hf, int Wf, int stride, int pad,
+                                                       int w_c, const int64_t* __restrict__ b_ids,
+                                                       const int64_t* __restrict__ ids, const int32_t* __restrict__ d_count,
+                                                       int m_max, float* __restrict__ out) {
+  constexpr int ROW16 = W * 16;              // 16-byte chunks per window row (64 channels x 4 bytes = 16 chunks per pixel)
+  constexpr int TOTAL16 = W * ROW16;         // ... per window: 400 / 784
+  constexpr int NIT = (TOTAL16 + 63) / 64;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int M = d_count ? min(d_count[0], m_max) : m_max;
+  const int per = (M + 7) >> 3;
+  const int slot = (int)(blockIdx.x >> 3) * 4 + wv;
+  const int m = (blockIdx.x & 7) * per + slot;
+  if (slot >= per || m >= M) return;
+  const int b = __builtin_amdgcn_readfirstlane((int)b_ids[m]);
+  const int id = __builtin_amdgcn_readfirstlane((int)ids[m]);
+  const int cy = id / w_c;
+  const int oy = cy * stride - pad, ox = (id - cy * w_c) * stride - pad;
+  const float4* src = reinterpret_cast<const float4*>(feat + (long)b * Hf * Wf * 64);
+  float4* dst = reinterpret_cast<float4*>(out + (long)m * W * W * 64);
+  float4 v[NIT];
 #pragma unroll
-  for (int r = 0; r < NP; ++r) p[r] = r < WW ? q0 * f1[r] : 0.f;
-  const float sim0 = transpose_reduce<NP>(p, lane);
+  for (int it = 0; it < NIT; ++it) {
+    const int k = it * 64 + lane;
+    const int wy = k / ROW16, within = k - wy * ROW16;
+    const int y = oy + wy, x = ox + (within >> 4);
+    const bool ok = k < TOTAL16 && y >= 0 && y < Hf && x >= 0 && x < Wf;
+    // (clamped address + select: no load behind a branch)
+    const float4 t = src[ok ? ((long)y * Wf + x) * 16 + (within & 15) : 0];
+    v[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
-  for (int r = 0; r < NP; ++r) p[r] = r < WW ? q1 * f0[r] : 0.f;
-  const float sim1 = transpose_reduce<NP>(p, lane);
+  for (int it = 0; it < NIT; ++it) {
+    const int k = it * 64 + lane;
+    if (k < TOTAL16) dst[k] = v[it];
+  }
+}
 
-  const int pos = tr_index<NP>(lane);
-  const bool on = pos < WW && lane < NP;
-  soft_argmax<W>(sim0, pos, on, lane, inv_sqrt_c, scale_f, kc0[m * 2], kc0[m * 2 + 1], out0 + (long)m * 3);
-  soft_argmax<W>(sim1, pos, on, lane, inv_sqrt_c, scale_f, kc1[m * 2], kc1[m * 2 + 1], out1 + (long)m * 3);
+template <int W>
+__global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map0, const float* __restrict__ map1, int Hf0,
+                                                   int Wf0, int Hf1, int Wf1, int stride, int pad, int w0c, int w1c,
+                                                   const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
+                                                   const int64_t* __restrict__ j_ids, const int32_t* __restrict__ d_count,
+                                                   int m_max, const float* __restrict__ mix0, const float* __restrict__ mix1,
+                                                   const float* __restrict__ kc0, const float* __restrict__ kc1, float scale_f,
+                                                   float* __restrict__ out0, float* __restrict__ out1) {
+  constexpr int WW = W * W;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int M = d_count ? min(d_count[0], m_max) : m_max;
+  const int per = (M + 7) >> 3;
+  const int slot = (int)(blockIdx.x >> 3) * 4 + wv;
+  const int m = (blockIdx.x & 7) * per + slot;
+  if (slot >= per || m >= M) return;
+  const int b = __builtin_amdgcn_readfirstlane((int)b_ids[m]);
+  const int i = __builtin_amdgcn_readfirstlane((int)i_ids[m]);
+  const int j = __builtin_amdgcn_readfirstlane((int)j_ids[m]);
+  const int cy0 = i / w0c, cy1 = j / w1c;
+  const int oy0 = cy0 * stride - pad, ox0 = (i - cy0 * w0c) * stride - pad;
+  const int oy1 = cy1 * stride - pad, ox1 = (j - cy1 * w1c) * stride - pad;
+  // One buffer descriptor per window ROW (base = that row of the map, size = one map row, or 0 bytes for a row above /
+  // below the map), one vector offset per window COLUMN (pixel x, this lane's channel; a negative x gets an offset
+  // beyond any row): the unfold's zero padding on all four sides then comes from the hardware's range check - no
+  // per-position conditions, ~10 scalar instructions per window row instead of ~12 per window position.
+  const float* base0 = map0 + (long)b * Hf0 * Wf0 * 64;
+  const float* base1 = map1 + (long)b * Hf1 * Wf1 * 64;
+  unsigned vo0[W], vo1[W];
+#pragma unroll
+  for (int wx = 0; wx < W; ++wx) {
+    const int x0 = ox0 + wx, x1 = ox1 + wx;
+    vo0[wx] = x0 >= 0 ? (unsigned)(x0 * 256 + lane * 4) : 0x80000000u;
+    vo1[wx] = x1 >= 0 ? (unsigned)(x1 * 256 + lane * 4) : 0x80000000u;
+  }
+  float f0[WW], f1[WW];
+#pragma unroll
+  for (int wy = 0; wy < W; ++wy) {
+    const int y0 = oy0 + wy, y1 = oy1 + wy;
+    const bool ok0 = y0 >= 0 && y0 < Hf0, ok1 = y1 >= 0 && y1 < Hf1;          // wave-uniform
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(base0 + (long)(ok0 ? y0 : 0) * Wf0 * 64), 0, ok0 ? Wf0 * 256 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(base1 + (long)(ok1 ? y1 : 0) * Wf1 * 64), 0, ok1 ? Wf1 * 256 : 0, 0x00020000);
+#pragma unroll
+    for (int wx = 0; wx < W; ++wx) {
+      f0[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, vo0[wx], 0, 0));
+      f1[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, vo1[wx], 0, 0));
+    }
+  }
+  fine_core<W>(f0, f1, lane, mix0, mix1, kc0[m * 2], kc0[m * 2 + 1], kc1[m * 2], kc1[m * 2 + 1], scale_f,
+               out0 + (long)m * 3, out1 + (long)m * 3);
+}
+
+// [N, 64, Hf, Wf] -> [N, Hf, Wf, 64]: one workgroup per (sample, row y, 64 pixels of the row); reads 64 channel
+// segments of 256 bytes (16-byte loads along x), writes one contiguous 16 KiB block; the transpose goes through an
+// LDS tile with an odd pitch.  grid (ceil(Wf / 64), Hf, N).
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const float* __restrict__ src, float* __restrict__ dst, int Hf, int Wf) {
+  __shared__ float tile[64 * 65];              // [x][c], pitch 65
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 64, y = blockIdx.y, b = blockIdx.z;
+  const float* in = src + ((long)b * 64 * Hf + y) * Wf + x0;      // + c * Hf * Wf
+  const long plane = (long)Hf * Wf;
+  const int nx = min(64, Wf - x0);
+  const bool vec = (Wf & 3) == 0;              // 16-byte aligned rows
+  float4 v[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {                // channel c = 16 p + tid / 16, pixels 4 (tid % 16) .. + 3
+    const int c = 16 * p + (tid >> 4), xq = (tid & 15) * 4;
+    const float* row = in + c * plane;
+    if (vec && xq + 3 < nx) v[p] = *reinterpret_cast<const float4*>(row + xq);
+    else v[p] = make_float4(xq < nx ? row[xq] : 0.f, xq + 1 < nx ? row[xq + 1] : 0.f, xq + 2 < nx ? row[xq + 2] : 0.f,
+                            xq + 3 < nx ? row[xq + 3] : 0.f);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = 16 * p + (tid >> 4), xq = (tid & 15) * 4;
+    tile[(xq + 0) * 65 + c] = v[p].x; tile[(xq + 1) * 65 + c] = v[p].y;
+    tile[(xq + 2) * 65 + c] = v[p].z; tile[(xq + 3) * 65 + c] = v[p].w;
+  }
+  __syncthreads();
+  float4* out = reinterpret_cast<float4*>(dst + (((long)b * Hf + y) * Wf + x0) * 64);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {                // pixel x = 16 p + tid / 16, channels 4 (tid % 16) .. + 3
+    const int x = 16 * p + (tid >> 4), c4 = (tid & 15) * 4;
+    if (x < nx)
+      out[x * 16 + (tid & 15)] = make_float4(tile[x * 65 + c4], tile[x * 65 + c4 + 1], tile[x * 65 + c4 + 2], tile[x * 65 + c4 + 3]);
+  }
 }
 
 }  // namespace fm
@@ -521,6 +673,13 @@ extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int
     if (smem > 64 * 1024) return FM_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_gather_nchw, dim3(m_max), dim3(256), smem, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c,
                        b_ids, ids, d_count, m_max, out);
+  } else if (Cf == 64 && (W == 5 || W == 7)) {      // channels-last fast path: one wave per window, 16-byte chunks
+    if (W == 5)
+      hipLaunchKernelGGL(k_gather_nhwc64<5>, dim3(list_blocks(m_max)), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
+                         b_ids, ids, d_count, m_max, out);
+    else
+      hipLaunchKernelGGL(k_gather_nhwc64<7>, dim3(list_blocks(m_max)), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
+                         b_ids, ids, d_count, m_max, out);
   } else {
     hipLaunchKernelGGL(k_gather_nhwc, dim3(m_max), dim3(256), 0, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c, b_ids,
                        ids, d_count, m_max, out);
@@ -637,5 +796,47 @@ extern "C" int fm_fine_match(const float* win0, const float* win1, int m_max, co
   else
     hipLaunchKernelGGL(k_fine<5>, dim3(blocks), dim3(256), 0, st, win0, win1, m_max, d_count, mix0, mix1, mkpts0_c,
                        mkpts1_c, scale_f, out0, out1);
+  return (int)hipGetLastError();
+}
+
+// the fine maps of one sample must be addressable with 31-bit byte offsets (buffer descriptor)
+static bool maps64_ok(int Cf, int Hf, int Wf, int W) {
+  return Cf == 64 && (W == 5 || W == 7) && (long)Hf * Wf * 256 < (1L << 31);
+}
+
+extern "C" size_t fm_fine_maps_scratch_bytes(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout) {
+  if (layout != 0 || N <= 0 || Cf <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0) return 0;
+  return (size_t)N * Cf * 4 * ((size_t)Hf0 * Wf0 + (size_t)Hf1 * Wf1);
+}
+
+extern "C" int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, int layout, int N, int Cf, int Hf0, int Wf0,
+                                  int Hf1, int Wf1, int W, int stride, int pad, int w0c, int w1c, const int64_t* b_ids,
+                                  const int64_t* i_ids, const int64_t* j_ids, const int32_t* d_count, int m_max,
+                                  const float* mix0, const float* mix1, const float* mkpts0_c, const float* mkpts1_c,
+                                  float scale_f, void* scratch, float* out0, float* out1, void* stream) {
+  if (m_max == 0) return FM_OK;
+  if (!feat_f0 || !feat_f1 || !b_ids || !i_ids || !j_ids || !mix0 || !mix1 || !mkpts0_c || !mkpts1_c || !out0 || !out1)
+    return FM_E_NULL;
+  if (N <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0 || stride <= 0 || w0c <= 0 || w1c <= 0 || m_max < 0)
+    return FM_E_SHAPE;
+  if ((layout != 0 && layout != 1) || !maps64_ok(Cf, Hf0, Wf0, W) || !maps64_ok(Cf, Hf1, Wf1, W)) return FM_E_UNSUPPORTED;
+  if (layout == 0 && !scratch) return FM_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const float* m0 = feat_f0;
+  const float* m1 = feat_f1;
+  if (layout == 0) {       // NCHW: channels-last copies first (coalesced on both sides)
+    float* s0 = (float*)scratch;
+    float* s1 = s0 + (size_t)N * 64 * Hf0 * Wf0;
+    hipLaunchKernelGGL(k_nchw_to_nhwc64, dim3((Wf0 + 63) / 64, Hf0, N), dim3(256), 0, st, feat_f0, s0, Hf0, Wf0);
+    hipLaunchKernelGGL(k_nchw_to_nhwc64, dim3((Wf1 + 63) / 64, Hf1, N), dim3(256), 0, st, feat_f1, s1, Hf1, Wf1);
+    m0 = s0; m1 = s1;
+  }
+  const int blocks = list_blocks(m_max);
+  if (W == 5)
+    hipLaunchKernelGGL(k_fine_maps<5>, dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, w0c, w1c,
+                       b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1);
+  else
+    hipLaunchKernelGGL(k_fine_maps<7>, dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, w0c, w1c,
+                       b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1);
   return (int)hipGetLastError();
 }

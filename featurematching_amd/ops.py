@@ -361,6 +361,51 @@ def fine_match(win0: torch.Tensor, win1: torch.Tensor, mix0: torch.Tensor, mix1:
     return out0, out1
 
 
+def _map_layout(t: torch.Tensor):
+    """(tensor, layout) of a logical [N,Cf,Hf,Wf] fine map: 0 = NCHW-contiguous, 1 = channels-last storage"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.is_contiguous():
+        return t, 0
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return t, 1
+    return t.contiguous(), 0
+
+
+def fine_match_maps(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, j_ids, w: int, stride: int, w0c: int,
+                    w1c: int, mix0: torch.Tensor, mix1: torch.Tensor, mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor,
+                    scale_f: float, pad: int = 2, count: Optional[torch.Tensor] = None,
+                    scratch: Optional[torch.Tensor] = None):
+    """Window crop + fine stage from the maps in one call (fm_fine_match_maps; fine_preprocess.py:43-50 with plain
+    windows + fine_matching_new.py:50-79): no window tensors.  Channels-last maps are read in place; NCHW maps are
+    first copied to channels-last storage in `scratch` (allocated when not given).  Returns (mkpts0_f, mkpts1_f)."""
+    lib = _lib.load()
+    if not feat_f0.is_cuda:
+        raise RuntimeError("feat_f0 must live on the GPU: the HIP path has no CPU fallback")
+    f0, lay0 = _map_layout(feat_f0)
+    f1, lay1 = _map_layout(feat_f1)
+    if lay0 != lay1:                                 # one layout per call
+        f1, lay1 = (f1.contiguous(), 0) if lay0 == 0 else (f1.contiguous(memory_format=torch.channels_last), 1)
+    n, cf, hf0, wf0 = f0.shape
+    hf1, wf1 = f1.shape[2:]
+    dev = f0.device
+    m_max = int(b_ids.shape[0])
+    out0 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
+    out1 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
+    if m_max == 0:
+        return out0, out1
+    need = int(lib.fm_fine_maps_scratch_bytes(n, cf, hf0, wf0, hf1, wf1, lay0))
+    if need and (scratch is None or scratch.numel() * scratch.element_size() < need):
+        scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    st = lib.fm_fine_match_maps(_ptr(f0), _ptr(f1), lay0, n, cf, hf0, wf0, hf1, wf1, w, stride, pad, int(w0c), int(w1c),
+                                _ptr(b_ids), _ptr(i_ids), _ptr(j_ids), _ptr(count), m_max, _ptr(_f32c(mix0, "mix0")),
+                                _ptr(_f32c(mix1, "mix1")), _ptr(_f32c(mkpts0_c, "mkpts0_c")), _ptr(_f32c(mkpts1_c, "mkpts1_c")),
+                                float(scale_f), _ptr(scratch) if need else None, _ptr(out0), _ptr(out1), _stream(dev))
+    _lib.check(st, "fm_fine_match_maps")
+    out0._keep = (f0, f1, scratch)
+    return out0, out1
+
+
 _TF_NAMES = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight",
              "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
 

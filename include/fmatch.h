@@ -159,7 +159,9 @@ int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, void* stream)
  * Window crop (fine_preprocess.py:43-50): out[m, wy*W+wx, c] =
  * feat_f[b_ids[m], c, stride*y - pad + wy, stride*x - pad + wx] (0 outside the
  * map) with (y,x) = divmod(ids[m], w_c).  layout 0 = NCHW contiguous (the
- * reference's), 1 = NHWC (channels-last storage of the same tensor).
+ * reference's), 1 = NHWC (channels-last storage of the same tensor; with Cf = 64 and
+ * W in {5,7} a copy in 16-byte chunks, one wave per window: a window row is W*256
+ * contiguous bytes there).
  * The number of windows is min(*d_count, m_max) when d_count != NULL (device
  * side, no host sync), else m_max.  out [m_max, W*W, Cf] float32.
  */
@@ -230,6 +232,24 @@ int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t
                   int WW, int Cf, const float* mix0, const float* mix1,
                   const float* mkpts0_c, const float* mkpts1_c, float scale_f,
                   float* out0, float* out1, void* stream);
+
+/*
+ * Window crop + fine stage in one call, straight from the fine maps (fine_preprocess.py:43-50 with the plain
+ * windows, then fine_matching_new.py:50-79): for callers without fine-level context layers between the two.  The
+ * window tensors never exist: with channels-last maps (layout 1: [N,Hf,Wf,64] storage - a window row is W*256
+ * contiguous bytes) every window position of both images is one coalesced 256-byte load of the kernel that does
+ * the arithmetic of fm_fine_match.  layout 0 (NCHW, the reference's) first makes channels-last copies of both maps
+ * in `scratch` (fm_fine_maps_scratch_bytes bytes [dev], 16-byte aligned; 0 bytes / NULL for layout 1) with a
+ * tiled transpose.  b_ids / i_ids / j_ids, d_count, mkpts*_c as the coarse stage left them; mix0 / mix1, scale_f,
+ * out0 / out1 as in fm_fine_match.  Cf = 64, W in {5,7}.  Results equal fm_gather_windows + fm_fine_match bit for bit.
+ */
+size_t fm_fine_maps_scratch_bytes(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout);
+int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, int layout, int N, int Cf, int Hf0, int Wf0,
+                       int Hf1, int Wf1, int W, int stride, int pad, int w0c, int w1c,
+                       const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids,
+                       const int32_t* d_count, int m_max, const float* mix0, const float* mix1,
+                       const float* mkpts0_c, const float* mkpts1_c, float scale_f,
+                       void* scratch, float* out0, float* out1, void* stream);
 
 /*
  * Coarse-level context layers in front of the coarse matching (network/net.py:74): the reference's

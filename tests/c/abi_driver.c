@@ -38,6 +38,8 @@ static __typeof__(fm_debug_launch_corr)* p_fm_debug_launch_corr;
 static __typeof__(fm_debug_launch_sum_sparse)* p_fm_debug_launch_sum_sparse;
 static __typeof__(fm_debug_launch_prep_f16)* p_fm_debug_launch_prep_f16;
 static __typeof__(fm_debug_launch_prep)* p_fm_debug_launch_prep;
+static __typeof__(fm_fine_match_maps)* p_fm_fine_match_maps;
+static __typeof__(fm_fine_maps_scratch_bytes)* p_fm_fine_maps_scratch_bytes;
 static __typeof__(fm_debug_reset_counters)* p_fm_debug_reset_counters;
 static __typeof__(fm_coarse_tf_packed_bytes)* p_fm_coarse_tf_packed_bytes;
 static __typeof__(fm_coarse_tf_workspace_bytes)* p_fm_coarse_tf_workspace_bytes;
@@ -59,7 +61,7 @@ int main(int argc, char** argv) {
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes); RESOLVE(fm_coarse_workspace_bytes_mode);
   RESOLVE(fm_coarse_match); RESOLVE(fm_coarse_match_dtype); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
-  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
+  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_fine_match_maps); RESOLVE(fm_fine_maps_scratch_bytes); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
@@ -183,6 +185,16 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_fine_match(NULL, NULL, 0, NULL, 49, 64, NULL, NULL, NULL, NULL, 2.f, NULL, NULL, NULL), FM_OK);
   EXPECT(p_fm_fine_match(NULL, f, 3, NULL, 49, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_NULL);
   EXPECT(p_fm_fine_match(f, f, -3, NULL, 49, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_SHAPE);
+  /* crop + fine from the maps */
+  EXPECT(p_fm_fine_maps_scratch_bytes(2, 64, 240, 320, 240, 320, 0) == (size_t)2 * 64 * 4 * 2 * 240 * 320, 1);
+  EXPECT(p_fm_fine_maps_scratch_bytes(2, 64, 240, 320, 240, 320, 1) == 0, 1);
+  EXPECT(p_fm_fine_match_maps(NULL, NULL, 0, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, NULL, NULL, NULL, NULL, 0, NULL, NULL, NULL, NULL, 2.f, NULL, NULL, NULL, NULL), FM_OK);   /* M == 0 */
+  EXPECT(p_fm_fine_match_maps(f, NULL, 1, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_fine_match_maps(f, f, 0, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_NULL);      /* NCHW needs scratch */
+  EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 64, 32, 32, 32, 0, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 32, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 64, 32, 32, 32, 32, 9, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_fine_match_maps(f, f, 2, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_fine_match(f, f, 3, NULL, 36, 64, f, f, f, f, 2.f, f, f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_fine_match(f, f, 3, NULL, 49, 32, f, f, f, f, 2.f, f, f, NULL), FM_E_UNSUPPORTED);
 

@@ -272,6 +272,46 @@ def test_fine_match_vs_oracle(w):
     assert (g1.cpu() - r1).abs().max().item() <= FINE_TOL_PX
 
 
+@pytest.mark.parametrize("w", [5, 7])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_fine_match_from_the_maps(w, channels_last):
+    """fm_fine_match_maps (crop + fine in one call, no window tensors; channels-last maps read in place, NCHW maps
+    through the tiled transpose) against the oracle's crop + fine (<= 1e-3 px) and against fm_gather_windows +
+    fm_fine_match bit for bit.  Rectangular maps of different sizes whose widths (52, 40) are not multiples of the
+    transpose's 64-pixel tile, cells on every border (zero padding on all four sides), N = 2."""
+    n, (h0c, w0c), (h1c, w1c) = 2, (9, 13), (11, 10)
+    ff0 = np.stack([synth.normal(171 + b, 1, (64, h0c * 4, w0c * 4)) for b in range(n)])
+    ff1 = np.stack([synth.normal(171 + b, 2, (64, h1c * 4, w1c * 4)) for b in range(n)])
+    m = 160
+    b = np.sort((synth.uniform(171, 3, m) * n).astype(np.int64))
+    i = (synth.uniform(171, 4, m) * h0c * w0c).astype(np.int64)
+    j = (synth.uniform(171, 5, m) * h1c * w1c).astype(np.int64)
+    i[:6] = [0, w0c - 1, (h0c - 1) * w0c, h0c * w0c - 1, 5, (h0c // 2) * w0c]           # corners and edges
+    j[:6] = [h1c * w1c - 1, 0, w1c - 1, (h1c - 1) * w1c, (h1c // 2) * w1c + w1c - 1, 3]
+    w0, b0, w1, b1 = synth.mix_weights(171, w * w)
+    kc0 = np.stack([(i % w0c) * 8.0, (i // w0c) * 8.0], 1).astype(np.float32)
+    kc1 = np.stack([(j % w1c) * 8.0, (j // w1c) * 8.0], 1).astype(np.float32)
+    bt, it, jt = torch.as_tensor(b), torch.as_tensor(i), torch.as_tensor(j)
+    r0, r1 = orc.fine_match(orc.crop_windows(ff0, bt, it, w, 4, w0c), orc.crop_windows(ff1, bt, jt, w, 4, w1c),
+                            w0, b0, w1, b1, kc0, kc1, 2.0)
+    t0, t1 = torch.as_tensor(ff0, device=DEV), torch.as_tensor(ff1, device=DEV)
+    if channels_last:
+        t0, t1 = t0.contiguous(memory_format=torch.channels_last), t1.contiguous(memory_format=torch.channels_last)
+    mix0 = torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=DEV)
+    mix1 = torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=DEV)
+    bd, idv, jd = bt.to(DEV), it.to(DEV), jt.to(DEV)
+    k0d, k1d = torch.as_tensor(kc0, device=DEV), torch.as_tensor(kc1, device=DEV)
+    cnt = torch.tensor([m - 7, 0], dtype=torch.int32, device=DEV)                       # device-side count < capacity
+    g0, g1 = ops.fine_match_maps(t0, t1, bd, idv, jd, w, 4, w0c, w1c, mix0, mix1, k0d, k1d, 2.0, count=cnt)
+    assert (g0[:m - 7].cpu() - r0[:m - 7]).abs().max().item() <= FINE_TOL_PX
+    assert (g1[:m - 7].cpu() - r1[:m - 7]).abs().max().item() <= FINE_TOL_PX
+    win0 = ops.gather_windows(t0, bd, idv, w, 4, w0c)
+    win1 = ops.gather_windows(t1, bd, jd, w, 4, w1c)
+    assert torch.equal(win0.cpu(), orc.crop_windows(ff0, bt, it, w, 4, w0c))            # (the 16-byte-chunk crop is exact)
+    h0, h1 = ops.fine_match(win0, win1, mix0, mix1, k0d, k1d, 2.0)
+    assert torch.equal(g0[:m - 7], h0[:m - 7]) and torch.equal(g1[:m - 7], h1[:m - 7])
+
+
 # ------------------------------------------------------------------ drop-in modules
 def test_modules_follow_the_data_dict_protocol():
     g = load_golden("cfg1_peaky")
