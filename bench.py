@@ -492,12 +492,12 @@ def context_layer_times(wl, dev, iters=10):
         w0, w1 = m.fine_preprocess(ff0, ff1, x0, x1, d)
     t_f, _ = timed(lambda: m.fine(w0, w1))
     t_all, _ = timed(lambda: m.forward_features(fc0, fc1, ff0, ff1, dict(base)))
-    os.environ["FM_HIP_COARSE_TF"] = os.environ["FM_HIP_FINE_TF"] = "0"
+    m.coarse.use_hip = m.fine.use_hip = False           # the same modules through their torch ops
     try:
         t_c_t, _ = timed(lambda: m.coarse(x0, x1))
         t_f_t, _ = timed(lambda: m.fine(w0, w1))
     finally:
-        del os.environ["FM_HIP_COARSE_TF"], os.environ["FM_HIP_FINE_TF"]
+        m.coarse.use_hip = m.fine.use_hip = True
     nl = len(m.coarse.layer_names)
     flop_c = 2.0 * n * 2 * l * 655360 * nl
     mm = int(w0.shape[0])

@@ -18,6 +18,7 @@ FM_E_CAPACITY = -5
 FM_E_CANDIDATES = -6
 FM_E_RANGE = -7
 FM_E_DENSE = -8
+FM_DEV_RANGE = 4                                    # device status bit
 FM_MODE_EXACT_SCREENING, FM_MODE_DENSE = 1, 2      # `mode` bits of fm_coarse_match
 
 _lib = None
@@ -59,6 +60,7 @@ SIGNATURES = {
     "fm_fine_tf_packed_bytes": (C.c_size_t, []),
     "fm_fine_tf_pack_weights": (_i, [_p, _p, _p, _p]),
     "fm_fine_transformer": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),
+    "fm_fine_transformer_status": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
     "fm_epipolar_errors": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
     "fm_fine_maps_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),

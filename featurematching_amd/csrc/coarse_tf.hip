@@ -683,8 +683,8 @@ extern "C" int fm_coarse_tf_pack_weights(const float* const* const* layers, int 
   return (int)hipGetLastError();
 }
 
-// layer_kinds[l]: 0 = 'self', 1 = 'cross' (transformer.py:88-95).  out0 / out1 [N,L,256] / [N,S,256] must not alias
-// the inputs (the first layer reads feat*, every later one updates out* in place).
+// layer_kinds[l]: 0 = 'self', 1 = 'cross' (transformer.py:88-95).  out0 / out1 [N,L,256] / [N,S,256] must not overlap
+// the inputs or each other (the first layer reads feat*, every later one updates out* in place): FM_E_UNSUPPORTED.
 extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, int S, int C, int nhead,
                                      const int* layer_kinds, int n_layers, const void* packed, void* workspace,
                                      size_t workspace_bytes, float* out0, float* out1, void* stream) {
@@ -693,7 +693,16 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
   if (C != kD || nhead != kH || n_layers <= 0 || n_layers > kMaxLayers) return FM_E_UNSUPPORTED;
   for (int l = 0; l < n_layers; ++l)
     if (layer_kinds[l] != 0 && layer_kinds[l] != 1) return FM_E_UNSUPPORTED;
-  if (feat0 == out0 || feat1 == out1 || out0 == out1) return FM_E_UNSUPPORTED;
+  {   // no output may overlap an input or the other output: a 'self' layer updates both images in one launch and the
+      // first layer reads feat* while it writes out* (byte ranges, not just equal pointers)
+    const uintptr_t n0 = (uintptr_t)N * L * kD * 4, n1 = (uintptr_t)N * S * kD * 4;
+    auto overlap = [](const void* a, uintptr_t na, const void* b, uintptr_t nb) {
+      return (uintptr_t)a < (uintptr_t)b + nb && (uintptr_t)b < (uintptr_t)a + na;
+    };
+    if (overlap(out0, n0, out1, n1) || overlap(out0, n0, feat0, n0) || overlap(out0, n0, feat1, n1) ||
+        overlap(out1, n1, feat0, n0) || overlap(out1, n1, feat1, n1))
+      return FM_E_UNSUPPORTED;
+  }
   if (workspace_bytes < ws_floats(N, L, S) * 4 || ((uintptr_t)workspace & 15) || ((uintptr_t)packed & 15))
     return FM_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;

@@ -67,11 +67,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // x = hi + lo in float16 (round-toward-zero packs: the remainder x - hi is exact in float32, and the scheme only
 // needs hi + lo = x to 22 bits, not nearest rounding): 3 VALU operations per element.  The tile is ALREADY in the
 // operand scale (see above), so there is no multiply here.
-__device__ __forceinline__ void split8(const f32x16& a, int half, half8& hi, half8& lo) {
+// RANGE: the scales are fixed, so a value beyond float16 (|x| * kActScale > 65504: a window value, a projection or a
+// hidden-layer value above 255.9) would be clamped silently by the round-toward-zero pack.  `amax` follows the largest
+// magnitude that ever went into an operand (one v_max3 per pair of elements); the kernel reports FM_DEV_RANGE through
+// its status word when it exceeded the float16 range, and the caller falls back to float32 layers.
+__device__ __forceinline__ void split8(const f32x16& a, int half, half8& hi, half8& lo, float& amax) {
   u32x4 uh, ul;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const float x0 = a[8 * half + 2 * p], x1 = a[8 * half + 2 * p + 1];
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(x0), "v"(x1));
     const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h2[0], x1 - (float)h2[1]);
     uh[p] = __builtin_bit_cast(unsigned, h2);
@@ -129,11 +134,12 @@ struct KvState {
 };                        // normaliser's operand Kd is rebuilt from ksum in LDS where it is used)
 
 // Kd fragment of k-step s: row = head r (< 8), element j = sum_s K of feature d = 16 s + 8 (j>>2) + 4 h + (j&3) if in head r
-__device__ __forceinline__ void kd_fragment(const float* ksum_lds, int s, int r, int h, half8& dh, half8& dl) {
+__device__ __forceinline__ void kd_fragment(const float* ksum_lds, int s, int r, int h, half8& dh, half8& dl, float& amax) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int d = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
     const float val = (r == (d >> 3)) ? ksum_lds[d] * (kSumScale / kActScale) : 0.f;     // ksum_lds is in the operand scale
+    amax = fmaxf(amax, val);                  // sum_s (elu(k) + 1) of a head feature must stay below 65504 / kSumScale = 2047
     const _Float16 hh = (_Float16)val;
     dh[j] = hh;
     dl[j] = (_Float16)(val - (float)hh);
@@ -143,13 +149,13 @@ __device__ __forceinline__ void kd_fragment(const float* ksum_lds, int s, int r,
 // [OT x 32 tokens] = W . X^T for one slice: rows[i] = the i-th 32-feature row tile of the source
 template <int OT, int KS, int KSW>
 __device__ __forceinline__ void gemm_T1(f32x16 (&out)[OT], const f32x16* const (&rows)[KS / 2], const half8* wf,
-                                        const half8* wfl, int lane) {
+                                        const half8* wfl, int lane, float& amax) {
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot) zero(out[ot]);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     half8 bh, bl;
-    split8(*rows[s >> 1], s & 1, bh, bl);
+    split8(*rows[s >> 1], s & 1, bh, bl, amax);
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
       const int fi = (ot * KSW + s) * 64 + lane;
@@ -214,7 +220,7 @@ __device__ __forceinline__ void store_slice(const f32x16 (&x)[2], float* win, in
 
 // kv phase: region B holds [K hi 8 | V hi 8 | K lo 8 | V lo 8] fragments
 template <int WW>
-__device__ __forceinline__ void kv_phase(const float* src, const half8* lb, float* ksum_lds, KvState& st, int lane) {
+__device__ __forceinline__ void kv_phase(const float* src, const half8* lb, float* ksum_lds, KvState& st, int lane, float& amax) {
   constexpr int NCT = (WW + 31) / 32;
   const int r = lane & 31, h = lane >> 5;
   const half8 *wk = lb, *wv_ = lb + 8 * 64, *wkl = lb + 16 * 64, *wvl = lb + 24 * 64;
@@ -235,7 +241,7 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       half8 ah, al;
-      split8(x[s >> 1], s & 1, ah, al);
+      split8(x[s >> 1], s & 1, ah, al, amax);
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot) {
         const int fi = (ot * 4 + s) * 64 + lane;
@@ -258,8 +264,8 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         half8 ah, al, bh, bl;
-        split8(k[dt], s, ah, al);
-        split8(v[dt], s, bh, bl);
+        split8(k[dt], s, ah, al, amax);
+        split8(v[dt], s, bh, bl, amax);
         mma3(kv[dt], ah, al, bh, bl);
       }
   }
@@ -275,14 +281,14 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
     for (int g = 0; g < 16; ++g)            // keep d / 8 == v / 8 (rows d = (g&3) + 8 (g>>2) + 4 h, column v = r)
       kv[dt][g] = ((g >> 2) != (r >> 3)) ? 0.f : kv[dt][g] * (1.0f / kActScale);     // back to the operand scale
 #pragma unroll
-  for (int s = 0; s < 4; ++s) split8(kv[s >> 1], s & 1, st.ah[s], st.al[s]);
+  for (int s = 0; s < 4; ++s) split8(kv[s >> 1], s & 1, st.ah[s], st.al[s], amax);
 }
 
 // update phase: region A holds [Q 8 | M 8 | W2 16 hi, then the same lo], region B [W1 32 hi | 32 lo]
 template <int WW>
 __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool store, const KvState& st,
                                              const float* ksum_lds, const half8* la, const half8* lb,
-                                             const float* __restrict__ ln, int lane) {
+                                             const float* __restrict__ ln, int lane, float& amax) {
   constexpr int NCT = (WW + 31) / 32;
   const int r = lane & 31, h = lane >> 5;
   const half8 *lal = la + 32 * 64, *lbl = lb + 32 * 64;
@@ -294,7 +300,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
     f32x16 q[2];
     {
       const f32x16* const rows[2] = {&x[0], &x[1]};
-      gemm_T1<2, 4, 4>(q, rows, la, lal, lane);
+      gemm_T1<2, 4, 4>(q, rows, la, lal, lane, amax);
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -306,8 +312,8 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       half8 bh, bl, dh, dl;
-      split8(q[s >> 1], s & 1, bh, bl);
-      kd_fragment(ksum_lds, s, r, h, dh, dl);
+      split8(q[s >> 1], s & 1, bh, bl, amax);
+      kd_fragment(ksum_lds, s, r, h, dh, dl, amax);
       mma3(msg[s >> 1], st.ah[s], st.al[s], bh, bl);     // KV[dt] only reaches output rows v in tile dt
       mma3(den, dh, dl, bh, bl);
     }
@@ -332,7 +338,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
     f32x16 m1[2];
     {
       const f32x16* const rows[2] = {&msg[0], &msg[1]};
-      gemm_T1<2, 4, 4>(m1, rows, la + 8 * 64, lal + 8 * 64, lane);
+      gemm_T1<2, 4, 4>(m1, rows, la + 8 * 64, lal + 8 * 64, lane, amax);
     }
     layer_norm_T1(m1, ln, ln + 64, h);
     // MLP in two halves of the hidden layer (64 of its 128 features at a time: 32 registers instead of 64):
@@ -344,7 +350,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
       f32x16 hid[2];
       {
         const f32x16* const rows[4] = {&x[0], &x[1], &m1[0], &m1[1]};
-        gemm_T1<2, 8, 8>(hid, rows, lb + (2 * hf) * 8 * 64, lbl + (2 * hf) * 8 * 64, lane);
+        gemm_T1<2, 8, 8>(hid, rows, lb + (2 * hf) * 8 * 64, lbl + (2 * hf) * 8 * 64, lane, amax);
       }
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot)
@@ -353,7 +359,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
 #pragma unroll
       for (int s = 0; s < 4; ++s) {             // k-steps 4 hf .. 4 hf + 3 of the second MLP matrix
         half8 bh, bl;
-        split8(hid[s >> 1], s & 1, bh, bl);
+        split8(hid[s >> 1], s & 1, bh, bl, amax);
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {
           const int fi = (ot * 8 + 4 * hf + s) * 64 + lane;
@@ -383,7 +389,8 @@ __device__ __forceinline__ void stage_frags_n(char* dst, const half8* src, int n
 template <int WW, int NW>
 __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const float* win1, int m_max,
                                                       const int32_t* __restrict__ d_count, const half8* __restrict__ wpack,
-                                                      const float* __restrict__ lnp, float* out0, float* out1) {
+                                                      const float* __restrict__ lnp, float* out0, float* out1,
+                                                      const int32_t* __restrict__ pack_status, int32_t* d_status) {
   extern __shared__ __attribute__((aligned(16))) char lds[];      // region A (64 KiB), region B (64 KiB)
   __shared__ float ksum[NW][64];
   const int lane = threadIdx.x & 63;
@@ -403,6 +410,7 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
   const float* xin[4] = {win1 + off, win0 + off, out0 + off, out1 + off};
   float* xout[4] = {out1 + off, out0 + off, out0 + off, out1 + off};
   const float* src[4] = {win1 + off, win0 + off, out1 + off, out0 + off};
+  float amax = 0.f;                     // largest magnitude that went into a float16 operand (operand scale)
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
     const half8* wl = wpack + (c >> 1) * kTfLayerHalf8;
@@ -420,18 +428,23 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
     stage_frags_n<NW>(rb + 16 * 1024, wl + (kTfFrags + kTfFragK) * 64, 16, wv, lane);    // K, V lo
     stage_wait();
     KvState st;
-    kv_phase<WW>(src[c], lb, ksum[wv], st, lane);
+    kv_phase<WW>(src[c], lb, ksum[wv], st, lane, amax);
     __syncthreads();                    // every wave has read K, V: the first MLP matrix takes region B
     stage_frags_n<NW>(rb, wl + kTfFrag1 * 64, 32, wv, lane);
     stage_frags_n<NW>(rb + 32 * 1024, wl + (kTfFrags + kTfFrag1) * 64, 32, wv, lane);
     stage_wait();
-    update_phase<WW>(xin[c], xout[c], store, st, ksum[wv], la, lb, ln, lane);
+    update_phase<WW>(xin[c], xout[c], store, st, ksum[wv], la, lb, ln, lane, amax);
   }
+  // an operand left the float16 range (or is not finite), or a packed weight did (|w| >= 16): the results of this
+  // match are not trustworthy - report it instead of clamping silently
+  if (d_status && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(d_status, (int)FM_DEV_RANGE);
+  if (d_status && blockIdx.x == 0 && threadIdx.x == 0 && *pack_status) atomicOr(d_status, (int)FM_DEV_RANGE);
 }
 
 // One weight matrix W [OUT x IN] (row-major, nn.Linear.weight) -> operand fragments [out tile][k-step][lane] x 8 halves,
 // hi plane at dst, lo plane at dst + kTfFrags*64: element j of lane (r, h) = W[32 ot + r][16 s + 8 (j>>2) + 4 h + (j&3)]
-__global__ __launch_bounds__(256) void k_tf_pack(const float* __restrict__ w, int out_f, int in_f, half8* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_tf_pack(const float* __restrict__ w, int out_f, int in_f, half8* __restrict__ dst,
+                                                 int32_t* __restrict__ pack_status) {
   const int ks = in_f / 16;
   const int idx = blockIdx.x * 256 + threadIdx.x;      // (ot, s, lane)
   if (idx >= out_f / 32 * ks * 64) return;
@@ -441,6 +454,7 @@ __global__ __launch_bounds__(256) void k_tf_pack(const float* __restrict__ w, in
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float x = w[(long)(32 * ot + r) * in_f + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)] * kWgtScale;
+    if (!(fabsf(x) <= 65504.f)) *pack_status = 1;        // |w| >= 16 (or not finite): beyond the fixed weight scale
     const _Float16 hh = (_Float16)x;
     hi[j] = hh;
     lo[j] = (_Float16)(x - (float)hh);
@@ -452,12 +466,16 @@ __global__ __launch_bounds__(256) void k_tf_pack(const float* __restrict__ w, in
 __global__ void k_tf_scale_copy(const float* __restrict__ src, float* __restrict__ dst, float scale) {
   dst[threadIdx.x] = src[threadIdx.x] * scale;
 }
+__global__ void k_tf_clear_status(int32_t* st) { st[threadIdx.x] = 0; }
 
 }  // namespace fm
 
 using namespace fm;
 
-extern "C" size_t fm_fine_tf_packed_bytes(void) { return 2 * ((size_t)kTfLayerHalf8 * 16 + kTfLayerFloats * 4); }
+// fragments of both layers, LayerNorm terms of both layers, then 16 bytes of pack status (word 0 != 0: a weight lies
+// outside the fixed weight scale)
+constexpr size_t kTfPackStatusOff = 2 * ((size_t)kTfLayerHalf8 * 16 + kTfLayerFloats * 4);
+extern "C" size_t fm_fine_tf_packed_bytes(void) { return kTfPackStatusOff + 16; }
 
 // layer_weights[l] for l = 0 ('self'), 1 ('cross'): pointers to q_proj, k_proj, v_proj, merge [64,64], mlp.0 [128,128],
 // mlp.2 [64,128], norm1.weight, norm1.bias, norm2.weight, norm2.bias [64]  (10 device pointers per layer)
@@ -468,6 +486,8 @@ extern "C" int fm_fine_tf_pack_weights(const float* const* layer0, const float* 
   hipStream_t st = (hipStream_t)stream;
   half8* frag = (half8*)packed;
   float* ln = (float*)((char*)packed + 2 * (size_t)kTfLayerHalf8 * 16);
+  int32_t* pstat = (int32_t*)((char*)packed + kTfPackStatusOff);
+  hipLaunchKernelGGL(k_tf_clear_status, dim3(1), dim3(4), 0, st, pstat);
   const int base[6] = {kTfFragQ, kTfFragK, kTfFragV, kTfFragM, kTfFrag1, kTfFrag2};
   const int outf[6] = {64, 64, 64, 64, 128, 64}, inf[6] = {64, 64, 64, 64, 128, 128};
   for (int l = 0; l < 2; ++l) {
@@ -475,7 +495,7 @@ extern "C" int fm_fine_tf_pack_weights(const float* const* layer0, const float* 
     for (int i = 0; i < 6; ++i) {
       const int n = outf[i] / 32 * (inf[i] / 16) * 64;
       hipLaunchKernelGGL(k_tf_pack, dim3((n + 255) / 256), dim3(256), 0, st, w[i], outf[i], inf[i],
-                         frag + (size_t)l * kTfLayerHalf8 + base[i] * 64);
+                         frag + (size_t)l * kTfLayerHalf8 + base[i] * 64, pstat);
     }
     for (int i = 0; i < 4; ++i)        // gamma and beta pre-multiplied by the operand scale
       hipLaunchKernelGGL(k_tf_scale_copy, dim3(1), dim3(64), 0, st, w[6 + i], ln + l * kTfLayerFloats + 64 * i, kActScale);
@@ -483,14 +503,16 @@ extern "C" int fm_fine_tf_pack_weights(const float* const* layer0, const float* 
   return (int)hipGetLastError();
 }
 
-extern "C" int fm_fine_transformer(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
-                                   const void* packed, float* out0, float* out1, void* stream) {
+extern "C" int fm_fine_transformer_status(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW,
+                                          int Cf, const void* packed, float* out0, float* out1, int32_t* d_status,
+                                          void* stream) {
   if (m_max == 0) return FM_OK;
   if (!win0 || !win1 || !packed || !out0 || !out1) return FM_E_NULL;
   if (m_max < 0) return FM_E_SHAPE;
   if (Cf != 64 || (WW != 25 && WW != 49)) return FM_E_UNSUPPORTED;
   const half8* frag = (const half8*)packed;
   const float* ln = (const float*)((const char*)packed + 2 * (size_t)kTfLayerHalf8 * 16);
+  const int32_t* pstat = (const int32_t*)((const char*)packed + kTfPackStatusOff);
   hipStream_t st = (hipStream_t)stream;
   constexpr int NW = 8;               // matches (waves) per workgroup: two waves per SIMD share the staged weights
   const int blocks = (m_max + NW - 1) / NW;
@@ -499,11 +521,16 @@ extern "C" int fm_fine_transformer(const float* win0, const float* win1, int m_m
   if (WW == 49) {
     hipError_t e = ensure_dynamic_lds(&k_fine_tf<49, NW>, smem, &set49);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_fine_tf<49, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1);
+    hipLaunchKernelGGL((k_fine_tf<49, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1, pstat, d_status);
   } else {
     hipError_t e = ensure_dynamic_lds(&k_fine_tf<25, NW>, smem, &set25);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_fine_tf<25, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1);
+    hipLaunchKernelGGL((k_fine_tf<25, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1, pstat, d_status);
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int fm_fine_transformer(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
+                                   const void* packed, float* out0, float* out1, void* stream) {
+  return fm_fine_transformer_status(win0, win1, m_max, d_count, WW, Cf, packed, out0, out1, nullptr, stream);
 }

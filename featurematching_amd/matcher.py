@@ -8,8 +8,8 @@ on PyTorch-ROCm"); `SmallFPN` is a plain torch stand-in with the reference's res
 seeded-random weights.  No checkpoint of the reference exists, so there is no parity claim for it.
 Everything after the backbone follows network/net.py:66-83 step by step - coarse context layers, coarse matching,
 window crop + context merge, fine context layers, fine matching (`Matcher.forward_features`) - and is checked
-against a fixture produced by the reference's own modules (tests: net_tail_small).  The context layers run on
-PyTorch-ROCm (transformer.py); the three matching stages are the HIP kernels.
+against a fixture produced by the reference's own modules (tests: net_tail_small).  In eval mode all five stages are
+HIP kernels (the context layers too: transformer.py keeps the torch ops as the trainable definition).
 """
 from __future__ import annotations
 
@@ -76,8 +76,25 @@ class Matcher(nn.Module):
         self.fine = LocalFeatureTransformer(cfg['fine'])
         self.fine_matching = FineMatching(cfg['fine'], window=cfg['fine_window_size'])
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """network/net.py:94-102: checkpoints of the reference's Lightning module carry a `matcher.` prefix (and older
+        ones `loftr_`); both are stripped.  The reference's sinusoidal position tables (`*.pos_encoding.pe`, dead in
+        its forward: net.py:67-68, fine_matching_new.py:20) are dropped if a checkpoint carries them."""
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith('matcher.'):
+                k = k.replace('matcher.', '', 1)
+            if k.startswith('loftr_'):
+                k = k.replace('loftr_', '', 1)
+            if k == 'pos_encoding.pe' or k.endswith('.pos_encoding.pe'):
+                continue
+            sd[k] = v
+        return super().load_state_dict(sd, *args, **kwargs)
+
     @torch.no_grad()
     def forward(self, data):
+        """network/net.py:40-92; results are written into `data` (returned as well, for convenience: the reference
+        returns None)"""
         data.update({'bs': data['image0'].size(0),
                      'hw0_i': data['image0'].shape[2:], 'hw1_i': data['image1'].shape[2:]})
         feats_c, feats_f = self.backbone(torch.cat([data['image0'], data['image1']], dim=0))

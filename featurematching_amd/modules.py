@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import logging
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -102,9 +101,13 @@ class CoarseMatching(nn.Module):
 
 
 class FinePreprocess(nn.Module):
-    def __init__(self, config):
+    """fused_merge=False keeps crop and context merge apart in eval mode too, cell_ordered=False takes the list-ordered
+    crop kernel (tools that time one variant against the other; both default to the fast path)."""
+
+    def __init__(self, config, fused_merge: bool = True, cell_ordered: bool = True):
         super().__init__()
         self.config = config
+        self.fused_merge, self.cell_ordered = fused_merge, cell_ordered
         self.cat_c_feat = config['fine_concat_coarse_feat']
         self.W = config['fine_window_size']
         d_model_c = config['coarse']['d_model']
@@ -120,11 +123,12 @@ class FinePreprocess(nn.Module):
             if p.dim() > 1:
                 nn.init.kaiming_normal_(p, mode="fan_out", nonlinearity="relu")
 
-    def _fused_ok(self, feat_f0, feat_f1, W) -> bool:
-        """The fused crop+merge kernel serves eval mode (no autograd through the two Linear layers) on NCHW
-        maps with 64 fine channels and W in {5,7}; FM_FUSED_MERGE=0 forces the two-step path."""
-        return not self.training and self.d_model_f == 64 and W in (5, 7) and feat_f0.shape[1] == 64 \
-            and feat_f0.is_contiguous() and feat_f1.is_contiguous() and os.environ.get("FM_FUSED_MERGE", "1") != "0"
+    def _fused_ok(self, feat_f0, feat_f1, feat_c0, feat_c1, W) -> bool:
+        """The fused crop+merge kernel serves eval mode (no autograd through the two Linear layers: inputs that
+        require grad under grad mode take the torch layers) on NCHW maps with 64 fine channels and W in {5,7}."""
+        wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (feat_f0, feat_f1, feat_c0, feat_c1))
+        return self.fused_merge and not self.training and not wants_grad and self.d_model_f == 64 and W in (5, 7) \
+            and feat_f0.shape[1] == 64 and feat_f0.is_contiguous() and feat_f1.is_contiguous()
 
     def _merge_constants(self):
         """(packed W_w fragments, E = W_c . down_proj.weight [64, C], e = W_c . down_proj.bias + merge bias),
@@ -151,13 +155,13 @@ class FinePreprocess(nn.Module):
             return feat0, feat1
         # windows of the matched cells only (the reference unfolds all L cells, then selects)
         # Cell-ordered crop when the ids are this coarse call's own (its cell -> match maps are still in the
-        # workspace): every XCD then reads one band of the map; FM_GATHER=list forces the list-ordered kernel.
+        # workspace): every XCD then reads one band of the map.
         cells0 = cells1 = None
-        buf = data.get('_fm_coarse') if os.environ.get("FM_GATHER", "cells") != "list" else None
+        buf = data.get('_fm_coarse') if self.cell_ordered else None
         if buf is not None and buf.b_ids.data_ptr() == b_ids.data_ptr():     # ids are this coarse call's
             cells0, cells1 = buf.cell_maps()
         hw0_c, hw1_c = data['hw0_c'], data['hw1_c']
-        if self.cat_c_feat and self._fused_ok(feat_f0, feat_f1, W):
+        if self.cat_c_feat and self._fused_ok(feat_f0, feat_f1, feat_c0, feat_c1, W):
             # inference: crop + merge in one HIP kernel (fm_gather_merge_windows); the un-merged windows never
             # reach memory.  The position-independent half of merge_feat becomes a per-cell table (plain GEMMs).
             with torch.no_grad():

@@ -1,20 +1,20 @@
-"""Linear-attention context layers on PyTorch-ROCm - the layers either side of the matching hot path
+"""Linear-attention context layers - the layers either side of the matching hot path
 (network/net.py:74 coarse, :79-80 fine; network/module/transformer.py:34-57,78-96;
 network/module/attentions.py:19-46).
 
-In inference both of the reference's default configurations take fused HIP kernels: the FINE
-layers (d_model 64, 8 heads, ['self', 'cross'], windows of 25 or 49 tokens) fm_fine_transformer - one wave per
-match, 13x the PyTorch module at 640x480 - and the COARSE layers (d_model 256, 8 heads, any self / cross sequence,
-8 x [N,4800,256] in the reference) fm_coarse_transformer - three launches per encoder layer on the float32 matrix
-cores.  Training and every other configuration use the torch ops below.  Parameter names and shapes equal the reference's, so a reference
-state dict loads unchanged:
+In eval mode both of the reference's default configurations run as fused HIP kernels: the FINE
+layers (d_model 64, 8 heads, ['self', 'cross'], windows of 25 or 49 tokens) as fm_fine_transformer - one wave per
+match - and the COARSE layers (d_model 256, 8 heads, any self / cross sequence, 8 x [N,4800,256] in the reference)
+as fm_coarse_transformer - three launches per encoder layer, hi/lo-split float16 products on the matrix cores (22
+significant bits).  That holds under the reference's own inference call, `matcher.eval()(data)` with grad mode on
+(demo/demo.py:105-108).  The torch ops below are the trainable definition: training mode, inputs that require grad,
+other configurations, CPU tensors.  Parameter names and shapes equal the reference's, so a reference state dict
+loads unchanged:
 
     layers.<k>.{q_proj,k_proj,v_proj,merge}.weight [d,d]   layers.<k>.mlp.{0,2}.weight [2d,2d] / [d,2d]
     layers.<k>.{norm1,norm2}.{weight,bias} [d]
 """
 from __future__ import annotations
-
-import os
 
 import torch
 import torch.nn as nn
@@ -58,10 +58,15 @@ class EncoderLayer(nn.Module):
 
 class LocalFeatureTransformer(nn.Module):
     """Alternating self / cross layers over the two images' token sets (transformer.py:78-96).  config =
-    {'d_model', 'nhead', 'layer_names': ['self', 'cross', ...], 'attention': 'linear'}."""
+    {'d_model', 'nhead', 'layer_names': ['self', 'cross', ...], 'attention': 'linear'}.  use_hip=False keeps the torch ops
+    in eval mode too (tools that time one against the other).  The fine kernel works with fixed float16 operand scales
+    (|activation| < 255.9, see fmatch.h) and reports when an input left them: with check_range (default) the module
+    reads that report (one host sync per call) and redoes such a call with the float32 torch layers."""
 
-    def __init__(self, config):
+    def __init__(self, config, use_hip: bool = True, check_range: bool = True):
         super().__init__()
+        self.use_hip, self.check_range = use_hip, check_range
+        self.range_fallbacks = 0
         if config.get('attention', 'linear') != 'linear':
             raise NotImplementedError("only the reference's default linear attention is provided")
         self.d_model, self.layer_names = config['d_model'], list(config['layer_names'])
@@ -71,18 +76,19 @@ class LocalFeatureTransformer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def _hip_kind(self, feat0, feat1):
-        """Which fused HIP kernel serves this call (inference on float32 GPU tensors only): 'fine' =
-        fm_fine_transformer (d_model 64, 8 heads, ['self', 'cross'], windows of 25 or 49 tokens), 'coarse' =
-        fm_coarse_transformer (d_model 256, 8 heads, any self / cross sequence), None = the torch ops below.
-        FM_HIP_FINE_TF=0 / FM_HIP_COARSE_TF=0 force the torch ops."""
-        if self.training or torch.is_grad_enabled() or not feat0.is_cuda or feat0.dtype != torch.float32 \
+        """Which fused HIP kernel serves this call: 'fine' = fm_fine_transformer (d_model 64, 8 heads, ['self',
+        'cross'], windows of 25 or 49 tokens), 'coarse' = fm_coarse_transformer (d_model 256, 8 heads, any self /
+        cross sequence), None = the torch ops below.  Eval mode on float32 GPU tensors that do not ask for a gradient;
+        grad MODE alone does not matter (the reference's demo calls the eval-mode matcher without no_grad)."""
+        wants_grad = torch.is_grad_enabled() and (feat0.requires_grad or feat1.requires_grad)
+        if not self.use_hip or self.training or wants_grad or not feat0.is_cuda or feat0.dtype != torch.float32 \
                 or feat1.dtype != torch.float32 or self.layers[0].nhead != 8 or feat0.shape[0] != feat1.shape[0]:
             return None
         if self.d_model == 64 and self.layer_names == ['self', 'cross'] and feat0.shape == feat1.shape \
-                and feat0.shape[1] in (25, 49) and os.environ.get("FM_HIP_FINE_TF", "1") != "0":
+                and feat0.shape[1] in (25, 49):
             return 'fine'
         if self.d_model == 256 and all(k in ('self', 'cross') for k in self.layer_names) and feat0.shape[1] > 0 \
-                and feat1.shape[1] > 0 and os.environ.get("FM_HIP_COARSE_TF", "1") != "0":
+                and feat1.shape[1] > 0:
             return 'coarse'
         return None
 
@@ -99,14 +105,27 @@ class LocalFeatureTransformer(nn.Module):
             self._pack_key = key
         return self._pack_cache
 
-    def forward(self, feat0: torch.Tensor, feat1: torch.Tensor):
+    def forward(self, feat0: torch.Tensor, feat1: torch.Tensor, mask0=None, mask1=None):
+        """network/module/transformer.py:78 (`net.forward` passes mask0 = mask1 = None, net.py:73-74)"""
         assert feat0.shape[2] == self.d_model, "the feature number of src and transformer must be equal"
+        if mask0 is not None or mask1 is not None:
+            raise NotImplementedError("padding masks are not provided (the reference's net.forward passes None)")
         kind = self._hip_kind(feat0, feat1)
         if kind is not None:
             from . import ops
-            if kind == 'fine':
-                return ops.fine_transformer(feat0, feat1, self._packed(feat0.device, kind))
-            return ops.coarse_transformer(feat0, feat1, self._packed(feat0.device, kind), self.layer_names)
+            with torch.no_grad():
+                packed = self._packed(feat0.device, kind)
+                if kind == 'coarse':
+                    return ops.coarse_transformer(feat0, feat1, packed, self.layer_names)
+                status = torch.zeros(1, dtype=torch.int32, device=feat0.device) if self.check_range else None
+                out = ops.fine_transformer(feat0, feat1, packed, status=status)
+                if status is None or not (int(status.item()) & 4):       # FM_DEV_RANGE
+                    return out
+                self.range_fallbacks += 1          # values beyond the kernel's float16 operand scales: float32 layers
+                return self._torch_layers(feat0, feat1)
+        return self._torch_layers(feat0, feat1)
+
+    def _torch_layers(self, feat0, feat1):
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
                 feat0, feat1 = layer(feat0, feat0), layer(feat1, feat1)

@@ -281,15 +281,21 @@ int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, 
  * fm_fine_tf_pack_weights(layer0, layer1, ...): each a HOST array of 10 DEVICE pointers in state-dict order -
  * q_proj, k_proj, v_proj, merge .weight [64,64]; mlp.0.weight [128,128]; mlp.2.weight [64,128]; norm1.weight,
  * norm1.bias, norm2.weight, norm2.bias [64] - of layers.0 ('self') and layers.1 ('cross').
- * Operand scales are fixed (activations x 2^8, weights x 2^12 in float16): window values, their projections and the
- * MLP's hidden layer must stay below 255 in magnitude and weights below 16 (beyond that the result is inf / NaN, as
- * float16 overflow dictates; LayerNorm-ed activations of a trained network are O(1)).  fm_coarse_transformer has no such
- * limit (its scales follow the data).
+ * Operand scales are fixed (activations x 2^8, weights x 2^12, the per-head sums of elu(k)+1 x 2^5 in float16): window
+ * values, their projections and the MLP's hidden layer must stay below 255.9 in magnitude, weights below 16 and
+ * sum_s (elu(k)+1) of a head feature below 2047 (LayerNorm-ed activations of a trained network are O(1)).  The kernel
+ * FOLLOWS the largest magnitude that enters a float16 operand and fm_fine_tf_pack_weights the largest weight:
+ * fm_fine_transformer_status ORs FM_DEV_RANGE into *d_status ([dev] int32, zeroed by the caller) when a limit was
+ * exceeded for any match - the outputs are then not trustworthy and the caller must use float32 layers for this input
+ * (the Python module does).  fm_fine_transformer is the same call without the report.  fm_coarse_transformer has no
+ * such limit (its scales follow the data).
  */
 size_t fm_fine_tf_packed_bytes(void);
 int fm_fine_tf_pack_weights(const float* const* layer0, const float* const* layer1, void* packed, void* stream);
 int fm_fine_transformer(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
                         const void* packed, float* out0, float* out1, void* stream);
+int fm_fine_transformer_status(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
+                               const void* packed, float* out0, float* out1, int32_t* d_status, void* stream);
 
 /*
  * Match post-processing (the step after the path; utils/metrics.py:33-81): squared symmetric epipolar distance

@@ -215,13 +215,21 @@ int main(int argc, char** argv) {
     EXPECT(nb == (size_t)(150 + 151 + 2) * 8448 * 4 ? FM_OK : 1, FM_OK);
     EXPECT(p_fm_coarse_tf_pack_weights(NULL, 8, f, NULL), FM_E_NULL);
     EXPECT(p_fm_coarse_tf_pack_weights((const float* const* const*)f, 0, f, NULL), FM_E_UNSUPPORTED);
-    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, NULL, f, nb, f, g, NULL), FM_E_NULL);
-    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 0, 256, 8, kinds, 2, f, f, nb, g, g + 1, NULL), FM_E_SHAPE);
-    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 128, 8, kinds, 2, f, f, nb, g, g + 1, NULL), FM_E_UNSUPPORTED);
-    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 4, kinds, 2, f, f, nb, g, g + 1, NULL), FM_E_UNSUPPORTED);
-    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, bad_kind, 1, f, f, nb, g, g + 1, NULL), FM_E_UNSUPPORTED);
-    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, f, f, nb, (float*)f, g, NULL), FM_E_UNSUPPORTED);
-    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, f, f, 16, g, g + 1, NULL), FM_E_WORKSPACE);
+    /* outputs far from the inputs and from each other (never dereferenced): [1 MiB, +64 KiB) and [2 MiB, +64 KiB) */
+    float* o0 = (float*)(uintptr_t)(1u << 20);
+    float* o1 = (float*)(uintptr_t)(2u << 20);
+    (void)g;
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, NULL, f, nb, o0, o1, NULL), FM_E_NULL);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 0, 256, 8, kinds, 2, f, f, nb, o0, o1, NULL), FM_E_SHAPE);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 128, 8, kinds, 2, f, f, nb, o0, o1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 4, kinds, 2, f, f, nb, o0, o1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, bad_kind, 1, f, f, nb, o0, o1, NULL), FM_E_UNSUPPORTED);
+    /* aliasing: equal pointers, crossed pointers (feat0 == out1), partially overlapping ranges, overlapping outputs */
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, f, f, nb, (float*)f, o1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(o1, f, 1, 64, 64, 256, 8, kinds, 2, f, f, nb, o0, o1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, o0 + 100, 1, 64, 64, 256, 8, kinds, 2, f, f, nb, o0, o1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, f, f, nb, o0, o0 + 64 * 256 - 1, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_transformer(f, f, 1, 64, 64, 256, 8, kinds, 2, f, f, 16, o0, o1, NULL), FM_E_WORKSPACE);
   }
 
   printf("abi_driver: %d checks, %d failures\n", checks, failures);

@@ -634,7 +634,7 @@ def test_fused_crop_and_context_merge(name, dist):
                                        atol=1e-6 * float((pos * ch).sum()))
 
 
-def test_fine_preprocess_module_fused_equals_two_step(monkeypatch):
+def test_fine_preprocess_module_fused_equals_two_step():
     """modules.FinePreprocess in eval mode (fused HIP crop+merge) against its own two-step path (HIP crop, then
     the two nn.Linear layers), random weights, W = 7 with a tie-free cfg1 case."""
     g = load_golden("cfg1_peaky")
@@ -650,9 +650,9 @@ def test_fine_preprocess_module_fused_equals_two_step(monkeypatch):
     cm(fc0, fc1, data)
     with torch.no_grad():
         a0, a1 = fp(ff0, ff1, fc0, fc1, data)
-        monkeypatch.setenv("FM_FUSED_MERGE", "0")
+        fp.fused_merge = False
         b0, b1 = fp(ff0, ff1, fc0, fc1, data)
-        monkeypatch.delenv("FM_FUSED_MERGE")
+        fp.fused_merge = True
         with torch.no_grad():
             fp.merge_feat.bias.add_(1.0)            # an in-place weight update must invalidate the cached constants
         c0, _ = fp(ff0, ff1, fc0, fc1, data)
@@ -731,7 +731,8 @@ def test_fine_transformer_vs_oracle(w):
     e0 = (g0.cpu() - r0).abs().max().item()
     e1 = (g1.cpu() - r1).abs().max().item()
     assert e0 <= 2e-5 and e1 <= 2e-5, (e0, e1)
-    # the module takes the kernel by itself in inference, its torch ops otherwise
+    # the module takes the kernel by itself in eval mode - also under the reference's own inference call, which leaves
+    # grad mode on (demo/demo.py:105-108: matcher.eval()(data)) - and its torch ops when a gradient is asked for
     from featurematching_amd.transformer import LocalFeatureTransformer
     tf = LocalFeatureTransformer(dict(d_model=64, nhead=8, layer_names=['self', 'cross'], attention='linear')).to(DEV).eval()
     tf.load_state_dict({k: torch.as_tensor(v) for k, v in wts.items()})
@@ -739,8 +740,68 @@ def test_fine_transformer_vs_oracle(w):
     with torch.no_grad():
         a0, _ = tf(t0, t1)
     assert torch.equal(a0, g0)
-    b0, _ = tf(t0, t1)                       # grad mode: torch ops
-    assert not torch.equal(b0, g0) and (b0.detach() - g0).abs().max().item() <= 2e-5
+    assert torch.is_grad_enabled()
+    b0, _ = tf(t0, t1, None, None)           # grad mode on, eval, the reference's four-argument call: still the HIP kernel
+    assert torch.equal(b0, g0) and not b0.requires_grad
+    c0, _ = tf(t0.clone().requires_grad_(), t1)      # an input that wants a gradient: torch ops
+    assert c0.requires_grad and not torch.equal(c0, g0) and (c0.detach() - g0).abs().max().item() <= 2e-5
+    d0, _ = tf.train()(t0, t1)               # training mode: torch ops
+    assert d0.requires_grad and (d0.detach() - g0).abs().max().item() <= 2e-5
+    with pytest.raises(NotImplementedError):
+        tf.eval()(t0, t1, torch.ones(m, ww, dtype=torch.bool, device=DEV), None)
+
+
+@pytest.mark.parametrize("gain,expect_flag", [(1e-3, False), (8.0, False), (120.0, True), (300.0, True)])
+def test_fine_transformer_reports_values_beyond_its_operand_scales(gain, expect_flag):
+    """fm_fine_transformer works with fixed float16 operand scales (|activation| < 255.9, fmatch.h).  Inside them it
+    keeps float32-level accuracy at any magnitude; beyond them it must SAY so (FM_DEV_RANGE in the status word)
+    instead of clamping silently, and the module then answers with its float32 layers.  Window values of magnitude
+    `gain` x N(0,1): 8 -> |x| up to ~35 and projections up to ~60, inside the range; 120 and 300 leave it."""
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    ww, m = 49, 21
+    wts = synth.transformer_weights(77, 64, 2)
+    x0 = (gain * synth.normal(79, 1, (m, ww, 64))).astype(np.float32)
+    x1 = (gain * synth.normal(79, 2, (m, ww, 64))).astype(np.float32)
+    r0, r1 = orc.local_feature_transformer(x0, x1, wts, 8, ['self', 'cross'])
+    tw = {k: torch.as_tensor(v) for k, v in wts.items()}
+    packed = ops.pack_fine_transformer(tw, DEV)
+    t0, t1 = torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    g0, g1 = ops.fine_transformer(t0, t1, packed, status=status)
+    flagged = bool(int(status.item()) & _lib.FM_DEV_RANGE)
+    assert flagged == expect_flag, (gain, float(np.abs(x0).max()))
+    tol = 2e-5 * max(1.0, float(r0.abs().max()))
+    if not flagged:
+        assert torch.isfinite(g0).all() and torch.isfinite(g1).all()
+        assert (g0.cpu() - r0).abs().max().item() <= tol and (g1.cpu() - r1).abs().max().item() <= tol
+    tf = LocalFeatureTransformer(dict(d_model=64, nhead=8, layer_names=['self', 'cross'], attention='linear')).to(DEV).eval()
+    tf.load_state_dict(tw)
+    a0, a1 = tf(t0, t1)                       # the module: HIP kernel inside the range, float32 layers beyond it
+    assert tf.range_fallbacks == (1 if expect_flag else 0)
+    assert (a0.cpu() - r0).abs().max().item() <= tol and (a1.cpu() - r1).abs().max().item() <= tol
+
+
+def test_fine_transformer_reports_weights_and_sums_beyond_its_scales():
+    """The two other limits of the fixed scales: a weight of magnitude >= 16 (caught when the weights are packed) and
+    per-head sums of elu(k)+1 >= 2047 (caught where the sum becomes an operand)."""
+    ww, m = 49, 9
+    x0 = synth.normal(80, 1, (m, ww, 64)).astype(np.float32)
+    x1 = synth.normal(80, 2, (m, ww, 64)).astype(np.float32)
+    t0, t1 = torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV)
+    for what in ("weight", "sum"):
+        wts = synth.transformer_weights(77, 64, 2)
+        if what == "weight":
+            wts["layers.1.mlp.0.weight"] = wts["layers.1.mlp.0.weight"].copy()
+            wts["layers.1.mlp.0.weight"][5, 7] = 17.0                     # one weight beyond the scale
+        else:
+            # all-positive tokens against an all-ones k projection: k = sum_c x_c ~ 51 for every token (inside the
+            # activation range) but sum_s (elu(k)+1) ~ 49 x 52 = 2550 > 2047 for every head feature
+            wts["layers.0.k_proj.weight"] = np.ones_like(wts["layers.0.k_proj.weight"])
+            t0, t1 = t0.abs(), t1.abs()
+        packed = ops.pack_fine_transformer({k: torch.as_tensor(v) for k, v in wts.items()}, DEV)
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.fine_transformer(t0, t1, packed, status=status)
+        assert int(status.item()) & _lib.FM_DEV_RANGE, what
 
 
 # ------------------------------------------------------------------ coarse context layers in HIP (8(f) row 1)
@@ -765,15 +826,19 @@ def test_coarse_transformer_vs_oracle(n, l, s, layers):
     assert torch.equal(t0.cpu(), torch.as_tensor(x0)) and torch.equal(t1.cpu(), torch.as_tensor(x1))    # inputs untouched
     h0, h1 = ops.coarse_transformer(t0, t1, packed, layers)
     assert torch.equal(g0, h0) and torch.equal(g1, h1)               # deterministic (no float atomics)
-    # the module takes the kernels by itself in inference, its torch ops otherwise
+    # the module takes the kernels by itself in eval mode (grad mode on or off, as the reference's demo calls it), its
+    # torch ops when a gradient is asked for
     from featurematching_amd.transformer import LocalFeatureTransformer
     tf = LocalFeatureTransformer(dict(d_model=256, nhead=8, layer_names=layers, attention='linear')).to(DEV).eval()
     tf.load_state_dict(tw)
     with torch.no_grad():
         a0, a1 = tf(t0, t1)
     assert torch.equal(a0, g0) and torch.equal(a1, g1)
-    b0, b1 = tf(t0, t1)                      # grad mode: torch ops
-    assert (b0.detach() - g0).abs().max().item() <= 5e-5 and (b1.detach() - g1).abs().max().item() <= 5e-5
+    b0, b1 = tf(t0, t1)                      # grad mode on: still the HIP kernels
+    assert torch.equal(b0, g0) and torch.equal(b1, g1)
+    c0, c1 = tf(t0.clone().requires_grad_(), t1)     # a gradient is wanted: torch ops
+    assert c0.requires_grad
+    assert (c0.detach() - g0).abs().max().item() <= 5e-5 and (c1.detach() - g1).abs().max().item() <= 5e-5
 
 
 @pytest.mark.parametrize("gain", [1e-3, 300.0])

@@ -28,7 +28,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1)
     x0 = torch.randn(a.n, a.l, 256, device=dev, generator=g)
     x1 = torch.randn(a.n, a.l, 256, device=dev, generator=g)
-    os.environ["FM_HIP_COARSE_TF"] = "0"      # the module itself takes the HIP kernels in inference: force its torch ops
+    tf.use_hip = False                          # the module itself takes the HIP kernels in eval mode: keep its torch ops
     with torch.no_grad():
         r0, r1 = tf(x0, x1)
     h0, h1 = ops.coarse_transformer(x0, x1, packed, names)

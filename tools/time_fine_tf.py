@@ -27,7 +27,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1)
     x0 = torch.randn(a.m, ww, 64, device=dev, generator=g)
     x1 = torch.randn(a.m, ww, 64, device=dev, generator=g)
-    os.environ["FM_HIP_FINE_TF"] = "0"        # the module itself takes the HIP kernel in inference: force its torch ops
+    tf.use_hip = False                          # the module itself takes the HIP kernel in eval mode: keep its torch ops
     with torch.no_grad():
         r0, r1 = tf(x0, x1)
     h0, h1 = ops.fine_transformer(x0, x1, packed)

@@ -60,9 +60,9 @@ def main():
         t_fm, _ = timed(lambda: m.fine_matching(v0, v1, d))
         t_ftf_t = float("nan")
         if not a.hip_only:
-            os.environ["FM_HIP_FINE_TF"] = "0"
+            m.fine.use_hip = False
             t_ftf_t, _ = timed(lambda: m.fine(w0, w1))
-            os.environ["FM_HIP_FINE_TF"] = "1"
+            m.fine.use_hip = True
     mm = int(d['b_ids'].numel())
     print(f"forward_features N={n} {hc * 8}x{wc * 8}: {t_all:.3f} ms per call (matches through the random context layers: "
           f"{int(data['b_ids'].numel())})")
