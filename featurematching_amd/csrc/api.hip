@@ -253,7 +253,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
     if (e != hipSuccess) return (int)e;
   }
   e = launch_select(w, base, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
-                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, mode, st);
+                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, dense ? (mode | FM_MODE_DENSE) : mode, st);
   return (int)e;
 }
 

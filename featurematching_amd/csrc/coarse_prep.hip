@@ -59,7 +59,6 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 template <int C>
 __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   constexpr int KS8 = C / 32;
-  constexpr int NCH = C / 8 / 8;          // 8-channel chunks per thread
   const int tid = threadIdx.x;
   // ---- clear this workgroup's slice of the per-call counters ----
   {
@@ -140,46 +139,55 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
 
   float s1 = 0.f, amax = 0.f, clip = 0.f;
   bool bad = false;
+  constexpr int NCH16 = (C / 16 + 7) / 8;     // 16-channel chunks per thread (one 16-byte store of codes each)
 #pragma unroll
-  for (int n = 0; n < NCH; ++n) {             // C/8 chunks of 8 channels, 8 per pass
-    const int q = n * 8 + (tid >> 5);          // 8-channel chunk; 16-channel chunk q/2, byte half q&1
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  for (int n = 0; n < NCH16; ++n) {           // C/16 chunks of 16 channels, 8 per pass
+    const int q16 = n * 8 + (tid >> 5);
+    if (q16 >= C / 16) break;                  // (C = 64: four chunks, half of the threads have none)
+    float4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (staged) {
-      v0 = *reinterpret_cast<const float4*>(&tile[r * PITCH + q * 8]);
-      v1 = *reinterpret_cast<const float4*>(&tile[r * PITCH + q * 8 + 4]);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const float4*>(&tile[r * PITCH + q16 * 16 + 4 * p]);
     } else if (local < rows) {
       if (a.in_dtype == FM_F32) {
         const float* row = (const float*)src + row_off;
-        if (q * 8 < a.c_in) v0 = *reinterpret_cast<const float4*>(row + q * 8);
-        if (q * 8 + 4 < a.c_in) v1 = *reinterpret_cast<const float4*>(row + q * 8 + 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (q16 * 16 + 4 * p < a.c_in) v[p] = *reinterpret_cast<const float4*>(row + q16 * 16 + 4 * p);
       } else {
         // half-precision rows (what a ROCm backbone under autocast hands over): 4 values per 8-byte load; every
         // float16 / bfloat16 value is exact in float32, so everything downstream sees the caller's numbers
         const unsigned short* row = (const unsigned short*)src + row_off;
-        uint2 h0 = make_uint2(0u, 0u), h1 = h0;
-        if (q * 8 < a.c_in) h0 = *reinterpret_cast<const uint2*>(row + q * 8);
-        if (q * 8 + 4 < a.c_in) h1 = *reinterpret_cast<const uint2*>(row + q * 8 + 4);
-        v0 = half4_to_float4(h0, a.in_dtype);
-        v1 = half4_to_float4(h1, a.in_dtype);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          uint2 hv = make_uint2(0u, 0u);
+          if (q16 * 16 + 4 * p < a.c_in) hv = *reinterpret_cast<const uint2*>(row + q16 * 16 + 4 * p);
+          v[p] = half4_to_float4(hv, a.in_dtype);
+        }
       }
     }
-    bad = bad || bad_value(v0) || bad_value(v1);
-    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    int w0 = 0, w1 = 0;
+    int wq[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float ax = fabsf(x[e]);
-      s1 += ax;
-      amax = fmaxf(amax, ax);
-      clip += fmaxf(ax - clip_at, 0.f);
-      const int v = (int)fminf(fmaxf(rintf(x[e] * inv_sigma), -127.f), 127.f);
-      if (e < 4) w0 |= (v & 0xff) << (8 * e);
-      else w1 |= (v & 0xff) << (8 * (e - 4));
+    for (int p = 0; p < 4; ++p) {
+      bad = bad || bad_value(v[p]);
+      const float x[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+      int wd = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ax = fabsf(x[e]);
+        s1 += ax;
+        amax = fmaxf(amax, ax);
+        clip += fmaxf(ax - clip_at, 0.f);
+        const int c = (int)fminf(fmaxf(rintf(x[e] * inv_sigma), -127.f), 127.f);
+        wd |= (c & 0xff) << (8 * e);
+      }
+      wq[p] = wd;
     }
-    const int q16 = q >> 1;
     const int h = q16 / KS8, ks = q16 - h * KS8;
-    const long off = (((rb * KS8 + ks) * 2 + h) * 32 + r) * 16 + (q & 1) * 8;
-    *reinterpret_cast<int2*>(qp + off) = make_int2(w0, w1);
+    const long off = (((rb * KS8 + ks) * 2 + h) * 32 + r) * 16;
+    *reinterpret_cast<int4*>(qp + off) = make_int4(wq[0], wq[1], wq[2], wq[3]);
   }
   // per-row L1 norm and clipped mass (a row's channels sit in 8 threads); block maxima
   sm[tid >> 5][r] = s1;

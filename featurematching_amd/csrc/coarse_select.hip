@@ -18,6 +18,7 @@ struct SelArgs {
   const float* rowS; const float* colS;   // partial sums of the sparse sum kernel: rows [N][splits_s][Lp], columns [N][panels][Sp]
   const float* rowB; const float* colB;   // ... of the dense sum kernel (valid when it had units): rows [N][splits][Lp]
   int exact;                              // exact screening ran: its overflow is then FM_DEV_CANDIDATES already
+  int dense_enabled;                      // the call runs the dense sum kernel (FM_MODE_DENSE): its regions exist
   const int* cand_count; const int* cand_j; const float* cand_x;          // the sparse sum kernel's candidates, per row
   const int* ccand_count; const int* ccand_i; const float* ccand_x;       // ... the same entries per column
   const int* cand_count_b; const int* cand_j_b; const float* cand_x_b;    // the dense one's (samples with dense_cnt > 0)
@@ -84,8 +85,10 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   const int slot = (int)(gid - grow * a.slots);
   const int b = (int)(grow / a.Lp);
   const int i = (int)(grow - (long)b * a.Lp);
-  // a sample is handled by ONE sum kernel: the dense one redid it if the sparse one flagged any of its units
-  const bool dense = b < a.N && a.dense_cnt[b] > 0;
+  // a sample is handled by ONE sum kernel: the dense one redid it if the sparse one flagged any of its units.  (Without
+  // FM_MODE_DENSE a flagged sample has no valid result - the call reports FM_E_DENSE - and the dense kernel's regions
+  // of the workspace do not exist: they must not be touched.)
+  const bool dense = a.dense_enabled && b < a.N && a.dense_cnt[b] > 0;
   const int* cand_count = dense ? a.cand_count_b : a.cand_count;
   const int* cand_j = dense ? a.cand_j_b : a.cand_j;
   const float* cand_x = dense ? a.cand_x_b : a.cand_x;
@@ -95,35 +98,50 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   const float* rowP = dense ? a.rowB : a.rowS;
   const float* colP = dense ? a.colB : a.colS;
   const int rparts = dense ? a.splits : a.splits_s;
-  const int cnt = (b < a.N && i < a.L) ? min(cand_count[grow], a.slots) : 0;
+  // Every load below that does not depend on a loaded value is issued before the first use of any of them: this
+  // row's candidate count, candidate slot (speculatively: a slot beyond the count is ignored), stabiliser and the
+  // partial sums of its softmax denominator - one memory round trip; the column's statistics follow in a second one.
+  const bool row_ok = b < a.N && i < a.L;
+  const long grow_c = row_ok ? grow : 0;                      // (clamped: no load behind a branch)
+  const int cnt_raw = cand_count[grow_c];
+  const int j_raw = cand_j[grow_c * a.slots + slot];
+  const float x = cand_x[grow_c * a.slots + slot];
+  const float nmr_i = a.nmr[grow_c];
+  const int b_c = row_ok ? b : 0, i_c = row_ok ? i : 0;
+  const float rs = fold_partials(rowP + (long)b_c * rparts * a.Lp + i_c, rparts, a.Lp);
+  const int cnt = row_ok ? min(cnt_raw, a.slots) : 0;
+  const bool live = slot < cnt;
   bool keep = false;
-  int j = 0x7fffffff;
+  int j = live ? j_raw : 0x7fffffff;
   float conf = 0.f, colbest = 0.f;
-  if (slot < cnt) {
-    j = cand_j[grow * a.slots + slot];
-    const float x = cand_x[grow * a.slots + slot];
-    const long gcol = (long)b * a.Sp + j;
-    // softmax denominators of this row and this column, folded from the sum kernels' partials in a fixed order
-    // (all loads independent: one round trip)
-    const float rs = fold_partials(rowP + (long)b * rparts * a.Lp + i, rparts, a.Lp);
-    const float cs = fold_partials(colP + (long)b * a.panels * a.Sp + j, a.panels, a.Sp);
+  {
+    const int jc = live ? j_raw : 0;
+    const long gcol = (long)b_c * a.Sp + jc;
+    // the column's denominator and its candidate list (this entry among them), each with its own row's denominator
+    const float cs = fold_partials(colP + (long)b_c * a.panels * a.Sp + jc, a.panels, a.Sp);
     const float nmc = a.nmc[gcol];
-    conf = entry_conf(x, a.k, a.nmr[grow], rs, nmc, cs);
-    // best conf of the column: its candidates (this one among them), each with its own row's denominator
-    const int ccnt = min(ccand_count[gcol], a.slots);
-    for (int t = 0; t < ccnt; ++t) {
-      const int i2 = ccand_i[gcol * a.slots + t];
-      float c2 = conf;
-      if (i2 != i) {
-        const float rs2 = fold_partials(rowP + (long)b * rparts * a.Lp + i2, rparts, a.Lp);
-        c2 = entry_conf(ccand_x[gcol * a.slots + t], a.k, a.nmr[(long)b * a.Lp + i2], rs2, nmc, cs);
+    const int ccnt_raw = ccand_count[gcol];
+    int ci[2]; float cx[2];                                    // the first two column candidates, speculatively
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ci[t] = ccand_i[gcol * a.slots + t]; cx[t] = ccand_x[gcol * a.slots + t]; }
+    if (live) {
+      conf = entry_conf(x, a.k, nmr_i, rs, nmc, cs);
+      const int ccnt = min(ccnt_raw, a.slots);
+      for (int t = 0; t < ccnt; ++t) {
+        const int i2 = t < 2 ? ci[t] : ccand_i[gcol * a.slots + t];
+        float c2 = conf;
+        if (i2 != i) {
+          const float x2 = t < 2 ? cx[t] : ccand_x[gcol * a.slots + t];
+          const float rs2 = fold_partials(rowP + (long)b * rparts * a.Lp + i2, rparts, a.Lp);
+          c2 = entry_conf(x2, a.k, a.nmr[(long)b * a.Lp + i2], rs2, nmc, cs);
+        }
+        colbest = fmaxf(colbest, c2);
       }
-      colbest = fmaxf(colbest, c2);
     }
   }
   float rowbest = conf;
   for (int m = 1; m < a.slots; m <<= 1) rowbest = fmaxf(rowbest, __shfl_xor(rowbest, m));
-  if (slot < cnt)
+  if (live)
     keep = conf > a.thr && conf == rowbest && conf == colbest &&
            interior(i, a.h0c, a.w0c, a.border) && interior(j, a.h1c, a.w1c, a.border);
   // rank among the row's kept entries by ascending j (torch.where order, :109)
@@ -212,6 +230,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
                          int mode, hipStream_t st) {
   SelArgs a;
   a.exact = (mode & FM_MODE_EXACT_SCREENING) ? 1 : 0;
+  a.dense_enabled = (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) ? 1 : 0;
   a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
   a.rowS = (const float*)(base + w.rowS); a.colS = (const float*)(base + w.colS);
   a.rowB = (const float*)(base + w.rowB); a.colB = (const float*)(base + w.colB);

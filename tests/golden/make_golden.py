@@ -416,6 +416,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "epi":
         epipolar_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r3":     # the fixtures added in round 3 only
+        full_case("cfg2_mixed", "cfg2", "mixed")
+        full_case("cfg3_first2_borderline", "cfg3", "borderline", with_fine=False, n=2)
+        full_case("cfg5_borderline", "cfg5", "borderline", with_fine=False)
+        sys.exit(0)
     kat_cases()
     kat_cases_round2()
     net_tail_case()
@@ -428,3 +433,8 @@ if __name__ == "__main__":
     full_case("cfg5_peaky", "cfg5", "peaky", with_fine=False)
     merge_case("merge_cfg1_w7", "cfg1", "peaky", 7)
     merge_case("merge_cfg2_w5", "cfg2", "borderline", 5)
+    # round 3: the reference's dual softmax at S = 16384 and at batch size on data whose conf values are NOT all 1.0,
+    # and peaked data with textureless cells (flat rows / columns next to peaked ones)
+    full_case("cfg2_mixed", "cfg2", "mixed")
+    full_case("cfg3_first2_borderline", "cfg3", "borderline", with_fine=False, n=2)
+    full_case("cfg5_borderline", "cfg5", "borderline", with_fine=False)

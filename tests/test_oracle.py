@@ -18,7 +18,8 @@ def _check_coarse(out, g):
 
 
 @pytest.mark.parametrize("name,dist", [("cfg1_peaky", "peaky"), ("cfg1_borderline", "borderline"),
-                                       ("cfg2_peaky", "peaky"), ("cfg2_borderline", "borderline")])
+                                       ("cfg2_peaky", "peaky"), ("cfg2_borderline", "borderline"),
+                                       ("cfg2_mixed", "mixed")])
 def test_full_path_matches_reference(name, dist):
     g = load_golden(name)
     inp = case_inputs(g['meta'], dist)
@@ -41,6 +42,19 @@ def test_batch_case_matches_reference():
     _check_coarse(out, g)
     assert set(np.unique(g['b_ids'])) == {0, 1}
     np.testing.assert_allclose(out['mkpts1_f'].numpy(), g['mkpts1_f'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["cfg3_first2_borderline", "cfg5_borderline"])
+def test_coarse_on_non_degenerate_data_at_batch_and_large_size(name):
+    """Round-3 fixtures: the reference's dual softmax on 'borderline' data (conf spread over (0.2, 1), not all 1.0) for
+    two samples of the cfg#3 batch and at S = 16384 (cfg#5)."""
+    g = load_golden(name)
+    inp = case_inputs(g['meta'], "borderline", with_fine=False)
+    torch.set_num_threads(8)
+    out = orc.coarse_match(inp['f0'], inp['f1'], inp['hw_i'], inp['hw_c'], inp['hw_c'], 0.2, 2, 0.1)
+    _check_coarse(out, g)
+    assert (g['mconf'] < 0.99).mean() > 0.5                 # a real check of the softmax arithmetic
+    assert g['i_ids'].shape[0] > 5000
 
 
 def test_kats_match_reference():

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
 rm -rf $O && mkdir -p $O
 COMMON="--steps 200 --warmup 20 --skip-cpu --quick"
+python -c "import bench; print(bench.kernel_source_sha())" > $O/kernel_src_sha16.txt
 # (1) the default command (hipGraph replay, 4 streams): per-kernel time under the bench's own concurrency
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -- python bench.py $COMMON > $O/default.json 2> $O/default.err
 echo "default done"

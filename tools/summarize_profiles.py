@@ -74,9 +74,13 @@ def main():
                 fw.setdefault(k, {})[c] = sum(v) / len(v)
                 fw[k]["launches_" + c] = len(v)
     if fw:
+        sha_file = os.path.join(SRC, "kernel_src_sha16.txt")       # written on the GPU box by collect_profiles.sh
+        sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
         with open(os.path.join(DST, f"{rnd}_pmc_fetch_write_cfg2.json"), "w") as oh:
             json.dump({"_note": "average per launch, KiB as rocprofv3 reports them; FETCH_SIZE must be doubled "
-                                "for wide reads on gfx950 (MI355X_MICROARCH.md, HBM section)", **fw}, oh, indent=1)
+                                "for wide reads on gfx950 (MI355X_MICROARCH.md, HBM section); kernel_src_sha16 = "
+                                "bench.kernel_source_sha() of the sources the counters were collected with",
+                       "kernel_src_sha16": sha, "kernels": fw}, oh, indent=1)
         print("wrote pmc_fetch_write")
 
     stats("ctx", f"{rnd}_forward_features_kernel_stats.csv")
