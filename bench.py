@@ -93,8 +93,8 @@ class Pair:
         elif fine_path == "windows":
             self.win0 = torch.empty(self.cap, window * window, wl["cf"], device=dev)
             self.win1 = torch.empty_like(self.win0)
-        elif layout == "nchw":    # channels-last copies of both maps (fm_fine_match_maps makes them per call)
-            self.scratch = torch.empty(2 * self.ff0.numel() * 4, dtype=torch.uint8, device=dev)
+        elif layout == "nchw":    # channels-last copy of image 1 (fm_fine_match_maps makes it per call)
+            self.scratch = torch.empty(self.ff1.numel() * 4, dtype=torch.uint8, device=dev)
         self.last = None
         self.gather = "cells"    # cells | list (see ops.gather_windows)
         self.dense = dist != "peaky"     # flat similarity needs the dense sum kernel (FM_MODE_DENSE); the common path is 4 launches
@@ -111,7 +111,8 @@ class Pair:
         else:
             buf = ops.coarse_match_async(self.f0, self.f1, self.hw_c, self.hw_c, self.hw_i[0] / self.hw_c[0],
                                          cap=self.cap, dense=self.dense, exact_screening=self.exact,
-                                         conf_matrix=self.conf_matrix)
+                                         conf_matrix=self.conf_matrix,
+                                         cell_maps=(self.fine_path == "windows" and self.layout == "nchw"))
         if self.stages == "coarse" and self.last is not None:
             self.last = (buf,) + self.last[1:]
             return self.last
@@ -226,7 +227,7 @@ def time_kernels(pair):
     buf = pair.last[0]
     if pair.fine_path == "maps":
         t["crop"] = 0.0
-        t["fine"] = _events(lambda: pair.fine_maps(buf), group=3)      # (NCHW: the two transposes + the fused kernel)
+        t["fine"] = _events(lambda: pair.fine_maps(buf), group=3)      # (NCHW: image 1's transpose + the fused kernel)
     else:
         t["crop"] = _events(lambda: pair.crop(buf), group=3 if pair.layout == "nhwc" else 6)
         t["fine"] = _events(lambda: pair.fine(buf))
@@ -705,7 +706,7 @@ def main():
     traffic, traffic_src = committed_traffic(a.workload)
     copy_gbs = copy_rate(crop_bytes, dev)
     maps_path = pairs[0].fine_path == "maps"
-    launches = 4 + (2 if pairs[0].dense else 0) + ((3 if a.layout == "nchw" else 1) if maps_path else (3 if a.layout == "nhwc" else 2))
+    launches = 4 + (2 if pairs[0].dense else 0) + ((2 if a.layout == "nchw" else 1) if maps_path else (3 if a.layout == "nhwc" else 2))
     map_bytes = 2.0 * wl["n"] * cf * 4 * sh0["hf"] * sh0["wf"]           # both fine maps
     out = {
         "metric": ("image-pairs/sec at 640x480 (coarse corr + dual-softmax mutual-NN + fine window refinement)"
@@ -759,12 +760,13 @@ def main():
                                       "assignment_and_gaps_ms": round(tk["coarse"] - t_corr - tk["prep"], 5)}},
         "roofline_aux": ({
             "fine_from_maps": {"bound": "hbm",
-                               "kernel": ("2 x k_nchw_to_nhwc64 + " if a.layout == "nchw" else "") + f"k_fine_maps<{a.window}> (window crop + fine stage, no window tensors)",
-                               # SURVEY 8(d) fine-kernel bytes (the window bytes, read once) + for NCHW maps the transposes' read + write
-                               "algorithmic_bytes": fine_bytes + (2.0 * map_bytes if a.layout == "nchw" else 0.0),
-                               "achieved": round((fine_bytes + (2.0 * map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9, 1),
+                               "kernel": ("k_nchw_to_nhwc64 (image 1) + " if a.layout == "nchw" else "") + f"k_fine_maps<{a.window}> (window crop + fine stage, no window tensors)",
+                               # SURVEY 8(d) fine-kernel bytes (the window bytes, read once) + for NCHW maps the read + write of
+                               # image 1's channels-last copy (= the bytes of both maps)
+                               "algorithmic_bytes": fine_bytes + (map_bytes if a.layout == "nchw" else 0.0),
+                               "achieved": round((fine_bytes + (map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round((fine_bytes + (2.0 * map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "frac": round((fine_bytes + (map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "avg_ms": round(tk["fine"], 5)}} if maps_path else {
             "window_crop": {"bound": "hbm", "kernel": "k_gather_cellorder64 (both images, one launch)" if a.layout == "nchw"
                                                       else f"2 x k_gather_nhwc64<{a.window}> (channels-last maps: 16-byte-chunk copy)",

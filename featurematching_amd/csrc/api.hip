@@ -120,6 +120,7 @@ extern "C" const char* fm_strerror(int s) {
     case FM_E_CANDIDATES: return "a coarse row or column exceeded its candidate slots (FM_MODE_EXACT_SCREENING, then more cand_slots)";
     case FM_E_RANGE: return "descriptor not finite or |x| >= 32768, or similarities of several thousand (screening margin >= 2^60)";
     case FM_E_DENSE: return "flat similarity in a sample: call again with FM_MODE_DENSE";
+    case FM_E_INTERNAL: return "assignment kernel: bounded wait for predecessor workgroups ran out; call again";
     default: return s > 0 ? hipGetErrorString((hipError_t)s) : "unknown fmatch status";
   }
 }
@@ -144,7 +145,7 @@ extern "C" int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int ca
   if (!bytes) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) return FM_E_UNSUPPORTED;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS)) return FM_E_UNSUPPORTED;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   *bytes = needs_dense_region(mode, want_conf_matrix != 0) ? w.total : w.common_total;
   return FM_OK;
@@ -207,7 +208,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) return FM_E_UNSUPPORTED;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS)) return FM_E_UNSUPPORTED;
   const bool exact = (mode & FM_MODE_EXACT_SCREENING) != 0;
   const bool dense = needs_dense_region(mode, conf_matrix != nullptr);      // exact screening and conf_matrix read the planes too
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
@@ -340,6 +341,7 @@ extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, vo
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return (int)e;
   *m_out = h[0];
+  if (h[1] & FM_DEV_INTERNAL) return FM_E_INTERNAL;
   if (h[1] & FM_DEV_RANGE) return FM_E_RANGE;
   if (h[1] & FM_DEV_DENSE) return FM_E_DENSE;
   if (h[1] & FM_DEV_CANDIDATES) return FM_E_CANDIDATES;

@@ -28,6 +28,7 @@ struct PrepArgs {
                                       // clipped L1 mass of a descriptor, largest |x|, 0}
   uint4* zero; int zero_vec;          // per-call counters to clear (uint4 units)
   int L, S, Lp, Sp, c_in, blocks0;    // blocks0 = workgroups that convert image 0
+  float* diag;                        // diagnostic build: stamp buffer
 };
 
 __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the comparison too
@@ -60,6 +61,13 @@ template <int C>
 __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   constexpr int KS8 = C / 32;
   const int tid = threadIdx.x;
+#ifdef FM_DIAG_CLOCK       // diagnostic build only: constant-clock stamps (10 ns) of every workgroup's phases
+  unsigned long long dg[5];
+  dg[0] = __builtin_amdgcn_s_memrealtime();
+#define PREP_STAMP(i) dg[i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PREP_STAMP(i)
+#endif
   // ---- clear this workgroup's slice of the per-call counters ----
   {
     const int per = (a.zero_vec + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -129,7 +137,9 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) amax_s = fmaxf(amax_s, __shfl_xor(amax_s, m));
   if ((tid & 63) == 0) wred[0][tid >> 6] = amax_s;
+  PREP_STAMP(1)
   __syncthreads();
+  PREP_STAMP(2)
   amax_s = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3]));
   // (a non-finite sample: some block reports the bad value below and the call fails; the step is irrelevant then)
   const float sigma = amax_s < INFINITY ? amax_s * (kPrepHeadroom / 127.0f) : 1.0f;
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
     const long off = (((rb * KS8 + ks) * 2 + h) * 32 + r) * 16;
     *reinterpret_cast<int4*>(qp + off) = make_int4(wq[0], wq[1], wq[2], wq[3]);
   }
+  PREP_STAMP(3)
   // per-row L1 norm and clipped mass (a row's channels sit in 8 threads); block maxima
   sm[tid >> 5][r] = s1;
   sm2[tid >> 5][r] = clip;
@@ -209,6 +220,11 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
       const bool bb = wred[2][0] + wred[2][1] + wred[2][2] + wred[2][3] > 0.f;
       (img1 ? a.bstat1 : a.bstat0)[rb] = make_float4(bb ? INFINITY : bl1, bce,
                                                      fmaxf(fmaxf(wred[1][0], wred[1][1]), fmaxf(wred[1][2], wred[1][3])), 0.f);
+#ifdef FM_DIAG_CLOCK
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PREP_STAMP(4)
+      for (int q2 = 0; q2 < 5; ++q2) a.diag[blockIdx.x * 8 + q2] = (float)(dg[q2] & 0xffffff);
+#endif
     }
   }
 }
@@ -304,6 +320,7 @@ static void fill_prep_args(PrepArgs& a, const void* feat0, const void* feat1, in
   a.blocks0 = (int)((long)w.N * w.Lp / 32);
   a.dense_cnt = (const int*)(base + w.dense_cnt); a.force = 0; a.f16inv = (float*)(base + w.f16inv);
   a.bstat0r = (const float4*)(base + w.bstat0); a.bstat1r = (const float4*)(base + w.bstat1); a.N = w.N;
+  a.diag = (float*)(base + w.colB);       // (diagnostic builds run on a full-size workspace)
 }
 
 hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,

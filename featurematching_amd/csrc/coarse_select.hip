@@ -3,7 +3,7 @@
 //   on the spot), best conf of its row (the row's candidates sit in adjacent lanes) and of its column (the column's
 //   candidates, listed per column by the sum kernels, are re-evaluated with the same arithmetic - no grid-wide pass),
 //   threshold + mutual nearest neighbour + border, a row's matches sorted by j, deterministic prefix offsets
-//   (ticket-ordered look-back over the workgroup totals) -> outputs in (b, i, j) order.
+//   (look-back over the workgroup totals, bounded wait) -> outputs in (b, i, j) order.
 //
 // Follows network/utils/coarse_matching_new.py:99-141.  Every entry of the L x S matrix
 // that is not a candidate has conf <= thr, so it can neither pass :99 nor beat a surviving
@@ -18,6 +18,7 @@ struct SelArgs {
   const float* rowS; const float* colS;   // partial sums of the sparse sum kernel: rows [N][splits_s][Lp], columns [N][panels][Sp]
   const float* rowB; const float* colB;   // ... of the dense sum kernel (valid when it had units): rows [N][splits][Lp]
   int exact;                              // exact screening ran: its overflow is then FM_DEV_CANDIDATES already
+  int cell_maps;                          // write the cell -> match maps (two returning atomics per match)
   int dense_enabled;                      // the call runs the dense sum kernel (FM_MODE_DENSE): its regions exist
   const int* cand_count; const int* cand_j; const float* cand_x;          // the sparse sum kernel's candidates, per row
   const int* ccand_count; const int* ccand_i; const float* ccand_x;       // ... the same entries per column
@@ -34,6 +35,7 @@ struct SelArgs {
   int* cell0; int* cell1;     // cell -> match index + 1 (for the cell-ordered window gathers)
   int* ties0; int* ties1;     // [0] = count, then the matches that lost their cell to an exactly tied match
   int nblk;                   // logical blocks of 256 (row, slot) pairs
+  float* diag;                // diagnostic build: stamp buffer
 };
 
 __device__ __forceinline__ bool interior(int id, int hh, int ww, int bd) {
@@ -42,16 +44,18 @@ __device__ __forceinline__ bool interior(int id, int hh, int ww, int bd) {
   return y >= bd && y < hh - bd && x >= bd && x < ww - bd;
 }
 
-// n partial sums `pitch` floats apart, 8 loads in flight, added in index order (the order is part of the result:
-// every thread that needs a denominator folds it the same way, so equal inputs give equal bits)
+// n partial sums `pitch` floats apart, added in index order (the order is part of the result: every thread that
+// needs a denominator folds it the same way, so equal inputs give equal bits).  Up to 32 loads in flight - the 19
+// column partials of a 640x480 pair are ONE memory round trip, not three - with clamped indices instead of predicates
+// (a repeated load of the last partial is discarded by the select).
 __device__ __forceinline__ float fold_partials(const float* p, int n, long pitch) {
   float t = 0.f;
-  for (int q0 = 0; q0 < n; q0 += 8) {
-    float v[8];
+  for (int q0 = 0; q0 < n; q0 += 32) {
+    float v[32];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = (q0 + q < n) ? p[(long)(q0 + q) * pitch] : 0.f;
+    for (int q = 0; q < 32; ++q) v[q] = p[(long)min(q0 + q, n - 1) * pitch];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t += v[q];
+    for (int q = 0; q < 32; ++q) t += (q0 + q < n) ? v[q] : 0.f;
   }
   return t;
 }
@@ -66,19 +70,26 @@ __device__ __forceinline__ float entry_conf(float x, float k, float nmr, float r
 }
 
 // One logical block = 256 (row, slot) pairs = 256/slots consecutive rows; a row's `slots` threads are adjacent lanes of
-// one wave.  Output offsets come from a look-back over the totals of the blocks before it, in TICKET order: a
-// workgroup only ever waits for workgroups that have started (no assumption on dispatch order or residency).  The
-// ticket (a returning atomic on one address) is requested first and consumed after the candidate loads, so its round
-// trip hides behind them.
+// one wave.  Output offsets come from a look-back over the totals of the blocks before it.  Block = blockIdx: a
+// workgroup then waits for workgroups of lower index, which the dispatcher starts first in practice (in-kernel stamps:
+// all 152 workgroups of a 640x480 pair start within 0.3 us); HIP does not promise that order, so the wait is BOUNDED -
+// a workgroup that does not see its predecessors within ~2^22 polls gives up and the call reports FM_E_INTERNAL
+// instead of hanging.  (Tickets - a returning atomic on one address before anything else can be loaded - made the
+// order a certainty at 1.2 us per launch and 146 us for the 9728 blocks of a 64-pair batch.)
 __global__ __launch_bounds__(256) void k_select(SelArgs a) {
-  __shared__ int s_ticket;
   __shared__ int sm[4];
   __shared__ int rowoff[64], rowcnt[64];
   __shared__ int s_kj[256];
   __shared__ float s_kc[256];
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&a.scal->ticket, 1);
-  __syncthreads();
-  const int blk = s_ticket;
+#ifdef FM_DIAG_CLOCK       // diagnostic build only: constant-clock stamps (10 ns) of every workgroup's phases
+  unsigned long long dg[6];
+  dg[0] = __builtin_amdgcn_s_memrealtime();
+#define SEL_STAMP(i) dg[i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define SEL_STAMP(i)
+#endif
+  const int blk = blockIdx.x;
+  SEL_STAMP(1)
   const int lane = threadIdx.x & 63;
   const long gid = (long)blk * 256 + threadIdx.x;
   const long grow = gid / a.slots;                 // b*Lp + i
@@ -141,6 +152,10 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   }
   float rowbest = conf;
   for (int m = 1; m < a.slots; m <<= 1) rowbest = fmaxf(rowbest, __shfl_xor(rowbest, m));
+#ifdef FM_DIAG_CLOCK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SEL_STAMP(2)
+#endif
   if (live)
     keep = conf > a.thr && conf == rowbest && conf == colbest &&
            interior(i, a.h0c, a.w0c, a.border) && interior(j, a.h1c, a.w1c, a.border);
@@ -165,11 +180,18 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   const int total = sm[0] + sm[1] + sm[2] + sm[3];
   if (threadIdx.x == 0)
     __hip_atomic_store(&a.blocktot[blk], total | (int)0x40000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  SEL_STAMP(3)
   // exclusive prefix of the totals of the blocks before this one (fixed order of integer adds)
   int pre = 0;
   for (int k = threadIdx.x; k < blk; k += 256) {
-    int v;
-    do { v = __hip_atomic_load(&a.blocktot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v & 0x40000000));
+    int v, polls = 0;
+    do {
+      v = __hip_atomic_load(&a.blocktot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(v & 0x40000000)) {
+        if (++polls > (1 << 22)) { atomicOr(&a.scal->flags, (unsigned)FM_INT_LOOKBACK_TIMEOUT); v = 0x40000000; }
+        else __builtin_amdgcn_s_sleep(1);
+      }
+    } while (!(v & 0x40000000));
     pre += v & 0x3fffffff;
   }
 #pragma unroll
@@ -194,18 +216,30 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
       // without the exact-screening pass an overflow of the sum kernels' candidate slots is final
       unsigned fl = a.scal->flags;
       if (!a.exact && (fl & (unsigned)FM_INT_SCREEN_OVERFLOW)) fl |= (unsigned)FM_DEV_CANDIDATES;
-      a.d_count[1] = (int)((fl & 15u & ~(unsigned)FM_DEV_CAPACITY) | (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
+      if (fl & (unsigned)FM_INT_LOOKBACK_TIMEOUT) fl |= (unsigned)FM_DEV_INTERNAL;
+      a.d_count[1] = (int)((fl & (15u | (unsigned)FM_DEV_INTERNAL) & ~(unsigned)FM_DEV_CAPACITY) |
+                           (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
     }
   }
   __syncthreads();
-  if (b >= a.N || slot >= rowcnt[q]) return;
+  SEL_STAMP(4)
+#ifdef FM_DIAG_CLOCK
+#define SEL_DIAG_OUT                                                                                  \
+  if (threadIdx.x == 0) {                                                                             \
+    SEL_STAMP(5)                                                                                      \
+    for (int q2 = 0; q2 < 6; ++q2) a.diag[blk * 8 + q2] = (float)(dg[q2] & 0xffffff);                 \
+  }
+#else
+#define SEL_DIAG_OUT
+#endif
+  if (b >= a.N || slot >= rowcnt[q]) { SEL_DIAG_OUT return; }
   const long o = (long)rowoff[q] + slot;
-  if (o >= a.cap) return;
+  if (o >= a.cap) { SEL_DIAG_OUT return; }
   const int jj = s_kj[q * a.slots + slot];
   a.b_ids[o] = b; a.i_ids[o] = i; a.j_ids[o] = jj;
   // cell -> match maps: with exact ties the largest match index keeps the cell, every other tied match
   // is listed once (whoever loses the atomicMax, now or when it is displaced later, is the one listed)
-  {
+  if (a.cell_maps) {
     const int me = (int)o + 1;
     int old = atomicMax(&a.cell0[grow], me);
     int loser = old > me ? me : old;
@@ -221,6 +255,10 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   if (a.scale1) { s1x = a.scale_px * a.scale1[b * 2]; s1y = a.scale_px * a.scale1[b * 2 + 1]; }
   a.k0[o * 2] = (float)(i % a.w0c) * s0x; a.k0[o * 2 + 1] = (float)(i / a.w0c) * s0y;
   a.k1[o * 2] = (float)(jj % a.w1c) * s1x; a.k1[o * 2 + 1] = (float)(jj / a.w1c) * s1y;
+#ifdef FM_DIAG_CLOCK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  SEL_DIAG_OUT
 }
 
 hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
@@ -231,6 +269,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   SelArgs a;
   a.exact = (mode & FM_MODE_EXACT_SCREENING) ? 1 : 0;
   a.dense_enabled = (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) ? 1 : 0;
+  a.cell_maps = (mode & FM_MODE_NO_CELL_MAPS) ? 0 : 1;
   a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
   a.rowS = (const float*)(base + w.rowS); a.colS = (const float*)(base + w.colS);
   a.rowB = (const float*)(base + w.rowB); a.colB = (const float*)(base + w.colB);
@@ -254,6 +293,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   a.ties0 = (int*)(base + w.ties0); a.ties1 = (int*)(base + w.ties1);
   const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
   a.nblk = blocks;
+  a.diag = (float*)(base + w.rowB);       // (diagnostic builds run on a full-size workspace)
   hipLaunchKernelGGL(k_select, dim3(blocks), dim3(256), 0, st, a);
   return hipGetLastError();
 }

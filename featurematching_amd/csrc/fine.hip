@@ -100,15 +100,15 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int W, bool MERGE = false>
-__device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int Wf, int oy, int ox,
-                                                   float* __restrict__ dst, float* tile, int lane,
-                                                   const half8* __restrict__ wpack = nullptr,
-                                                   const float* __restrict__ ctx_row = nullptr) {
-  constexpr int CF = 64, WW = W * W, TOTAL = CF * WW, PITCH = CF + 4;
-  // lane -> (channel within the instruction, window position) is the same for every load: W = 5 puts two
-  // channels x 32 position slots (25 used) in one wave-load, W = 7 one channel x 64 slots (49 used).  Only
-  // the channel advances from load to load, by a SCALAR offset, so the address math is done once.
+// One W x W window of a 64-channel NCHW map into a wave-private LDS tile [position][channel] (pitch 68 floats).
+// lane -> (channel within the instruction, window position) is the same for every load: W = 5 puts two channels x 32
+// position slots (25 used) in one wave-load, W = 7 one channel x 64 slots (49 used).  Only the channel advances from
+// load to load, by a SCALAR offset, so the address math is done once.  Buffer loads through a descriptor of this
+// sample's map (src is wave-uniform): positions outside the map (the zero padding of the unfold) get an out-of-range
+// offset, which the hardware range check answers with 0 - no branch, no 64-bit address per load.
+template <int W>
+__device__ __forceinline__ void wave_load_window64(const float* src, int Hf, int Wf, int oy, int ox, float* tile, int lane) {
+  constexpr int CF = 64, WW = W * W, PITCH = CF + 4;
   constexpr int SLOTS = W == 5 ? 32 : 64, CPI = 64 / SLOTS, NLOAD = CF / CPI;
   static_assert(W == 5 || W == 7, "position decode below is for W in {5,7}");
   const int rem = lane & (SLOTS - 1), hi = lane / SLOTS;
@@ -116,9 +116,6 @@ __device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int
   const int wx = rem - wy * W;
   const int y = oy + wy, x = ox + wx;
   const bool ok = rem < WW && y >= 0 && y < Hf && x >= 0 && x < Wf;
-  // Buffer loads through a descriptor of this sample's map (src is wave-uniform): positions outside the
-  // map (the zero padding of the unfold) get an out-of-range offset, which the hardware range check
-  // answers with 0 - no branch, no 64-bit address per load.
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, CF * Hf * Wf * 4, 0x00020000);
   const unsigned voff = ok ? (unsigned)((hi * Hf + y) * Wf + x) * 4u : 0x80000000u;
@@ -137,6 +134,15 @@ __device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int
   for (int it = 0; it < NLOAD; ++it)
     if (rem < WW) slot[it * CPI] = v[it];
   __builtin_amdgcn_wave_barrier();       // same-wave LDS accesses are processed in order: no s_barrier needed
+}
+
+template <int W, bool MERGE = false>
+__device__ __forceinline__ void wave_copy_window64(const float* src, int Hf, int Wf, int oy, int ox,
+                                                   float* __restrict__ dst, float* tile, int lane,
+                                                   const half8* __restrict__ wpack = nullptr,
+                                                   const float* __restrict__ ctx_row = nullptr) {
+  constexpr int CF = 64, WW = W * W, TOTAL = CF * WW, PITCH = CF + 4;
+  wave_load_window64<W>(src, Hf, Wf, oy, ox, tile, lane);
   if (MERGE) wave_merge_tile<W>(tile, lane, wpack, ctx_row);
   float4* dst4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
@@ -531,7 +537,10 @@ __global__ __launch_bounds__(256) void k_gather_nhwc64(const float* __restrict__
   }
 }
 
-template <int W>
+// NCHW0: image 0 is still in the reference's NCHW layout - its windows are visited in raster order here (the match list
+// is sorted by the image-0 cell), which is the access pattern the NCHW loader of the cell-ordered crop copes with, so only
+// image 1 (whose windows land wherever the partners are) needs the channels-last copy.
+template <int W, bool NCHW0>
 __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map0, const float* __restrict__ map1, int Hf0,
                                                    int Wf0, int Hf1, int Wf1, int stride, int pad, int w0c, int w1c,
                                                    const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
@@ -558,6 +567,7 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
   // per-position conditions, ~10 scalar instructions per window row instead of ~12 per window position.
   const float* base0 = map0 + (long)b * Hf0 * Wf0 * 64;
   const float* base1 = map1 + (long)b * Hf1 * Wf1 * 64;
+  __shared__ __attribute__((aligned(16))) float tile_all[NCHW0 ? 4 * kGatherTileFloats(W) : 4];
   unsigned vo0[W], vo1[W];
 #pragma unroll
   for (int wx = 0; wx < W; ++wx) {
@@ -570,15 +580,24 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
   for (int wy = 0; wy < W; ++wy) {
     const int y0 = oy0 + wy, y1 = oy1 + wy;
     const bool ok0 = y0 >= 0 && y0 < Hf0, ok1 = y1 >= 0 && y1 < Hf1;          // wave-uniform
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(base0 + (long)(ok0 ? y0 : 0) * Wf0 * 64), 0, ok0 ? Wf0 * 256 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(base1 + (long)(ok1 ? y1 : 0) * Wf1 * 64), 0, ok1 ? Wf1 * 256 : 0, 0x00020000);
+    if (!NCHW0) {
+      const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(base0 + (long)(ok0 ? y0 : 0) * Wf0 * 64), 0, ok0 ? Wf0 * 256 : 0, 0x00020000);
 #pragma unroll
-    for (int wx = 0; wx < W; ++wx) {
-      f0[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, vo0[wx], 0, 0));
-      f1[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, vo1[wx], 0, 0));
+      for (int wx = 0; wx < W; ++wx)
+        f0[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, vo0[wx], 0, 0));
     }
+#pragma unroll
+    for (int wx = 0; wx < W; ++wx)
+      f1[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, vo1[wx], 0, 0));
+  }
+  if (NCHW0) {      // image 0 straight from the NCHW map: the crop's loader into a wave-private tile, read back by channel
+    float* tile = tile_all + wv * kGatherTileFloats(W);
+    wave_load_window64<W>(base0, Hf0, Wf0, oy0, ox0, tile, lane);
+#pragma unroll
+    for (int r = 0; r < WW; ++r) f0[r] = tile[r * 68 + lane];
   }
   fine_core<W>(f0, f1, lane, mix0, mix1, kc0[m * 2], kc0[m * 2 + 1], kc1[m * 2], kc1[m * 2 + 1], scale_f,
                out0 + (long)m * 3, out1 + (long)m * 3);
@@ -806,7 +825,7 @@ static bool maps64_ok(int Cf, int Hf, int Wf, int W) {
 
 extern "C" size_t fm_fine_maps_scratch_bytes(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout) {
   if (layout != 0 || N <= 0 || Cf <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0) return 0;
-  return (size_t)N * Cf * 4 * ((size_t)Hf0 * Wf0 + (size_t)Hf1 * Wf1);
+  return (size_t)N * Cf * 4 * (size_t)Hf1 * Wf1;      // the channels-last copy of image 1
 }
 
 extern "C" int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, int layout, int N, int Cf, int Hf0, int Wf0,
@@ -824,19 +843,17 @@ extern "C" int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, in
   hipStream_t st = (hipStream_t)stream;
   const float* m0 = feat_f0;
   const float* m1 = feat_f1;
-  if (layout == 0) {       // NCHW: channels-last copies first (coalesced on both sides)
-    float* s0 = (float*)scratch;
-    float* s1 = s0 + (size_t)N * 64 * Hf0 * Wf0;
-    hipLaunchKernelGGL(k_nchw_to_nhwc64, dim3((Wf0 + 63) / 64, Hf0, N), dim3(256), 0, st, feat_f0, s0, Hf0, Wf0);
+  if (layout == 0) {       // NCHW: a channels-last copy of image 1 (coalesced on both sides); image 0 is read as it is
+    float* s1 = (float*)scratch;
     hipLaunchKernelGGL(k_nchw_to_nhwc64, dim3((Wf1 + 63) / 64, Hf1, N), dim3(256), 0, st, feat_f1, s1, Hf1, Wf1);
-    m0 = s0; m1 = s1;
+    m1 = s1;
   }
   const int blocks = list_blocks(m_max);
-  if (W == 5)
-    hipLaunchKernelGGL(k_fine_maps<5>, dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, w0c, w1c,
-                       b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1);
-  else
-    hipLaunchKernelGGL(k_fine_maps<7>, dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, w0c, w1c,
-                       b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1);
+#define FM_FINE_MAPS_LAUNCH(WQ, N0)                                                                                      \
+  hipLaunchKernelGGL((k_fine_maps<WQ, N0>), dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, w0c,  \
+                     w1c, b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1)
+  if (W == 5) { if (layout == 0) FM_FINE_MAPS_LAUNCH(5, true); else FM_FINE_MAPS_LAUNCH(5, false); }
+  else { if (layout == 0) FM_FINE_MAPS_LAUNCH(7, true); else FM_FINE_MAPS_LAUNCH(7, false); }
+#undef FM_FINE_MAPS_LAUNCH
   return (int)hipGetLastError();
 }

@@ -18,6 +18,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kSkipLog2 = 32.f;    // terms more than 2^32 below every stabiliser are negligible (see coarse_sum_sparse.hip)
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
 constexpr unsigned FM_INT_SCREEN_OVERFLOW = 16u;
+constexpr unsigned FM_INT_LOOKBACK_TIMEOUT = 64u;   // k_select: a predecessor's total never showed up (reported as FM_DEV_INTERNAL)
 constexpr int kPrepSampleRows = 32;  // rows of an image every k_prep_split workgroup samples for the image's int8 step
 constexpr float kPrepHeadroom = 1.5f; // step = headroom * (largest |x| of the sample) / 127: what lies beyond is clipped
                                       // and accounted for in the screening margins (fm_device.h)
@@ -80,7 +81,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots);
 struct Scalars {          // lives at ws.scalars (zeroed per call)
   unsigned flags;         // FM_DEV_* bits
   int dense_units;        // 32x32 units the sparse sum kernel left to the dense one (0: that kernel exits at once)
-  int ticket;             // k_select: next logical workgroup index
+  int reserved;
 };
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----

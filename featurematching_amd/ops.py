@@ -74,6 +74,8 @@ class CoarseBuffers:
         maps and tie lists of image 0 and image 1 inside the workspace (valid while this object is alive);
         feed them to gather_windows(cells=...) for the cell-ordered crops."""
         lib = _lib.load()
+        if not getattr(self, '_has_cell_maps', True):
+            raise RuntimeError("this coarse call ran with cell_maps=False (FM_MODE_NO_CELL_MAPS)")
         n, l, s, c, slots = self._shape
         p0, p1, t0, t1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         q0, q1 = C.c_int(), C.c_int()
@@ -91,7 +93,8 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        thr: float = 0.2, border_rm: int = 2, temperature: float = 0.1,
                        scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
-                       conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False) -> CoarseBuffers:
+                       conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False,
+                       cell_maps: bool = True) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
@@ -99,7 +102,8 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     `dense` (FM_MODE_DENSE) adds the float16 planes and the dense sum kernel for samples with flat similarity (without
     it such samples report FM_E_DENSE through read_count), `exact_screening` (FM_MODE_EXACT_SCREENING) the two kernels
     that re-screen the candidates with exact softmax denominators (without it rows / columns that overflow their
-    candidate slots report FM_E_CANDIDATES)."""
+    candidate slots report FM_E_CANDIDATES).  cell_maps=False (FM_MODE_NO_CELL_MAPS) skips the cell -> match maps the
+    cell-ordered window crops read (CoarseBuffers.cell_maps() is then meaningless)."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -114,7 +118,8 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
         cap = n * min(l, s)
     if cand_slots is None:
         cand_slots = lib.fm_default_cand_slots(float(thr))
-    mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0)
+    mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
+           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS)
     nbytes = C.c_size_t(0)
     _lib.check(lib.fm_coarse_workspace_bytes_mode(n, l, s, c, cand_slots, mode, int(bool(conf_matrix)), C.byref(nbytes)),
                "fm_coarse_workspace_bytes_mode")
@@ -139,6 +144,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     _lib.check(st, "fm_coarse_match_dtype")
     out._keep = (f0, f1, sc0, sc1)   # inputs must outlive the enqueued kernels
     out._shape = (n, l, s, c, cand_slots)
+    out._has_cell_maps = bool(cell_maps)
     return out
 
 

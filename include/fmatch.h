@@ -47,15 +47,19 @@ enum fm_status {
   FM_E_RANGE = -7,       /* (device status) a descriptor is not finite or has |x| >= 32768, or the similarities are so
                             large (several thousand: |f0||f1| / (C*temperature)) that the int8 screening margin alone,
                             2^60 in the log2 domain, could overflow the float32 exponentials */
-  FM_E_DENSE = -8        /* (device status) a sample's similarity is flat (more significant entries per 32 x 32 unit
+  FM_E_DENSE = -8,       /* (device status) a sample's similarity is flat (more significant entries per 32 x 32 unit
                             than the sparse sum kernel resolves: an untrained network, textureless images); its result
                             is incomplete: call again with mode | FM_MODE_DENSE */
+  FM_E_INTERNAL = -9     /* (device status) the assignment kernel's bounded wait for its predecessor workgroups ran
+                            out (never observed; the outputs are incomplete): call again */
 };
 
 /* `mode` bits of fm_coarse_match / fm_coarse_workspace_bytes_mode (0 = the common path: 4 launches) */
 #define FM_MODE_EXACT_SCREENING 1 /* two more kernels re-screen the candidates with the exact softmax denominators */
 #define FM_MODE_DENSE 2           /* float16 planes + the dense sum kernel (float32-equivalent product on the matrix
                                      cores) for the samples the sparse sum kernel flags; both exit at once otherwise */
+#define FM_MODE_NO_CELL_MAPS 4    /* skip the cell -> match maps of fm_coarse_cell_maps (two returning atomics per match):
+                                     for callers that do not use the cell-ordered window crops */
 
 /* element type of the coarse descriptors handed to fm_coarse_match_dtype */
 enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
@@ -65,6 +69,7 @@ enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
 #define FM_DEV_CANDIDATES 2
 #define FM_DEV_RANGE 4
 #define FM_DEV_DENSE 8
+#define FM_DEV_INTERNAL 32
 
 int fm_version(void);
 const char* fm_strerror(int status);
@@ -238,9 +243,10 @@ int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t
  * windows, then fine_matching_new.py:50-79): for callers without fine-level context layers between the two.  The
  * window tensors never exist: with channels-last maps (layout 1: [N,Hf,Wf,64] storage - a window row is W*256
  * contiguous bytes) every window position of both images is one coalesced 256-byte load of the kernel that does
- * the arithmetic of fm_fine_match.  layout 0 (NCHW, the reference's) first makes channels-last copies of both maps
- * in `scratch` (fm_fine_maps_scratch_bytes bytes [dev], 16-byte aligned; 0 bytes / NULL for layout 1) with a
- * tiled transpose.  b_ids / i_ids / j_ids, d_count, mkpts*_c as the coarse stage left them; mix0 / mix1, scale_f,
+ * the arithmetic of fm_fine_match.  layout 0 (NCHW, the reference's): the windows of image 0 are read from the
+ * NCHW map as it is (the match list walks image 0 in raster order, which the NCHW window loader copes with); image 1,
+ * whose windows land wherever the partners are, first gets a channels-last copy in `scratch`
+ * (fm_fine_maps_scratch_bytes bytes [dev], 16-byte aligned; 0 bytes / NULL for layout 1) by a tiled transpose.  b_ids / i_ids / j_ids, d_count, mkpts*_c as the coarse stage left them; mix0 / mix1, scale_f,
  * out0 / out1 as in fm_fine_match.  Cf = 64, W in {5,7}.  Results equal fm_gather_windows + fm_fine_match bit for bit.
  */
 size_t fm_fine_maps_scratch_bytes(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout);

@@ -258,6 +258,21 @@ def test_flat_rows_with_conf_matrix_run_the_coarse_stage_once(monkeypatch):
     assert 2 <= n_first <= 3 and calls[0] is False and calls[n_first - 1] is True and calls[n_first:] == [True]
 
 
+def test_coarse_without_cell_maps_gives_the_same_matches():
+    """FM_MODE_NO_CELL_MAPS only drops the cell -> match maps (for callers that never run the cell-ordered crops)."""
+    f0, f1 = synth.coarse_descriptors(44, 2, 20 * 30, 128, "peaky")
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    a = ops.coarse_match_async(t0, t1, (20, 30), (20, 30), 8.0)
+    b = ops.coarse_match_async(t0, t1, (20, 30), (20, 30), 8.0, cell_maps=False)
+    ma, mb = a.read_count(), b.read_count()
+    assert ma == mb > 300
+    for k, v in a.sliced(ma).items():
+        assert torch.equal(v, b.sliced(mb)[k]), k
+    a.cell_maps()
+    with pytest.raises(RuntimeError):
+        b.cell_maps()
+
+
 def test_non_finite_input_is_reported():
     f0, f1 = synth.coarse_descriptors(42, 1, 64, 64, "peaky")
     f0[0, 3, 5] = np.inf
