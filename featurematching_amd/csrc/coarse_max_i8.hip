@@ -20,6 +20,8 @@
 // block per instruction), handed over by counted vmcnt + raw s_barrier; B fragments are read ahead through
 // inline-asm ds_read_b128 + counted lgkmcnt.  The LDS footprint (64 KiB) and < 100 VGPRs leave room for two
 // workgroups per CU.
+#include <type_traits>
+
 #include "fm_device.h"
 
 namespace fm {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   constexpr int PER_WAVE = PIECES >= 8 ? PIECES / 8 : 1;   // (C = 64: the 8 waves bring the 4 blocks twice - harmless)
   constexpr int PF = KS8 < 4 ? KS8 : 4;             // B-fragment read-ahead
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ unsigned s_colmax[2 * 64];             // per tile parity: q_encode'd column maxima of 64 columns (ds_max_u32)
+  __shared__ unsigned s_colmax[3 * 64];             // per tile (mod 3): q_encode'd column maxima of 64 columns (ds_max_u32)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
     for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
   }
   const unsigned colmax_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)s_colmax;
-  if (tid < 128) asm volatile("ds_write_b32 %0, %1" ::"v"(colmax_a + tid * 4), "v"(0u) : "memory");
+  if (tid < 192) asm volatile("ds_write_b32 %0, %1" ::"v"(colmax_a + tid * 4), "v"(0u) : "memory");
 
   int rstat[16];                 // running maxima of q_i . q_j over the columns this lane has seen
 #pragma unroll
@@ -131,36 +133,6 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   const bool row_edge = wrow0 + 32 > a.L;       // wave-uniform
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  v16i acc;
-  auto mfma_unit = [&](int u) {
-    const unsigned base = lds0 + (((u >> 1) - t0) % NBUF) * TILE_BYTES + (u & 1) * (KS8 * 1024) + lane * 16;
-    constexpr int RING = PF + 1;
-    v4i bq[RING];
-    auto issue = [&](int ks) {
-      asm volatile("ds_read_b128 %0, %1" : "=v"(bq[ks % RING]) : "v"(base + (unsigned)(ks * 1024)));
-    };
-#pragma unroll
-    for (int ks = 0; ks < PF && ks < KS8; ++ks) issue(ks);
-#pragma unroll
-    for (int ks = 0; ks < KS8; ++ks) {
-      if (ks + PF < KS8) issue(ks + PF);
-      const int ahead = (KS8 - 1 - ks) < PF ? (KS8 - 1 - ks) : PF;     // k-steps issued beyond ks
-      if (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[ks % RING]));
-      else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[ks % RING]));
-      else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bq[ks % RING]));
-      else if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bq[ks % RING]));
-      else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[ks % RING]));
-      static_assert(PF <= 4, "lgkmcnt ladder above covers at most 4 reads in flight");
-      if (ks == 0) {
-        v16i z;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) z[g] = 0;
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks % RING], z, 0, 0, 0);
-      } else {
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks % RING], acc, 0, 0, 0);
-      }
-    }
-  };
 
   auto tile_barrier = [&](int tiles_after) {
     if (tiles_after <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -177,50 +149,120 @@ __global__ __launch_bounds__(512) void k_max_i8(MaxArgs a) {
   dg_pro = __builtin_amdgcn_s_memtime() - dg0;
 #endif
 
-  for (int u = 2 * t0; u < 2 * t1; ++u) {
-    const int t = u >> 1, par = (t - t0) & 1;
-    if ((u & 1) == 0 && t + NBUF - 1 < t1) { DG_T0 stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF); DG_ADD(dg_stage) }   // refill the slot of tile t-1
-    { DG_T0 mfma_unit(u); asm volatile("" ::"v"(acc)); DG_ADD(dg_mfma) }
-#ifdef FM_DIAG_CLOCK
-    const unsigned long long dg_e0 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- epilogue: rows in registers, columns on lanes; integers only ----
-    const int ucol0 = u * 32;
-    if (row_edge || ucol0 + 32 > a.S) {              // padded rows (>= L) / columns (>= S) never count
-      const bool cok = ucol0 + r < a.S;
+  // every wave's column maxima of tile t are in LDS once a barrier separates this from their epilogues: the wave whose
+  // turn it is publishes them and clears the words for tile t + 3
+  auto fold_columns = [&](int t) {
+    if (wv != (t & 7)) return;
+    const unsigned ad = colmax_a + (((t - t0) % 3) * 64 + lane) * 4;
+    unsigned cv;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(ad) : "memory");
+    asm volatile("ds_write_b32 %0, %1" ::"v"(ad), "v"(0u) : "memory");
+    if (t * kTileCols + lane < a.S && cv != 0u)
+      __hip_atomic_fetch_max(a.colmax_u + (long)b * a.Sp + t * kTileCols + lane, cv, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  // Software pipeline over the units, written out instruction slot by instruction slot: the 8 MFMAs of the NEXT unit
+  // (accumulator `an`) with one slice of the epilogue of the CURRENT unit (accumulator `ac`: rows in registers, columns
+  // on lanes; integers only) behind each of them - a wave issues in order, so the ~45 integer instructions of an
+  // epilogue only run under the matrix core's 32 cycles per MFMA if they sit between the MFMAs in program order
+  // (sched_barrier keeps hipcc from regrouping them).  Slices: padding masks | row maxima (2) | column maximum tree |
+  // halves | LDS column maximum | unit maximum (DPP) | its store.
+  auto pipe = [&](auto do_next, auto do_cur, int un, v16i& an, int uc, v16i& ac) {
+    constexpr bool DN = decltype(do_next)::value, DC = decltype(do_cur)::value;
+    const unsigned base = lds0 + (((un >> 1) - t0) % NBUF) * TILE_BYTES + (un & 1) * (KS8 * 1024) + lane * 16;
+    constexpr int RING = PF + 1;
+    v4i bq[RING];
+    auto issue = [&](int ks) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(bq[ks % RING]) : "v"(base + (unsigned)(ks * 1024)));
+    };
+    int cstat = 0, um = 0;
+    auto slice = [&](int sl) {
+      if (sl == 0) {
+        const int ucol0 = uc * 32;
+        if (row_edge || ucol0 + 32 > a.S) {              // padded rows (>= L) / columns (>= S) never count
+          const bool cok = ucol0 + r < a.S;
 #pragma unroll
-      for (int g = 0; g < 16; ++g)
-        if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) acc[g] = kQMasked;
-    }
+          for (int g = 0; g < 16; ++g)
+            if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) ac[g] = kQMasked;
+        }
+      } else if (sl == 1) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) rstat[g] = max(rstat[g], acc[g]);
-    int c01 = max(max(acc[0], acc[1]), acc[2]), c23 = max(max(acc[3], acc[4]), acc[5]);
-    int c45 = max(max(acc[6], acc[7]), acc[8]), c67 = max(max(acc[9], acc[10]), acc[11]);
-    int c89 = max(max(acc[12], acc[13]), acc[14]);
-    int cstat = max(max(max(c01, c23), c45), max(max(c67, c89), acc[15]));
-    cstat = halves_max_i(cstat);                                     // this lane's column over the wave's 32 rows
-    if (h == 0)                                                       // the 8 waves' maxima of a column meet in LDS
-      asm volatile("ds_max_u32 %0, %1" ::"v"(colmax_a + (par * 64 + (u & 1) * 32 + r) * 4), "v"(q_encode(cstat)) : "memory");
-    const int um = half_max32_hi_i(cstat);                           // unit maximum (lanes 16..31, 48..63)
-    if (lane == 63) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * nunits + u] = (float)um;
-#ifdef FM_DIAG_CLOCK
-    dg_epi += __builtin_amdgcn_s_memtime() - dg_e0;
-#endif
-    if (u & 1) {
-      // tile t consumed by every wave; tile t+1 landed; tiles t+2.. of the ring stay in flight
-      { DG_T0 tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1)); DG_ADD(dg_bar) }
-      if (wv == (t & 7)) {
-        // every wave's column maxima of tile t are in LDS (their ds_max precede the barrier): this wave publishes them
-        // and clears the words for tile t+2 (whose first ds_max follows the next barrier, which this wave joins after
-        // its write has completed: tile_barrier waits lgkmcnt(0))
-        unsigned cv;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cv) : "v"(colmax_a + (par * 64 + lane) * 4) : "memory");
-        asm volatile("ds_write_b32 %0, %1" ::"v"(colmax_a + (par * 64 + lane) * 4), "v"(0u) : "memory");
-        if (t * kTileCols + lane < a.S && cv != 0u)
-          __hip_atomic_fetch_max(a.colmax_u + (long)b * a.Sp + t * kTileCols + lane, cv, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
+        for (int g = 0; g < 8; ++g) rstat[g] = max(rstat[g], ac[g]);
+      } else if (sl == 2) {
+#pragma unroll
+        for (int g = 8; g < 16; ++g) rstat[g] = max(rstat[g], ac[g]);
+      } else if (sl == 3) {
+        const int c01 = max(max(ac[0], ac[1]), ac[2]), c23 = max(max(ac[3], ac[4]), ac[5]);
+        const int c45 = max(max(ac[6], ac[7]), ac[8]), c67 = max(max(ac[9], ac[10]), ac[11]);
+        const int c89 = max(max(ac[12], ac[13]), ac[14]);
+        cstat = max(max(max(c01, c23), c45), max(max(c67, c89), ac[15]));
+      } else if (sl == 4) {
+        cstat = halves_max_i(cstat);                                 // this lane's column over the wave's 32 rows
+      } else if (sl == 5) {
+        if (h == 0)                                                   // the 8 waves' maxima of a column meet in LDS
+          asm volatile("ds_max_u32 %0, %1" ::"v"(colmax_a + ((((uc >> 1) - t0) % 3) * 64 + (uc & 1) * 32 + r) * 4),
+                       "v"(q_encode(cstat)) : "memory");
+      } else if (sl == 6) {
+        um = half_max32_hi_i(cstat);                                 // unit maximum (lanes 16..31, 48..63)
+      } else {
+        if (lane == 63) a.umax[((long)b * (a.Lp / 32) + wrow0 / 32) * nunits + uc] = (float)um;
       }
+    };
+    if (DN) {
+#pragma unroll
+      for (int ks = 0; ks < PF && ks < KS8; ++ks) issue(ks);
     }
+#pragma unroll
+    for (int ks = 0; ks < KS8; ++ks) {
+      if (DN) {
+        if (ks + PF < KS8) issue(ks + PF);
+        const int ahead = (KS8 - 1 - ks) < PF ? (KS8 - 1 - ks) : PF;     // k-steps issued beyond ks
+        if (ahead == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[ks % RING]));
+        else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[ks % RING]));
+        else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bq[ks % RING]));
+        else if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bq[ks % RING]));
+        else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bq[ks % RING]));
+        static_assert(PF <= 4, "lgkmcnt ladder above covers at most 4 reads in flight");
+        if (ks == 0) {
+          v16i z;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) z[g] = 0;
+          an = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks % RING], z, 0, 0, 0);
+        } else {
+          an = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks % RING], an, 0, 0, 0);
+        }
+      }
+      if (DC) {        // the epilogue slices of this k-step (8 slices over KS8 steps)
+#pragma unroll
+        for (int sl = ks * 8 / KS8; sl < (ks + 1) * 8 / KS8; ++sl) slice(sl);
+      }
+      if (DN && DC) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  // Per tile t (units 2t in accA, 2t+1 in accB):
+  //   refill the ring slot of tile t-1 | MFMAs(2t+1) -> B with the epilogue of 2t (A) between them |
+  //   barrier: every wave has read tile t, tile t+1 has landed | publish tile t-1's column maxima |
+  //   MFMAs(2t+2) -> A with the epilogue of 2t+1 (B) between them
+  v16i accA, accB;
+  if (t0 < t1) pipe(T_{}, F_{}, 2 * t0, accA, 0, accB);
+  for (int t = t0; t < t1; ++t) {
+    if (t + NBUF - 1 < t1) { DG_T0 stage(t + NBUF - 1, (t - t0 + NBUF - 1) % NBUF); DG_ADD(dg_stage) }
+    { DG_T0 pipe(T_{}, T_{}, 2 * t + 1, accB, 2 * t, accA); DG_ADD(dg_mfma) }
+    { DG_T0 tile_barrier(min(t + NBUF - 1, t1 - 1) - (t + 1)); DG_ADD(dg_bar) }
+    if (t > t0) fold_columns(t - 1);
+    { DG_T0
+      if (t + 1 < t1) pipe(T_{}, T_{}, 2 * t + 2, accA, 2 * t + 1, accB);
+      else pipe(F_{}, T_{}, 0, accA, 2 * t + 1, accB);
+      DG_ADD(dg_epi) }
+  }
+  if (t0 < t1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fold_columns(t1 - 1);
   }
 
 #ifdef FM_DIAG_CLOCK
