@@ -132,9 +132,13 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   int* s_tc = reinterpret_cast<int*>(s_dyn + a.units_s * 32);
   float* s_colacc = s_dyn + 2 * a.units_s * 32;
   const int cpitch = a.units_s * 32;
-  __shared__ int s_list[8][LIST];              // (unit << 10) | (row in wave << 5) | column in unit
-  __shared__ int s_qkey[8][kSparseQueue];
+  __shared__ int s_list[8][LIST];              // (row block << 16) | (unit << 10) | (row in block << 5) | column in unit
+  __shared__ int s_qkey[8][kSparseQueue];      // candidate queue: row inside the panel, column, dot product
+  __shared__ int s_qcol[8][kSparseQueue];
   __shared__ float s_qx[8][kSparseQueue];
+  __shared__ unsigned long long s_mask[8];     // live units of the 8 waves' row blocks
+  __shared__ float s_nmr[8][32];               // -stabiliser*log2e of the 8 waves' rows
+  __shared__ float s_rowacc[8 * kPanelRows];   // per wave: row sums of the entries it resolved, all 256 rows of the panel
 
   // ---- everything the decisions below depend on is requested at once (ONE memory round trip: every load below is
   // issued before the first use of any of them; indices are clamped instead of predicated so that no load sits behind
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
   }
   for (int c = lane; c < U * 32; c += 64) s_colacc[wv * cpitch + c] = 0.f;
+  for (int c = lane; c < kPanelRows; c += 64) s_rowacc[wv * kPanelRows + c] = 0.f;
 
   float l1A_max = 0.f, l1B_max = 0.f, clipA = 0.f, clipB = 0.f;     // image maxima (every wave folds them itself)
 #pragma unroll
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   const float emu_rows = margin_log2(q8_margin_raw(sig0, bl1A, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
   if (h == 0) {
     s_tr[wv][r] = sig_threshold(nm_lane, emu_rows, inv_kss);
+    s_nmr[wv][r] = nm_lane;
     if (split == 0) a.nmr[gi] = nm_lane;
   }
   // padded rows (>= L) never contribute: keep them out of the wave's largest stabiliser
@@ -242,124 +248,154 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     const float top = __builtin_fmaf(um, kss, emu_lane);          // >= k * (exact product), log2 domain
     hot = !screen_ok || !((top + wmax_nmr < -kSkipLog2) && (top + s_cmax[lane] < -kSkipLog2));
   }
-  unsigned long long mask = __ballot(hot);          // wave-uniform
-  if (lane == 0) s_hot[wv] = __builtin_popcountll(mask);
+  const unsigned long long own_mask = __ballot(hot);          // wave-uniform
+  if (lane == 0) s_mask[wv] = own_mask;
   __syncthreads();
+  // ---- the live units of the WHOLE workgroup, dealt out in equal shares ----
+  // A wave's own row block holds between 0 and ~2.5x the average number of live units (each is ~1.7k cycles of
+  // dependent loads + MFMAs + screening, and the workgroup ends with its slowest wave), so the (row block, unit)
+  // pairs of the workgroup are put in one order - row block major - and wave w takes the w-th share of
+  // ceil(total / 8).  A share is one run of that order: it lies in one or two (rarely more) row blocks; for a row
+  // block that is not its own a wave loads that block's A fragments and thresholds.  Which wave handles what is a
+  // function of the data only: all sums are still formed in a fixed order.
+  unsigned long long masks[8];
   int tot = 0;
 #pragma unroll
-  for (int w8 = 0; w8 < 8; ++w8) tot += s_hot[w8];
-  unsigned long long dmask = 0;  // units left to the dense kernel
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const unsigned long long m = s_mask[w8];
+    masks[w8] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    tot += __builtin_popcountll(masks[w8]);
+  }
   // more than half of a block of >= 64 units is alive: flat similarity, a matrix-core job (a small block - a tiny
   // image, a one-unit split - is cheap to sweep whatever is alive, and truly flat units still overflow kMaxExact below)
-  if ((tot * 2 > 8 * U && 8 * U >= 64) || !screen_ok) {
-    dmask = mask;
-    mask = 0;
-  }
+  const bool flat = (tot * 2 > 8 * U && 8 * U >= 64) || !screen_ok;
+  int nd_units = flat ? __builtin_popcountll(own_mask) : 0;      // units this wave leaves to the dense kernel
 
   int nlist = 0;                 // parked significant entries (wave-uniform)
   DIAG_STAMP(2)
 #ifdef FM_DIAG_CLOCK
-  const int diag_units = __builtin_popcountll(mask);
+  int diag_units = 0;
   dg[3] = dg[2];
 #endif
-  if (mask) {
-    const bool row_edge = (wrow0 + 32 > a.L);
-    // this lane's 16 row thresholds (rows 8q + 4h + 0..3 of the wave's 32): loop invariant, four 16-byte LDS reads
-    int trr[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int4 t4 = *reinterpret_cast<const int4*>(&s_tr[wv][8 * q + 4 * h]);
-      trr[4 * q] = t4.x; trr[4 * q + 1] = t4.y; trr[4 * q + 2] = t4.z; trr[4 * q + 3] = t4.w;
-    }
-
-    // B fragments of three units: while one feeds the MFMA chain the next two units' 16 KiB are in flight (a unit's
-    // 8 KiB come from L2 or beyond: with one unit of read-ahead every unit waited for its fragments)
+  if (!flat && tot) {
+    const int chunk = (tot + 7) >> 3, lo = wv * chunk, hi = min(tot, lo + chunk);
+    int cur_k = wv;                // row block whose A fragments sit in aq
+    int trr[16];                   // this lane's 16 row thresholds of the current row block (rows 8q + 4h + 0..3)
     v4i bq0[KS8], bq1[KS8], bq2[KS8];
-    auto load_b = [&](v4i (&bq)[KS8], int ul) {
-      const signed char* src = a.q1 + (((long)b * nunits + u0 + ul) * KS8 * 64 + lane) * 16;
-#pragma unroll
-      for (int ks = 0; ks < KS8; ++ks) bq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
-    };
-    auto unit = [&](const v4i (&bq)[KS8], int ul) {
-      const int ucol0 = (u0 + ul) * 32;
-      v16i acc;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc[g] = 0;
-#pragma unroll
-      for (int ks = 0; ks < KS8; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks], acc, 0, 0, 0);
-      if (row_edge || ucol0 + 32 > a.S) {              // padded rows (>= L) / columns (>= S) never count
-        const bool cok = ucol0 + r < a.S;
-#pragma unroll
-        for (int g = 0; g < 16; ++g)
-          if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) acc[g] = kQMasked;
-      }
-      // significance: the integer product beats the row's or the column's threshold (k x~ + margin within 2^32 of
-      // that stabiliser).  Two integer instructions per accumulator register write the wave's mask straight to
-      // scalar registers; the (rare) significant entries are parked at once, in (register, lane) order, and taken
-      // back if the unit turns out to have too many of them (flat similarity: the dense kernel's job).
-      const int tcl = s_tc[ul * 32 + r];
-      const int nlist0 = nlist;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        unsigned long long m = __ballot(acc[g] > min(trr[g], tcl));
-        while (m) {                    // wave-uniform, usually not entered
-          const int l = __builtin_ctzll(m);
-          m &= m - 1;
-          const int rl = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-          if (lane == 0 && nlist < LIST) s_list[wv][nlist] = (ul << 10) | (rl << 5) | (l & 31);
-          ++nlist;
-        }
-      }
-      if (nlist - nlist0 > kMaxExact || nlist > LIST) { nlist = nlist0; dmask |= 1ull << ul; }
-    };
-    // the unit after next (or `cur` again when there is none: the prefetch is UNCONDITIONAL - behind a branch hipcc has
-    // to assume the shorter path at the join and waits vmcnt(0) in front of the MFMA chain, i.e. for the prefetch it
-    // has just issued; measured 2.5k cycles per unit instead of ~1k)
-    auto after_next = [](unsigned long long m, int cur) {
-      const unsigned long long m2 = m & (m - 1);
-      return m2 ? __builtin_ctzll(m2) : (m ? __builtin_ctzll(m) : cur);
-    };
-    {
-      const int first = __builtin_ctzll(mask);
-      load_b(bq0, first);
-      const unsigned long long m1 = mask & (mask - 1);
-      load_b(bq1, m1 ? __builtin_ctzll(m1) : first);
-    }
+    int base = 0;
+    for (int k = 0; k < 8 && base < hi; ++k) {
+      const int ck = __builtin_popcountll(masks[k]);
+      const int first = max(lo - base, 0), keep = min(hi, base + ck) - max(lo, base);
+      base += ck;
+      if (keep <= 0) continue;
+      unsigned long long mask = masks[k];
+      for (int d = 0; d < first; ++d) mask &= mask - 1;                       // drop the units of earlier shares
+      { unsigned long long sub = 0, t2 = mask;                                // ... and of later ones
+        for (int c = 0; c < keep; ++c) { sub |= t2 & (0 - t2); t2 &= t2 - 1; }
+        mask = sub; }
 #ifdef FM_DIAG_CLOCK
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    DIAG_STAMP(3)
+      diag_units += __builtin_popcountll(mask);
 #endif
-    while (mask) {
-      const int ua = __builtin_ctzll(mask);
-      mask &= mask - 1;                              // bq1 holds ctz(mask) now
-      load_b(bq2, after_next(mask, ua));
-      unit(bq0, ua);
-      if (!mask) break;
-      const int ub = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      load_b(bq0, after_next(mask, ub));
-      unit(bq1, ub);
-      if (!mask) break;
-      const int uc = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      load_b(bq1, after_next(mask, uc));
-      unit(bq2, uc);
+      const int wrow0k = (panel * 8 + k) * 32;
+      const bool row_edge = (wrow0k + 32 > a.L);
+      // B fragments of three units: while one feeds the MFMA chain the next two units' 16 KiB are in flight
+      auto load_b = [&](v4i (&bq)[KS8], int ul) {
+        const signed char* src = a.q1 + (((long)b * nunits + u0 + ul) * KS8 * 64 + lane) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS8; ++ks) bq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
+      };
+      // the unit after next (or `cur` again when there is none: the prefetch is UNCONDITIONAL - behind a branch hipcc
+      // has to assume the shorter path at the join and waits vmcnt(0) in front of the MFMA chain, i.e. for the
+      // prefetch it has just issued; measured 2.5k cycles per unit instead of ~1k)
+      auto after_next = [](unsigned long long m, int cur) {
+        const unsigned long long m2 = m & (m - 1);
+        return m2 ? __builtin_ctzll(m2) : (m ? __builtin_ctzll(m) : cur);
+      };
+      {
+        const int first_u = __builtin_ctzll(mask);
+        load_b(bq0, first_u);
+        const unsigned long long m1 = mask & (mask - 1);
+        load_b(bq1, m1 ? __builtin_ctzll(m1) : first_u);
+      }
+      if (k != cur_k) {            // another wave's row block: its A fragments (the thresholds are in LDS)
+        const signed char* src = a.q0 + (((long)b * a.Lp + wrow0k) / 32 * KS8 * 64 + lane) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
+        cur_k = k;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int4 t4 = *reinterpret_cast<const int4*>(&s_tr[k][8 * q + 4 * h]);
+        trr[4 * q] = t4.x; trr[4 * q + 1] = t4.y; trr[4 * q + 2] = t4.z; trr[4 * q + 3] = t4.w;
+      }
+      auto unit = [&](const v4i (&bq)[KS8], int ul) {
+        const int ucol0 = (u0 + ul) * 32;
+        v16i acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0;
+#pragma unroll
+        for (int ks = 0; ks < KS8; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks], acc, 0, 0, 0);
+        if (row_edge || ucol0 + 32 > a.S) {              // padded rows (>= L) / columns (>= S) never count
+          const bool cok = ucol0 + r < a.S;
+#pragma unroll
+          for (int g = 0; g < 16; ++g)
+            if (!cok || wrow0k + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) acc[g] = kQMasked;
+        }
+        // significance: the integer product beats the row's or the column's threshold (k x~ + margin within 2^32 of
+        // that stabiliser).  Two integer instructions per accumulator register write the wave's mask straight to
+        // scalar registers; the (rare) significant entries are parked at once, in (register, lane) order, and taken
+        // back if the unit turns out to have too many of them (flat similarity: the dense kernel's job).
+        const int tcl = s_tc[ul * 32 + r];
+        const int nlist0 = nlist;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          unsigned long long m = __ballot(acc[g] > min(trr[g], tcl));
+          while (m) {                    // wave-uniform, usually not entered
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int rl = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+            if (lane == 0 && nlist < LIST) s_list[wv][nlist] = (k << 16) | (ul << 10) | (rl << 5) | (l & 31);
+            ++nlist;
+          }
+        }
+        if (nlist - nlist0 > kMaxExact || nlist > LIST) { nlist = nlist0; ++nd_units; }
+      };
+#ifdef FM_DIAG_CLOCK
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (dg[3] == dg[2]) { DIAG_STAMP(3) }
+#endif
+      while (mask) {
+        const int ua = __builtin_ctzll(mask);
+        mask &= mask - 1;                              // bq1 holds ctz(mask) now
+        load_b(bq2, after_next(mask, ua));
+        unit(bq0, ua);
+        if (!mask) break;
+        const int ub = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        load_b(bq0, after_next(mask, ub));
+        unit(bq1, ub);
+        if (!mask) break;
+        const int uc = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        load_b(bq1, after_next(mask, uc));
+        unit(bq2, uc);
+      }
     }
   }
 
   // ---- the parked entries: exact float32 dot products of the caller's descriptors, eight entries (sixteen row
   // loads per lane) in flight; sums in list order (deterministic) ----
-  float racc = 0.f;              // lanes 0..31: sum_j exp2(k x - m^) of row wrow0 + lane over this range
   int qn = 0;                    // parked candidates (wave-uniform)
   DIAG_STAMP(4)
   // a candidate goes to its row's AND its column's slot list (k_select takes the row best from the one, the column
-  // best from the other, without a grid-wide pass in between)
-  auto record = [&](int rl, int col, float x) {
-    const long grow = (long)b * a.Lp + wrow0 + rl, gcol = (long)b * a.Sp + col;
+  // best from the other, without a grid-wide pass in between); rp = row inside the panel
+  auto record = [&](int rp, int col, float x) {
+    const long grow = (long)b * a.Lp + panel * kPanelRows + rp, gcol = (long)b * a.Sp + col;
     const int pos = atomicAdd(&a.cand_count[grow], 1);
     const int cpos = atomicAdd(&a.ccand_count[gcol], 1);
     if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = col; a.cand_x[grow * a.slots + pos] = x; }
-    if (cpos < a.slots) { a.ccand_i[gcol * a.slots + cpos] = wrow0 + rl; a.ccand_x[gcol * a.slots + cpos] = x; }
+    if (cpos < a.slots) { a.ccand_i[gcol * a.slots + cpos] = panel * kPanelRows + rp; a.ccand_x[gcol * a.slots + cpos] = x; }
     if (pos >= a.slots || cpos >= a.slots) atomicOr(&a.scal->flags, (unsigned)FM_INT_SCREEN_OVERFLOW);
   };
   constexpr int EB = 8;          // entries per batch: 16 row loads per lane in flight
@@ -370,8 +406,8 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     for (int q = 0; q < EB; ++q) {
       if (e0 + q >= nlist) break;                 // wave-uniform
       key[q] = __builtin_amdgcn_readfirstlane(s_list[wv][e0 + q]);
-      const int rl = (key[q] >> 5) & 31, col = (u0 + (key[q] >> 10)) * 32 + (key[q] & 31);
-      const long ro = ((long)b * a.L + wrow0 + rl) * a.c_in, co = ((long)b * a.S + col) * a.c_in;
+      const int rp = (key[q] >> 16) * 32 + ((key[q] >> 5) & 31), col = (u0 + ((key[q] >> 10) & 63)) * 32 + (key[q] & 31);
+      const long ro = ((long)b * a.L + panel * kPanelRows + rp) * a.c_in, co = ((long)b * a.S + col) * a.c_in;
       const bool in = lane * 4 < a.c_in;
       av[q] = bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in && a.in_dtype == FM_F32) {
@@ -395,19 +431,21 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 #pragma unroll
     for (int q = 0; q < EB; ++q) {
       if (e0 + q >= nlist) break;
-      const int ul = key[q] >> 10, rl = (key[q] >> 5) & 31, cl = key[q] & 31;
-      const float nr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm_lane), rl));
+      const int kk2 = key[q] >> 16, ul = (key[q] >> 10) & 63, rl = (key[q] >> 5) & 31, cl = key[q] & 31;
+      const float nr = s_nmr[kk2][rl];
       const float nc = s_nmc[ul * 32 + cl];
       const float rr = __builtin_fmaf(x[q], a.k, nr);
       const float cc = __builtin_fmaf(x[q], a.k, nc);
-      racc += (lane == rl) ? __builtin_amdgcn_exp2f(rr) : 0.f;
-      if (lane == 0) s_colacc[wv * cpitch + ul * 32 + cl] += __builtin_amdgcn_exp2f(cc);
+      if (lane == 0) {
+        s_rowacc[wv * kPanelRows + kk2 * 32 + rl] += __builtin_amdgcn_exp2f(rr);
+        s_colacc[wv * cpitch + ul * 32 + cl] += __builtin_amdgcn_exp2f(cc);
+      }
       if (rr > a.lt && cc > a.lt) {                     // wave-uniform: a candidate (superset of conf > thr)
         const int col = (u0 + ul) * 32 + cl;
         if (qn < kSparseQueue) {
-          if (lane == 0) { s_qkey[wv][qn] = (col << 5) | rl; s_qx[wv][qn] = x[q]; }
+          if (lane == 0) { s_qkey[wv][qn] = kk2 * 32 + rl; s_qcol[wv][qn] = col; s_qx[wv][qn] = x[q]; }
         } else if (lane == 0) {                         // queue full: straight to the slot lists
-          record(rl, col, x[q]);
+          record(kk2 * 32 + rl, col, x[q]);
         }
         ++qn;
       }
@@ -415,18 +453,14 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   }
 
   DIAG_STAMP(5)
-  // ---- results of this wave: row partial, dense flags, candidates ----
-  if (lane < 32) a.rowS[((long)b * a.splits + split) * a.Lp + wrow0 + lane] = racc;
+  // ---- results of this wave: candidates, dense flags ----
   {
     const int nq = min(qn, kSparseQueue);
-    if (lane < nq) {
-      const int key = s_qkey[wv][lane];
-      record(key & 31, key >> 5, s_qx[wv][lane]);
-    }
+    if (lane < nq) record(s_qkey[wv][lane], s_qcol[wv][lane], s_qx[wv][lane]);
   }
-  // ---- the workgroup's dense-unit count (one atomic per workgroup) and its column partial: the 8 waves'
+  // ---- the workgroup's dense-unit count (one atomic per workgroup) and its row / column partials: the 8 waves'
   // accumulators folded in a fixed order ----
-  if (lane == 0) s_hot[wv] = __builtin_popcountll(dmask);
+  if (lane == 0) s_hot[wv] = nd_units;
   __syncthreads();
   if (tid == 0) {
     int nd = 0;
@@ -438,12 +472,18 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
       if (!a.dense_enabled) atomicOr(&a.scal->flags, (unsigned)FM_DEV_DENSE);   // nobody will redo this sample
     }
   }
+  if (tid < kPanelRows) {
+    float s2 = s_rowacc[tid];
+#pragma unroll
+    for (int w8 = 1; w8 < 8; ++w8) s2 += s_rowacc[w8 * kPanelRows + tid];
+    a.rowS[((long)b * a.splits + split) * a.Lp + panel * kPanelRows + tid] = s2;
+  }
   float* co = a.colS + ((long)b * a.panels + panel) * a.Sp + u0 * 32;
   for (int c = tid; c < U * 32; c += 512) {
-    float s = s_colacc[c];
+    float s2 = s_colacc[c];
 #pragma unroll
-    for (int w8 = 1; w8 < 8; ++w8) s += s_colacc[w8 * cpitch + c];
-    co[c] = s;
+    for (int w8 = 1; w8 < 8; ++w8) s2 += s_colacc[w8 * cpitch + c];
+    co[c] = s2;
   }
 #ifdef FM_DIAG_CLOCK
   DIAG_STAMP(6)
