@@ -109,45 +109,61 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   const float* rowP = dense ? a.rowB : a.rowS;
   const float* colP = dense ? a.colB : a.colS;
   const int rparts = dense ? a.splits : a.splits_s;
-  // Every load below that does not depend on a loaded value is issued before the first use of any of them: this
-  // row's candidate count, candidate slot (speculatively: a slot beyond the count is ignored), stabiliser and the
-  // partial sums of its softmax denominator - one memory round trip; the column's statistics follow in a second one.
+  // The `slots` lanes of a row work TOGETHER on the row's candidates (usually one): lane s of the group loads the
+  // partial sums s, s + slots, ... of a denominator and the group adds the lanes' shares in lane order - one load per
+  // lane and round trip instead of every lane folding every partial (most lanes hold empty candidate slots), and a
+  // fixed order that every group evaluating the same row or column reproduces bit for bit.
   const bool row_ok = b < a.N && i < a.L;
   const long grow_c = row_ok ? grow : 0;                      // (clamped: no load behind a branch)
+  const int b_c = row_ok ? b : 0, i_c = row_ok ? i : 0;
+  const int base = lane - slot;                               // first lane of this row's group
+  auto group_sum = [&](float v) {                             // v of lane base, + base+1, ... in that order
+    float t = 0.f;
+    for (int q = 0; q < a.slots; ++q) t += __shfl(v, base + q);
+    return t;
+  };
+  auto share = [&](const float* p, int n, long pitch) {       // this lane's share of n partials `pitch` apart
+    float t = 0.f;
+    for (int q = slot; q < n; q += a.slots) t += p[(long)q * pitch];
+    return t;
+  };
+  // round trip 1: candidate count, this lane's candidate slot (speculatively), stabiliser, the row's denominator
   const int cnt_raw = cand_count[grow_c];
   const int j_raw = cand_j[grow_c * a.slots + slot];
-  const float x = cand_x[grow_c * a.slots + slot];
+  const float x_raw = cand_x[grow_c * a.slots + slot];
   const float nmr_i = a.nmr[grow_c];
-  const int b_c = row_ok ? b : 0, i_c = row_ok ? i : 0;
-  const float rs = fold_partials(rowP + (long)b_c * rparts * a.Lp + i_c, rparts, a.Lp);
+  const float rs = group_sum(share(rowP + (long)b_c * rparts * a.Lp + i_c, rparts, a.Lp));
   const int cnt = row_ok ? min(cnt_raw, a.slots) : 0;
   const bool live = slot < cnt;
   bool keep = false;
   int j = live ? j_raw : 0x7fffffff;
   float conf = 0.f, colbest = 0.f;
-  {
-    const int jc = live ? j_raw : 0;
-    const long gcol = (long)b_c * a.Sp + jc;
-    // the column's denominator and its candidate list (this entry among them), each with its own row's denominator
-    const float cs = fold_partials(colP + (long)b_c * a.panels * a.Sp + jc, a.panels, a.Sp);
-    const float nmc = a.nmc[gcol];
-    const int ccnt_raw = ccand_count[gcol];
-    int ci[2]; float cx[2];                                    // the first two column candidates, speculatively
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { ci[t] = ccand_i[gcol * a.slots + t]; cx[t] = ccand_x[gcol * a.slots + t]; }
-    if (live) {
-      conf = entry_conf(x, a.k, nmr_i, rs, nmc, cs);
-      const int ccnt = min(ccnt_raw, a.slots);
-      for (int t = 0; t < ccnt; ++t) {
-        const int i2 = t < 2 ? ci[t] : ccand_i[gcol * a.slots + t];
-        float c2 = conf;
-        if (i2 != i) {
-          const float x2 = t < 2 ? cx[t] : ccand_x[gcol * a.slots + t];
-          const float rs2 = fold_partials(rowP + (long)b * rparts * a.Lp + i2, rparts, a.Lp);
-          c2 = entry_conf(x2, a.k, a.nmr[(long)b * a.Lp + i2], rs2, nmc, cs);
+  for (int t = 0; t < a.slots; ++t) {                         // candidate t of every row of the wave that has one
+    if (!__any(t < cnt)) break;                               // wave-uniform
+    if (t < cnt) {                                            // (a row's lanes take this branch together)
+      const int jt = __shfl(j_raw, base + t);
+      const float xt = __shfl(x_raw, base + t);
+      const long gcol = (long)b_c * a.Sp + jt;
+      // round trip 2: the column's denominator (shared fold), stabiliser, and its candidate list - lane s the s-th entry
+      const float cpart = share(colP + (long)b_c * a.panels * a.Sp + jt, a.panels, a.Sp);
+      const float nmc = a.nmc[gcol];
+      const int ccnt = min(ccand_count[gcol], a.slots);
+      const int ci = ccand_i[gcol * a.slots + slot];
+      const float cx = ccand_x[gcol * a.slots + slot];
+      const float cs = group_sum(cpart);
+      const float ct = entry_conf(xt, a.k, nmr_i, rs, nmc, cs);
+      float cb = 0.f;
+      for (int e = 0; e < ccnt; ++e) {                        // the column's candidates: this entry among them
+        const int i2 = __shfl(ci, base + e);
+        float c2 = ct;
+        if (i2 != i) {                                        // another row's entry (rare): that row's denominator
+          const float x2 = __shfl(cx, base + e);
+          const float rs2 = group_sum(share(rowP + (long)b_c * rparts * a.Lp + i2, rparts, a.Lp));
+          c2 = entry_conf(x2, a.k, a.nmr[(long)b_c * a.Lp + i2], rs2, nmc, cs);
         }
-        colbest = fmaxf(colbest, c2);
+        cb = fmaxf(cb, c2);
       }
+      if (slot == t) { conf = ct; colbest = cb; }
     }
   }
   float rowbest = conf;
@@ -162,7 +178,6 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   // rank among the row's kept entries by ascending j (torch.where order, :109)
   const int kj = keep ? j : 0x7fffffff;
   int rank = 0, nkeep = 0;
-  const int base = lane - slot;
   for (int s = 0; s < a.slots; ++s) {
     const int oj = __shfl(kj, base + s);
     rank += (oj < kj) ? 1 : 0;

@@ -42,7 +42,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     wl = bench.WORKLOADS[a.workload]
-    p = bench.Pair(wl, 1017, a.window, dev, a.dist)
+    p = bench.Pair(wl, 1017, a.window, dev, a.dist, fine_path="windows")   # this tool times the window-tensor kernels
     if a.layout == "nhwc":
         p.ff0 = p.ff0.contiguous(memory_format=torch.channels_last)
         p.ff1 = p.ff1.contiguous(memory_format=torch.channels_last)
@@ -71,7 +71,8 @@ def main():
                  timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 0, st), a.iters)))
     rows.append(("  corr sum pass (k_corr<.,1>)",
                  timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 1, st), a.iters, reset)))
-    buf, k0, k1 = p.step()          # the sweep timings above reset this workspace (cell maps included)
+    p.step()                        # the sweep timings above reset this workspace
+    buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, cell_maps=True)   # windows path: with cell maps
     torch.cuda.synchronize()
     rows.append(("gather windows (both images, list order)", timed(lambda: (
         ops.gather_windows(p.ff0, buf.b_ids, buf.i_ids, w, 4, p.hw_c[1], count=buf.count, out=p.win0),
