@@ -44,6 +44,10 @@ static int choose_splits_sparse(int N, int panels, int nunits, int* units_per_sp
   return (nunits + per - 1) / per;
 }
 
+// k_max_i8's workgroups are 4 waves (256 rows x a range of tiles) and two of them fit a CU: two per CU when the batch
+// alone cannot fill the chip
+constexpr int kMaxPassTarget = 512;
+
 CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   CoarseWs w;
   memset(&w, 0, sizeof(w));
@@ -54,9 +58,9 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.panels = w.Lp / kPanelRows;
   w.tiles = w.Sp / kTileCols;
   w.splits = choose_splits(N, w.panels, w.tiles);
-  w.splits0 = w.splits;
+  w.splits0 = choose_splits(N, w.panels, w.tiles, kMaxPassTarget);
 #ifdef FM_TUNE_ENV
-  if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : 256);
+  if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : kMaxPassTarget);
 #endif
   w.splits_s = choose_splits_sparse(N, w.panels, w.Sp / 32, &w.units_s);
   const size_t rows = (size_t)N * w.Lp, cols = (size_t)N * w.Sp;

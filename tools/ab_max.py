@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""A/B of the max pass (k_max_i8) of two builds of the library in ONE process, interleaved rounds (devices and runs
+differ by ~10 %: never compare numbers of different gpurun calls):
+
+    python tools/ab_max.py build/variants/libfmatch_A.so build/variants/libfmatch_B.so [--workloads cfg2 cfg3 cfg5]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from featurematching_amd import _lib, ops  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--workloads", nargs="+", default=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--mode", type=int, default=0, help="fm_debug_launch_corr mode (0 = max pass)")
+    ap.add_argument("--rounds", type=int, default=7)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    slots = lib.fm_default_cand_slots(0.2)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res, args = _lib.SIGNATURES["fm_debug_launch_corr"]
+    vs = []
+    for path in a.libs:
+        v = C.CDLL(os.path.abspath(path))
+        v.fm_debug_launch_corr.restype, v.fm_debug_launch_corr.argtypes = res, args
+        vs.append(v)
+    for wl in a.workloads:
+        p = bench.Pair(bench.WORKLOADS[wl], 1017, 5, dev, "peaky")
+        buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)
+        torch.cuda.synchronize()
+        ws = buf.workspace
+        ptr = C.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
+        n = 200 if wl == "cfg2" else 30
+        t = [[] for _ in vs]
+        for rnd in range(a.rounds + 1):
+            for k, v in enumerate(vs):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, a.mode, st)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    t[k].append(e0.elapsed_time(e1) * 1e3 / n)
+        for k, path in enumerate(a.libs):
+            print(f"{wl} {os.path.basename(path):28s} median {np.median(t[k]):9.2f} us  min {min(t[k]):9.2f} us")
+
+
+if __name__ == "__main__":
+    main()
