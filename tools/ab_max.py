@@ -24,17 +24,23 @@ def main():
     ap.add_argument("--workloads", nargs="+", default=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--mode", type=int, default=0, help="fm_debug_launch_corr mode (0 = max pass)")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--env", default="", help="NAME=v1,v2,..: every library is timed once per value (FM_TUNE_ENV builds read "
+                                              "their tuning variables at every call)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
     slots = lib.fm_default_cand_slots(0.2)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     res, args = _lib.SIGNATURES["fm_debug_launch_corr"]
-    vs = []
+    vs, names, envs = [], [], []
+    ename, evals = (a.env.split("=")[0], a.env.split("=")[1].split(",")) if a.env else (None, [None])
     for path in a.libs:
         v = C.CDLL(os.path.abspath(path))
         v.fm_debug_launch_corr.restype, v.fm_debug_launch_corr.argtypes = res, args
-        vs.append(v)
+        for ev in evals:
+            vs.append(v); envs.append(ev)
+            names.append(os.path.basename(path) + (f" {ename}={ev}" if ev else ""))
+    libc = C.CDLL(None)
     for wl in a.workloads:
         p = bench.Pair(bench.WORKLOADS[wl], 1017, 5, dev, "peaky")
         buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)
@@ -45,6 +51,8 @@ def main():
         t = [[] for _ in vs]
         for rnd in range(a.rounds + 1):
             for k, v in enumerate(vs):
+                if envs[k] is not None:
+                    libc.setenv(ename.encode(), envs[k].encode(), 1)      # (os.environ alone may not reach getenv of the C side)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(n):
@@ -53,8 +61,8 @@ def main():
                 torch.cuda.synchronize()
                 if rnd:
                     t[k].append(e0.elapsed_time(e1) * 1e3 / n)
-        for k, path in enumerate(a.libs):
-            print(f"{wl} {os.path.basename(path):28s} median {np.median(t[k]):9.2f} us  min {min(t[k]):9.2f} us")
+        for k, nm in enumerate(names):
+            print(f"{wl} {nm:44s} median {np.median(t[k]):9.2f} us  min {min(t[k]):9.2f} us")
 
 
 if __name__ == "__main__":

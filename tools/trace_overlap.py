@@ -1,47 +1,65 @@
 #!/usr/bin/env python3
-"""Concurrency summary of a rocprofv3 kernel trace (…_kernel_trace.csv): how much of the wall time the
-correlation sweeps run, how many kernels overlap, idle share.  Usage: trace_overlap.py FILE [skip_fraction]"""
-import collections
+"""Concurrency of the kernels of a multi-stream bench run from a rocprofv3 --kernel-trace CSV:
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 bench.py --quick --skip-cpu --steps 600 --reps 2
+    python tools/trace_overlap.py gpurun_out/trace
+
+per kernel: launches, mean duration; per queue: mean gap between consecutive kernels; how many kernels run at once
+(time-weighted) over the densest part of the trace."""
 import csv
+import glob
+import os
 import sys
+from collections import defaultdict
 
-
-def short(n):
-    return n.replace('void fm::', '').replace('fm::', '').split('(')[0]
+import numpy as np
 
 
 def main():
-    rows = list(csv.DictReader(open(sys.argv[1])))
-    skip = 0.3
-    ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])) for r in rows)
-    t0, t1 = ev[int(len(ev) * skip)][0], ev[-40][1]
-    pts = []
-    for s, e, n in ev:
-        if s >= t0 and e <= t1:
-            pts.append((s, 1, n))
-            pts.append((e, -1, n))
-    pts.sort()
-    active, conc, tot = collections.Counter(), collections.Counter(), collections.Counter()
-    last = pts[0][0]
-    for t, d, n in pts:
-        dt = t - last
-        if dt > 0:
-            k = sum(active.values())
-            conc[k] += dt
-            for name, v in active.items():
-                if v:
-                    tot[name] += dt
-            sweeps = sum(v for kk, v in active.items() if kk.startswith('k_corr<') and not kk.endswith('2>'))
-            tot['[any sweep]'] += dt if sweeps else 0
-            tot['[two sweeps]'] += dt if sweeps >= 2 else 0
-        active[n] += d
+    root = sys.argv[1]
+    f = max(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    rows = []
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            n = r["Kernel_Name"]
+            if not n.startswith("void fm::") and "fm::" not in n:
+                continue
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n.split("fm::")[-1].split("(")[0],
+                         r.get("Queue_Id", "0"), r.get("Stream_Id", "0")))
+    rows.sort()
+    # the timed part: the last 60 % of the launches
+    rows = rows[int(len(rows) * 0.4):]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    print(f"{len(rows)} launches over {(t1 - t0) / 1e3:.0f} us")
+    dur = defaultdict(list)
+    for s, e, n, q, st in rows:
+        dur[n].append((e - s) / 1e3)
+    tot = 0.0
+    for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        print(f"  {n:28s} {len(v):6d} launches  mean {np.mean(v):7.2f} us  median {np.median(v):7.2f}  sum/wall {sum(v) * 1e3 / (t1 - t0):.3f}")
+        tot += sum(v)
+    print(f"  sum of durations / wall = {tot * 1e3 / (t1 - t0):.2f} kernels running on average")
+    ev = []
+    for s, e, *_ in rows:
+        ev.append((s, 1)); ev.append((e, -1))
+    ev.sort()
+    lvl, last, hist = 0, ev[0][0], defaultdict(float)
+    for t, d in ev:
+        hist[lvl] += t - last
         last = t
-    w = t1 - t0
-    print(f"window {w / 1e3:.0f} us")
-    for k, v in sorted(conc.items()):
-        print(f"  {k} kernels running: {v / w:6.3f}")
-    for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
-        print(f"  {k:28s} active {v / w:6.3f} of the time")
+        lvl += d
+    wall = sum(hist.values())
+    print("  kernels running at once: " + "  ".join(f"{k}: {v / wall:.3f}" for k, v in sorted(hist.items())))
+    byq = defaultdict(list)
+    for s, e, n, q, st in rows:
+        byq[(q, st)].append((s, e, n))
+    gaps = defaultdict(list)
+    for q, v in byq.items():
+        for (s0, e0, n0), (s1, e1, n1) in zip(v, v[1:]):
+            gaps[f"{n0} -> {n1}"].append((s1 - e0) / 1e3)
+    print(f"  {len(byq)} queues/streams; gaps between consecutive kernels of a queue:")
+    for k, v in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:12]:
+        print(f"    {k:60s} n {len(v):5d}  median {np.median(v):6.2f} us  mean {np.mean(v):6.2f}")
 
 
 if __name__ == "__main__":
