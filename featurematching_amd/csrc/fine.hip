@@ -552,9 +552,12 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = d_count ? min(d_count[0], m_max) : m_max;
   const int per = (M + 7) >> 3;
-  const int slot = (int)(blockIdx.x >> 3) * 4 + wv;
+  __shared__ __attribute__((aligned(16))) float tile_all[NCHW0 ? 4 * kGatherTileFloats(W) : 4];
+  // (a grid smaller than the match list walks it in strides: fm_fine_match_maps may cap the grid so that the kernel's
+  // workgroups do not fill every wave slot of the chip while another pair's coarse kernels wait for theirs)
+  for (int slot = (int)(blockIdx.x >> 3) * 4 + wv; slot < per; slot += (int)(gridDim.x >> 3) * 4) {
   const int m = (blockIdx.x & 7) * per + slot;
-  if (slot >= per || m >= M) return;
+  if (m >= M) break;
   const int b = __builtin_amdgcn_readfirstlane((int)b_ids[m]);
   const int i = __builtin_amdgcn_readfirstlane((int)i_ids[m]);
   const int j = __builtin_amdgcn_readfirstlane((int)j_ids[m]);
@@ -567,7 +570,6 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
   // per-position conditions, ~10 scalar instructions per window row instead of ~12 per window position.
   const float* base0 = map0 + (long)b * Hf0 * Wf0 * 64;
   const float* base1 = map1 + (long)b * Hf1 * Wf1 * 64;
-  __shared__ __attribute__((aligned(16))) float tile_all[NCHW0 ? 4 * kGatherTileFloats(W) : 4];
   unsigned vo0[W], vo1[W];
 #pragma unroll
   for (int wx = 0; wx < W; ++wx) {
@@ -601,15 +603,20 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
   }
   fine_core<W>(f0, f1, lane, mix0, mix1, kc0[m * 2], kc0[m * 2 + 1], kc1[m * 2], kc1[m * 2 + 1], scale_f,
                out0 + (long)m * 3, out1 + (long)m * 3);
+  }
 }
 
 // [N, 64, Hf, Wf] -> [N, Hf, Wf, 64]: one workgroup per (sample, row y, 64 pixels of the row); reads 64 channel
 // segments of 256 bytes (16-byte loads along x), writes one contiguous 16 KiB block; the transpose goes through an
 // LDS tile with an odd pitch.  grid (ceil(Wf / 64), Hf, N).
-__global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const float* __restrict__ src, float* __restrict__ dst, int Hf, int Wf) {
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const float* __restrict__ src, float* __restrict__ dst, int Hf, int Wf,
+                                                        int N) {
   __shared__ float tile[64 * 65];              // [x][c], pitch 65
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * 64, y = blockIdx.y, b = blockIdx.z;
+  const int tx = (Wf + 63) / 64;
+  const long total = (long)tx * Hf * N;        // (sample, row, 64-pixel piece) in a flat order walked in grid strides
+  for (long t = blockIdx.x; t < total; t += gridDim.x) {
+  const int x0 = (int)(t % tx) * 64, y = (int)((t / tx) % Hf), b = (int)(t / ((long)tx * Hf));
   const float* in = src + ((long)b * 64 * Hf + y) * Wf + x0;      // + c * Hf * Wf
   const long plane = (long)Hf * Wf;
   const int nx = min(64, Wf - x0);
@@ -636,6 +643,8 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const float* __restrict_
     const int x = 16 * p + (tid >> 4), c4 = (tid & 15) * 4;
     if (x < nx)
       out[x * 16 + (tid & 15)] = make_float4(tile[x * 65 + c4], tile[x * 65 + c4 + 1], tile[x * 65 + c4 + 2], tile[x * 65 + c4 + 3]);
+  }
+  __syncthreads();                             // the tile is rewritten by the next piece
   }
 }
 
@@ -673,6 +682,8 @@ static bool fast_nchw64(int Cf, int Hf, int Wf, int W) {
 }
 // 8 XCD ranges of ceil(M/8) windows, four windows (waves) per workgroup
 static int list_blocks(int m_max) { return 8 * (((m_max + 7) / 8 + 3) / 4); }
+// largest grid of the kernels of fm_fine_match_maps (a multiple of 8; they walk longer lists in grid strides)
+constexpr int kFineGridCap = 1 << 20;
 // one wave per cell, four per workgroup, grid a multiple of 8
 static int cell_blocks(long total) { return (int)(((total + 3) / 4 + 7) / 8 * 8); }
 
@@ -843,12 +854,18 @@ extern "C" int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, in
   hipStream_t st = (hipStream_t)stream;
   const float* m0 = feat_f0;
   const float* m1 = feat_f1;
+  int grid_cap = kFineGridCap;
+#ifdef FM_TUNE_ENV
+  if (const char* e = getenv("FM_FINE_GRID")) grid_cap = atoi(e) > 0 ? atoi(e) / 8 * 8 : kFineGridCap;
+#endif
   if (layout == 0) {       // NCHW: a channels-last copy of image 1 (coalesced on both sides); image 0 is read as it is
     float* s1 = (float*)scratch;
-    hipLaunchKernelGGL(k_nchw_to_nhwc64, dim3((Wf1 + 63) / 64, Hf1, N), dim3(256), 0, st, feat_f1, s1, Hf1, Wf1);
+    const long pieces = (long)((Wf1 + 63) / 64) * Hf1 * N;
+    hipLaunchKernelGGL(k_nchw_to_nhwc64, dim3((unsigned)(pieces < grid_cap ? pieces : grid_cap)), dim3(256), 0, st, feat_f1, s1,
+                       Hf1, Wf1, N);
     m1 = s1;
   }
-  const int blocks = list_blocks(m_max);
+  const int blocks = list_blocks(m_max) < grid_cap ? list_blocks(m_max) : grid_cap;
 #define FM_FINE_MAPS_LAUNCH(WQ, N0)                                                                                      \
   hipLaunchKernelGGL((k_fine_maps<WQ, N0>), dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, w0c,  \
                      w1c, b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1)
