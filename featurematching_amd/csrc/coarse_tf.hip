@@ -331,12 +331,15 @@ __device__ __forceinline__ void token_scale(const f32x16 (&v)[NB], float* redm, 
 // ------------------------------------------------------------------------------------------------ k_ctx_kv
 constexpr int kKtStride = 36;            // floats per channel row of the K / V transposes (32 tokens + pad, 16-byte aligned)
 constexpr int kPlane = 16 * 1024;        // bytes of one float16 plane of 256 channels x 32 tokens
-constexpr int kKvLdsBytes = 2 * kPlane + 2 * kD * kKtStride * 4 + (8 * 32 + 2 * 32) * 4;
+// the K / V transposes reuse the bytes of the source planes (dead once both projections are done): 75 KB per workgroup,
+// two workgroups per CU - the 300 tiles of a self layer (both images in one launch) then run in ONE round
+constexpr int kKvLdsBytes = 2 * kD * kKtStride * 4 + (8 * 32 + 2 * 32) * 4;
+static_assert(2 * kD * kKtStride * 4 >= 2 * kPlane, "the planes fit under the transposes");
 
 __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const xh = lds;                                                   // source tile: hi plane, lo plane
-  float* const kt = reinterpret_cast<float*>(lds + 2 * kPlane);           // [256][36]  K, channel-major
+  float* const kt = reinterpret_cast<float*>(lds);                        // [256][36]  K, channel-major (over the planes)
   float* const vt = kt + kD * kKtStride;                                  // [256][36]  V
   float* const red8 = vt + kD * kKtStride;
   float* const xinv = red8 + 8 * 32;
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
   {
     f32x16 acc[4] = {};
     gemm_stage<4, 16, kPlane, 8>(a.w + kFragK, 2 * wv, xh, acc, lane);
+    __syncthreads();                      // every wave has read the planes: their bytes become the transposes
     const float fk = hdr[kHdrWinv + 1] * xi, fv = hdr[kHdrWinv + 2] * xi;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
