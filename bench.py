@@ -97,8 +97,13 @@ class Pair:
             self.scratch = torch.empty(self.ff1.numel() * 4, dtype=torch.uint8, device=dev)
         self.last = None
         self.gather = "cells"    # cells | list (see ops.gather_windows)
-        self.dense = dist != "peaky"     # flat similarity needs the dense sum kernel (FM_MODE_DENSE); the common path is 4 launches
-        self.exact = dist == "mixed"     # ... and rows without any peak the exact screening pass (FM_MODE_EXACT_SCREENING)
+        # rows without a peak need the dense sum kernel (FM_MODE_DENSE): all of them in 'borderline' data, the cells whose
+        # partner is a textureless cell in 'mixed' data (the textureless cells themselves - near-zero descriptors - are
+        # certified dead by the sparse sum kernel and cost nothing); 'peaky' takes the common 4 launches
+        self.dense = dist != "peaky"
+        # ... and in 'mixed' data those peakless rows sit next to peaked ones: more candidates than slots until the exact
+        # screening pass (FM_MODE_EXACT_SCREENING) has the denominators
+        self.exact = dist == "mixed"
         self.conf_matrix = False         # materialise data['conf_matrix'] (cfg#3's HBM-bound mode)
         self.stages = "all"      # diagnostic only (--stages): "coarse" or "fine" time a part of the step
 
@@ -833,8 +838,9 @@ def extras(a, wl, dev, streams, flops):
             "on all of them (3 f16 MFMA per k-step: ceiling 1/3 of the f16 peak); 4 streams, inputs generated on the device")))
         guarded("mixed_data", lambda: dict(dist_line("mixed"), note=(
             "'peaky' descriptors with 20 % near-zero cells in both images (textureless regions, missing partners): the "
-            "rows / columns of those cells are flat, their sample goes through the dense sum kernel, which skips the "
-            "units that are negligible for all their rows and columns")))
+            "near-zero rows / columns are certified dead by the sparse sum kernel (||a||_1 max|b| / (C T) bounds their "
+            "softmax terms below thr) and cost nothing; the cells whose partner is missing are rows without a peak and "
+            "send the sample through the dense sum kernel and the exact screening pass")))
 
         def cfg3_line():
             w3 = dict(WORKLOADS["cfg3"])

@@ -183,17 +183,26 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   for (int c = lane; c < kPanelRows; c += 64) s_rowacc[wv * kPanelRows + c] = 0.f;
 
   float l1A_max = 0.f, l1B_max = 0.f, clipA = 0.f, clipB = 0.f;     // image maxima (every wave folds them itself)
+  float infA = 0.f, infB = 0.f;                                     // largest |element| of image 0 / image 1
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    l1A_max = fmaxf(l1A_max, st0[q].x); clipA = fmaxf(clipA, st0[q].y);
-    l1B_max = fmaxf(l1B_max, st1[q].x); clipB = fmaxf(clipB, st1[q].y);
+    l1A_max = fmaxf(l1A_max, st0[q].x); clipA = fmaxf(clipA, st0[q].y); infA = fmaxf(infA, st0[q].z);
+    l1B_max = fmaxf(l1B_max, st1[q].x); clipB = fmaxf(clipB, st1[q].y); infB = fmaxf(infB, st1[q].z);
   }
-  for (int i = 512 + lane; i < nb0; i += 64) { const float4 v = bs0[i]; l1A_max = fmaxf(l1A_max, v.x); clipA = fmaxf(clipA, v.y); }
-  for (int i = 512 + lane; i < nunits; i += 64) { const float4 v = bs1[i]; l1B_max = fmaxf(l1B_max, v.x); clipB = fmaxf(clipB, v.y); }
+  for (int i = 512 + lane; i < nb0; i += 64) {
+    const float4 v = bs0[i];
+    l1A_max = fmaxf(l1A_max, v.x); clipA = fmaxf(clipA, v.y); infA = fmaxf(infA, v.z);
+  }
+  for (int i = 512 + lane; i < nunits; i += 64) {
+    const float4 v = bs1[i];
+    l1B_max = fmaxf(l1B_max, v.x); clipB = fmaxf(clipB, v.y); infB = fmaxf(infB, v.z);
+  }
   l1A_max = wave_reduce64<false>(l1A_max);
   clipA = wave_reduce64<false>(clipA);
   l1B_max = wave_reduce64<false>(l1B_max);
   clipB = wave_reduce64<false>(clipB);
+  infA = wave_reduce64<false>(infA);
+  infB = wave_reduce64<false>(infB);
   if (lane >= U) um = -INFINITY;
   const float ss = sig0 * sig1;                    // integer screening product -> raw dot-product units
   const float kss = a.k * ss;                      // ... -> log2-domain similarity
@@ -210,8 +219,18 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 
   // ---- stabilisers and integer thresholds: this wave's 32 rows, the workgroup's column range ----
   // lanes 0..31 (and their mirror 32..63): -stabiliser*log2e of row wrow0 + r
-  const float nm_lane = neg_stabiliser_log2(ss * q_decode(rmax_u),
-                                            q8_margin_raw(sig0, rl1, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
+  // DEAD rows and columns.  Every similarity of row i lies in [-B, B] with B = ||a_i||_1 max|b| / (C T) (Hoelder), so its
+  // softmax terms are all <= e^{2B} / S, and conf <= that: a row with e^{2B} / S < thr (a near-zero descriptor: a
+  // textureless cell) cannot hold a match, whatever the other image looks like, and nobody ever reads its denominator.
+  // Its entries then only matter for their COLUMNS: the row gets the stabiliser of a padding row (-inf: no entry is
+  // significant on its account, no candidate, the unit test ignores it).  Without this every entry of such a row is
+  // within 2^32 of the row's (tiny) maximum, i.e. significant, and one textureless patch sends the whole sample to the
+  // dense kernel - 24x the time.  Columns likewise.  (1.001, 1e-3: the float roundings of B.)
+  const float ln2 = 0.69314718f;
+  const bool dead_row = 2.002f * rl1 * infB * a.inv_ct + 1e-3f < (a.lt + __builtin_log2f((float)a.S)) * ln2;
+  const float nm_lane = dead_row ? -INFINITY
+                                 : neg_stabiliser_log2(ss * q_decode(rmax_u),
+                                                       q8_margin_raw(sig0, rl1, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
   // margin of any entry of this row block (its largest L1 norm against the other image's largest)
   const float emu_rows = margin_log2(q8_margin_raw(sig0, bl1A, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
   if (h == 0) {
@@ -226,8 +245,10 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     const int c = tid + 512 * k;
     if (c < U * 32) {
       const long gj = (long)b * a.Sp + u0 * 32 + c;
-      const float nm = neg_stabiliser_log2(ss * q_decode(cmax_u[k]),
-                                           q8_margin_raw(sig0, l1A_max, clipA, sig1, cl1[k], clipB, a.cpad), a.inv_ct);
+      const bool dead_col = 2.002f * cl1[k] * infA * a.inv_ct + 1e-3f < (a.lt + __builtin_log2f((float)a.L)) * ln2;
+      const float nm = dead_col ? -INFINITY
+                                : neg_stabiliser_log2(ss * q_decode(cmax_u[k]),
+                                                      q8_margin_raw(sig0, l1A_max, clipA, sig1, cl1[k], clipB, a.cpad), a.inv_ct);
       s_nmc[c] = nm;
       s_tc[c] = sig_threshold(nm, margin_log2(q8_margin_raw(sig0, l1A_max, clipA, sig1, cbl1[k], clipB, a.cpad), a.inv_ct), inv_kss);
       if (panel == 0) a.nmc[gj] = nm;

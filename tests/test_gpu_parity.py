@@ -210,14 +210,39 @@ def test_half_precision_descriptors(dtype, shape, dist):
     assert ref['i_ids'].shape[0] > 50
 
 
-def test_flat_rows_take_the_exact_screening_pass():
-    """Half of the cells of BOTH images carry almost no signal: every (flat row, flat column) entry is
-    within ln(thr) of its row and its column maximum, the max-based screening of the sum pass overflows the
-    candidate slots of those rows, and the exact screening pass (opt-in, decided on the device) must recover
-    the exact set."""
+def _repetitive_texture():
+    """a quarter of the cells of BOTH images carry the same descriptor: every (repeated, repeated) entry ties with its
+    row and its column maximum"""
+    f0, f1 = synth.coarse_descriptors(43, 2, 30 * 40, 128, "peaky")
+    f0[:, ::4] = f0[:, :1]
+    f1[:, ::4] = f0[:, :1]
+    return f0, f1
+
+
+def test_textureless_cells_are_certified_dead():
+    """Half of the cells of BOTH images carry almost no signal (near-zero descriptors).  Every entry of such a row is
+    within e^-32 of the row's tiny maximum - formally significant, and every (textureless, textureless) entry passes
+    the candidate test (360 k candidates against 8 slots per row: FM_E_CANDIDATES, the exact screening pass) - but
+    ||a||_1 max|b| / (C T) bounds every softmax term of the row below thr: the sparse sum kernel drops such rows and
+    columns (k_sum_sparse: DEAD rows), nothing overflows and no exact screening is needed.  The cells whose PARTNER is
+    textureless are rows without a peak: those still need the dense sum kernel (FM_MODE_DENSE)."""
     f0, f1 = synth.coarse_descriptors(43, 2, 30 * 40, 128, "peaky")
     f0[:, ::2] *= 1e-4
     f1[:, ::2] *= 1e-4
+    ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
+    assert 100 < ref['i_ids'].shape[0] < 900
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    buf = ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0, dense=True, exact_screening=False)
+    m = buf.read_count()                 # (raises FM_E_CANDIDATES if a slot list had overflowed)
+    assert m == ref['i_ids'].shape[0]
+    _assert_coarse(buf.sliced(m), ref)
+
+
+def test_flat_rows_take_the_exact_screening_pass():
+    """Repetitive texture: every (repeated, repeated) entry is within ln(thr) of its row and its column maximum, the
+    max-based screening of the sum pass overflows the candidate slots of those rows, and the exact screening pass
+    (opt-in, decided on the device) must recover the exact set."""
+    f0, f1 = _repetitive_texture()
     ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
     out = _run_coarse(f0, f1, (240, 320), (30, 40), (30, 40))          # ops.coarse_match: retries with the exact pass
     _assert_coarse(out, ref)
@@ -237,9 +262,7 @@ def test_flat_rows_take_the_exact_screening_pass():
 def test_flat_rows_with_conf_matrix_run_the_coarse_stage_once(monkeypatch):
     """Training-shaped call (conf_matrix requested) on flat rows: the exact screening is on from the first call, so
     the coarse stage is enqueued once - not once to overflow and once more to recover."""
-    f0, f1 = synth.coarse_descriptors(43, 2, 30 * 40, 128, "peaky")
-    f0[:, ::2] *= 1e-4
-    f1[:, ::2] *= 1e-4
+    f0, f1 = _repetitive_texture()
     ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
     calls = []
     real = ops.coarse_match_async
