@@ -80,6 +80,16 @@ __device__ __forceinline__ float wave_reduce64(float v) {
   return v;
 }
 
+// maximum over the 32 lanes that share lane >> 5 (every lane of the half ends with it)
+__device__ __forceinline__ float half_reduce32_max(float v) {
+  v = fmaxf(v, dpp_mov_s<0xB1, 0xf>(v, v));                                                       // lane ^ 1
+  v = fmaxf(v, dpp_mov_s<0x4E, 0xf>(v, v));                                                       // lane ^ 2
+  { float t = dpp_mov_s<0x104, 0x5>(v, v); t = dpp_mov_s<0x114, 0xA>(t, v); v = fmaxf(v, t); }   // lane ^ 4
+  v = fmaxf(v, dpp_mov_s<0x128, 0xf>(v, v));                                                      // lane ^ 8
+  { float p = v, q = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q)); v = fmaxf(p, q); }
+  return v;
+}
+
 // Integer significance threshold: an entry with integer screening product q can matter for a row / column whose
 // -stabiliser*log2e is nm iff  kss q + emu + nm > -kSkipLog2  <=>  q > (-kSkipLog2 - emu - nm) / kss.
 // floor() - 1 absorbs the float roundings of the quotient (a lower threshold only lets more entries through).
@@ -240,24 +250,27 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   }
   // padded rows (>= L) never contribute: keep them out of the wave's largest stabiliser
   const float wmax_nmr = wave_reduce64<false>(wrow0 + r < a.L ? nm_lane : -INFINITY);
+  // (a wave's 64 consecutive columns are two units: their largest stabilisers - padded and dead columns excluded - come
+  // out of the same pass by a butterfly over each half of the wave)
 #pragma unroll
   for (int k = 0; k < CSETS; ++k) {
     const int c = tid + 512 * k;
+    float nm = -INFINITY;
     if (c < U * 32) {
       const long gj = (long)b * a.Sp + u0 * 32 + c;
       const bool dead_col = 2.002f * cl1[k] * infA * a.inv_ct + 1e-3f < (a.lt + __builtin_log2f((float)a.L)) * ln2;
-      const float nm = dead_col ? -INFINITY
-                                : neg_stabiliser_log2(ss * q_decode(cmax_u[k]),
-                                                      q8_margin_raw(sig0, l1A_max, clipA, sig1, cl1[k], clipB, a.cpad), a.inv_ct);
+      nm = dead_col ? -INFINITY
+                    : neg_stabiliser_log2(ss * q_decode(cmax_u[k]),
+                                          q8_margin_raw(sig0, l1A_max, clipA, sig1, cl1[k], clipB, a.cpad), a.inv_ct);
       s_nmc[c] = nm;
       s_tc[c] = sig_threshold(nm, margin_log2(q8_margin_raw(sig0, l1A_max, clipA, sig1, cbl1[k], clipB, a.cpad), a.inv_ct), inv_kss);
       if (panel == 0) a.nmc[gj] = nm;
     }
-  }
-  __syncthreads();
-  for (int u = wv; u < U; u += 8) {
-    const float v = wave_reduce64<false>((u0 + u) * 32 + r < a.S ? s_nmc[u * 32 + r] : -INFINITY);
-    if (lane == 0) s_cmax[u] = v;
+    if (64 * wv + 512 * k < U * 32) {                       // wave-uniform: this wave holds columns of the range
+      const float v = half_reduce32_max(u0 * 32 + c < a.S ? nm : -INFINITY);
+      const int ul = 2 * wv + 16 * k + h;
+      if (r == 0 && ul < U) s_cmax[ul] = v;
+    }
   }
   __syncthreads();
 

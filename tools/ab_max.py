@@ -23,6 +23,8 @@ def main():
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--workloads", nargs="+", default=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--mode", type=int, default=0, help="fm_debug_launch_corr mode (0 = max pass)")
+    ap.add_argument("--kernel", default="corr", choices=["corr", "sparse"],
+                    help="corr: fm_debug_launch_corr(--mode); sparse: counter reset + fm_debug_launch_sum_sparse")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--env", default="", help="NAME=v1,v2,..: every library is timed once per value (FM_TUNE_ENV builds read "
                                               "their tuning variables at every call)")
@@ -37,6 +39,8 @@ def main():
     for path in a.libs:
         v = C.CDLL(os.path.abspath(path))
         v.fm_debug_launch_corr.restype, v.fm_debug_launch_corr.argtypes = res, args
+        for fn in ("fm_debug_launch_sum_sparse", "fm_debug_reset_counters"):
+            getattr(v, fn).restype, getattr(v, fn).argtypes = _lib.SIGNATURES[fn]
         for ev in evals:
             vs.append(v); envs.append(ev)
             names.append(os.path.basename(path) + (f" {ename}={ev}" if ev else ""))
@@ -55,8 +59,13 @@ def main():
                     libc.setenv(ename.encode(), envs[k].encode(), 1)      # (os.environ alone may not reach getenv of the C side)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+                f0p, f1p = C.c_void_p(p.f0.data_ptr()), C.c_void_p(p.f1.data_ptr())
                 for _ in range(n):
-                    v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, a.mode, st)
+                    if a.kernel == "corr":
+                        v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, a.mode, st)
+                    else:
+                        v.fm_debug_reset_counters(ptr, p.n, p.l, p.l, p.c, slots, st)
+                        v.fm_debug_launch_sum_sparse(ptr, f0p, f1p, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, st)
                 e1.record()
                 torch.cuda.synchronize()
                 if rnd:
