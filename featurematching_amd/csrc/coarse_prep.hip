@@ -87,6 +87,28 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   const long row_off = ((long)b * rows + local) * a.c_in;          // elements
   const void* const src = img1 ? a.src1 : a.src0;
 
+  // Full float32 rows (the common hand-over): the 32 rows of this block are one contiguous span of the source -
+  // copied to LDS with fully coalesced 16-byte loads (one row per wave instruction at C = 256) and read back in
+  // the (row = lane, 8-channel chunk) order the fragment-major stores need.  Row pitch + 16 bytes: the 32 lanes
+  // of a half-wave then start 4 banks apart.  The loads are ISSUED here, ahead of the sample's (which mostly hit L2):
+  // the block's own rows come from HBM, and behind the sample's round trip they were a second one (5.8 us from the
+  // launch until both had landed).
+  constexpr int PITCH = C + 4;
+  constexpr int OWN = 32 * (C / 4) / 256;        // float4 per thread
+  __shared__ float tile[32 * PITCH];
+  const bool staged = a.in_dtype == FM_F32 && a.c_in == C;
+  float4 own[OWN];
+  const int first = (int)(rb * 32 - (long)b * rows_pad);            // first row of the block inside its sample
+  const int valid4 = max(0, min(32, rows - first)) * (C / 4);        // float4s that exist (the sample's tail block is short)
+  if (staged) {
+    // (clamped, not predicated - no load behind a branch - and NOT touched before the sample's loads are out: what lies
+    // beyond the sample's rows is zeroed where the tile is written)
+    const float4* span = valid4 > 0 ? reinterpret_cast<const float4*>((const float*)src + ((long)b * rows + first) * C)
+                                    : reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int p = 0; p < OWN; ++p) own[p] = span[valid4 > 0 ? min(p * 256 + tid, valid4 - 1) : 0];
+  }
+
   // ---- the image's step: largest |x| over kPrepSampleRows rows spread evenly over the image (the same rows in every
   // workgroup of the image: max is order independent, so all of them arrive at the same step).  <= 8 loads per
   // thread, all in flight together and ahead of the block's own rows ----
@@ -116,22 +138,12 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
     for (int p = 0; p < 8; ++p)
       amax_s = fmaxf(amax_s, fmaxf(fmaxf(fabsf(sv[p].x), fabsf(sv[p].y)), fmaxf(fabsf(sv[p].z), fabsf(sv[p].w))));
   }
-  // Full float32 rows (the common hand-over): the 32 rows of this block are one contiguous span of the source -
-  // copied to LDS with fully coalesced 16-byte loads (one row per wave instruction at C = 256) and read back in
-  // the (row = lane, 8-channel chunk) order the fragment-major stores need.  Row pitch + 16 bytes: the 32 lanes
-  // of a half-wave then start 4 banks apart.
-  constexpr int PITCH = C + 4;
-  __shared__ float tile[32 * PITCH];
-  const bool staged = a.in_dtype == FM_F32 && a.c_in == C;
   if (staged) {
-    const int first = (int)(rb * 32 - (long)b * rows_pad);          // first row of the block inside its sample
-    const float4* span = reinterpret_cast<const float4*>((const float*)src + ((long)b * rows + first) * C);
-    const int valid4 = max(0, min(32, rows - first)) * (C / 4);      // float4s that exist (the sample's tail block is short)
 #pragma unroll
-    for (int p = 0; p < 32 * (C / 4) / 256; ++p) {
+    for (int p = 0; p < OWN; ++p) {
       const int idx = p * 256 + tid;
-      const float4 v = idx < valid4 ? span[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&tile[(idx / (C / 4)) * PITCH + (idx % (C / 4)) * 4]) = v;
+      *reinterpret_cast<float4*>(&tile[(idx / (C / 4)) * PITCH + (idx % (C / 4)) * 4]) =
+          idx < valid4 ? own[p] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 #pragma unroll

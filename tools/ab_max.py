@@ -23,7 +23,7 @@ def main():
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--workloads", nargs="+", default=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--mode", type=int, default=0, help="fm_debug_launch_corr mode (0 = max pass)")
-    ap.add_argument("--kernel", default="corr", choices=["corr", "sparse"],
+    ap.add_argument("--kernel", default="corr", choices=["corr", "sparse", "prep"],
                     help="corr: fm_debug_launch_corr(--mode); sparse: counter reset + fm_debug_launch_sum_sparse")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--env", default="", help="NAME=v1,v2,..: every library is timed once per value (FM_TUNE_ENV builds read "
@@ -39,7 +39,7 @@ def main():
     for path in a.libs:
         v = C.CDLL(os.path.abspath(path))
         v.fm_debug_launch_corr.restype, v.fm_debug_launch_corr.argtypes = res, args
-        for fn in ("fm_debug_launch_sum_sparse", "fm_debug_reset_counters"):
+        for fn in ("fm_debug_launch_sum_sparse", "fm_debug_reset_counters", "fm_debug_launch_prep"):
             getattr(v, fn).restype, getattr(v, fn).argtypes = _lib.SIGNATURES[fn]
         for ev in evals:
             vs.append(v); envs.append(ev)
@@ -61,7 +61,9 @@ def main():
                 e0.record()
                 f0p, f1p = C.c_void_p(p.f0.data_ptr()), C.c_void_p(p.f1.data_ptr())
                 for _ in range(n):
-                    if a.kernel == "corr":
+                    if a.kernel == "prep":
+                        v.fm_debug_launch_prep(ptr, f0p, f1p, p.n, p.l, p.l, p.c, slots, st)
+                    elif a.kernel == "corr":
                         v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, a.mode, st)
                     else:
                         v.fm_debug_reset_counters(ptr, p.n, p.l, p.l, p.c, slots, st)
