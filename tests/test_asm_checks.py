@@ -29,3 +29,26 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert "instructions walked, 0 hazards" in r.stdout, r.stdout
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def test_the_checker_sees_a_register_touched_while_its_load_is_in_flight(tmp_path):
+    """the checker itself: a copy of a loaded register before the wait is reported, the same copy after it is not"""
+    listing = tmp_path / "toy.s"
+    body = """_Z3toyv: ; @_Z3toyv
+	global_load_dwordx4 v[4:7], v[0:1], off
+	global_load_dwordx4 v[8:11], v[0:1], off offset:16
+	%s
+	s_waitcnt vmcnt(1)
+	v_mov_b32_e32 v20, v4
+	s_waitcnt vmcnt(0)
+	v_mov_b32_e32 v21, v9
+	s_endpgm
+.Lfunc_end0:
+"""
+    tool = os.path.join(ROOT, "tools", "check_inflight_regs.py")
+    listing.write_text(body % "v_mov_b32_e32 v12, v9")          # v9 is still in flight here
+    r = subprocess.run([sys.executable, tool, str(listing), "toy"], capture_output=True, text=True)
+    assert r.returncode == 1 and "touches in-flight registers [9]" in r.stdout, r.stdout
+    listing.write_text(body % "v_mov_b32_e32 v12, v13")         # nothing in flight is touched
+    r = subprocess.run([sys.executable, tool, str(listing), "toy"], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 hazards" in r.stdout, r.stdout
