@@ -374,40 +374,64 @@ __device__ __forceinline__ float wave_all(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return wave_all<OpAdd>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_all<OpMax>(v); }
 
-// One butterfly step of the transpose-reduce: p[0..2*HALF) -> p[0..HALF); lanes with bit MASK set
-// continue with the upper half of the sums, the others with the lower half.
-template <int HALF, int MASK, int NP>
-__device__ __forceinline__ void tr_step(float (&p)[NP], int lane) {
-  const bool up = (lane & MASK) != 0;
-#pragma unroll
-  for (int k = 0; k < HALF; ++k) {
-    const float a = pair_op<MASK, OpAdd>(p[k]);
-    const float b = pair_op<MASK, OpAdd>(p[k + HALF]);
-    p[k] = up ? b : a;
-  }
-}
-
-// in: p[k] = this lane's term of sum k.  out: the lane whose tr_index is k returns sum_lanes p[k].
-// The steps with many pairs use the cheapest exchanges (quad permutes); see tr_index for the map.
+// Transpose-reduce: p[k] = this lane's term of sum k (k < NP = 32 or 64) -> every sum ends in ONE lane (NP = 64) or in
+// a pair of neighbouring lanes (NP = 32), tr_index(lane) tells which.  Each level halves the registers: a lane keeps one
+// half and hands the other to its partner.  Written so that the levels with many pairs cost TWO instructions per pair
+// and no select (round 2's butterfly spent five: two DPP moves, two adds, one select):
+//   lane ^ 32 : v_permlane32_swap X, Y leaves {X.lo, Y.lo} / {X.hi, Y.hi}; X + Y = X's sum in lanes 0-31, Y's in 32-63
+//   lane ^ 16 : v_permlane16_swap likewise for the rows of 16 lanes
+//   15 - i    : row_mirror DPP add with bank-masked writes: banks 0-1 keep X, banks 2-3 receive Y's sum (into X)
+//   7 - i     : row_half_mirror, banks 0 / 2 keep X, banks 1 / 3 receive Y's
+//   3 - i     : inside the quad by select + quad_perm (one or two pairs are left by then)
+//   i ^ 1     : NP = 64: one more transposing level; NP = 32: a plain sum (both lanes of a pair hold it)
+// (s_nop 1: the two wait states a DPP / permlane operand needs after the VALU write of its register.)
 template <int NP>
 __device__ __forceinline__ float transpose_reduce(float (&p)[NP], int lane) {
-  if constexpr (NP == 64) {
-    tr_step<32, 1>(p, lane); tr_step<16, 2>(p, lane); tr_step<8, 8>(p, lane);
-    tr_step<4, 4>(p, lane); tr_step<2, 16>(p, lane); tr_step<1, 32>(p, lane);
-  } else {
-    tr_step<16, 1>(p, lane); tr_step<8, 2>(p, lane); tr_step<4, 8>(p, lane);
-    tr_step<2, 4>(p, lane); tr_step<1, 16>(p, lane);
-    p[0] = pair_op<32, OpAdd>(p[0]);     // the two half-waves hold the two halves of the channels
+  constexpr int H1 = NP / 2, H2 = NP / 4, H3 = NP / 8, H4 = NP / 16, H5 = NP / 32;
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < H1; ++k) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(p[k]), "+v"(p[k + H1]));
+#pragma unroll
+  for (int k = 0; k < H1; ++k) p[k] += p[k + H1];
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < H2; ++k) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(p[k]), "+v"(p[k + H2]));
+#pragma unroll
+  for (int k = 0; k < H2; ++k) p[k] += p[k + H2];
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < H3; ++k)
+    asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3" : "+v"(p[k]));
+#pragma unroll
+  for (int k = 0; k < H3; ++k)
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(p[k]) : "v"(p[k + H3]));
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < H4; ++k)
+    asm volatile("v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5" : "+v"(p[k]));
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < H4; ++k)
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(p[k]) : "v"(p[k + H4]));
+  const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+#pragma unroll
+  for (int k = 0; k < H5; ++k) {                 // lane 3 - i of the quad: quad_perm [3,2,1,0]
+    const float own = b1 ? p[k + H5] : p[k], other = b1 ? p[k] : p[k + H5];
+    p[k] = own + dpp_mov<0x1B, 0xf>(other, other);
   }
-  return p[0];
+  if constexpr (NP == 64) {                      // lane i ^ 1 takes the second of the last two sums
+    const float own = b0 ? p[1] : p[0], other = b0 ? p[0] : p[1];
+    return own + dpp_mov<0xB1, 0xf>(other, other);
+  } else {
+    return p[0] + dpp_mov<0xB1, 0xf>(p[0], p[0]);
+  }
 }
+// lane bits b5..b0 -> the sum it holds
 template <int NP>
 __device__ __forceinline__ int tr_index(int lane) {
-  if constexpr (NP == 64)
-    return 32 * (lane & 1) + 16 * ((lane >> 1) & 1) + 8 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1) +
-           2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
-  else
-    return 16 * (lane & 1) + 8 * ((lane >> 1) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 4) & 1);
+  const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1, b1 = (lane >> 1) & 1;
+  if constexpr (NP == 64) return 32 * b5 + 16 * b4 + 8 * b3 + 4 * b2 + 2 * b1 + (lane & 1);
+  else return 16 * b5 + 8 * b4 + 4 * b3 + 2 * b2 + b1;
 }
 
 // pos = window position this lane holds (sim is that position's similarity), on = lane takes part
@@ -459,7 +483,7 @@ __device__ __forceinline__ void fine_core(const float (&f0)[W * W], const float 
   const float sim1 = transpose_reduce<NP>(p, lane);
 
   const int pos = tr_index<NP>(lane);
-  const bool on = pos < WW && lane < NP;
+  const bool on = pos < WW && (NP == 64 || !(lane & 1));      // NP = 32: the even lane of the pair that holds a sum
   soft_argmax<W>(sim0, pos, on, lane, inv_sqrt_c, scale_f, k0x, k0y, out0);
   soft_argmax<W>(sim1, pos, on, lane, inv_sqrt_c, scale_f, k1x, k1y, out1);
 }
