@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
     };
     auto dpp = [&](auto step) {
       constexpr int st = decltype(step)::value;
-      if (st == 0) asm volatile("v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(um));
-      else if (st == 1) asm volatile("v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(um));
-      else if (st == 2) asm volatile("v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(um));
+      if (st == 0) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(um));
+      else if (st == 1) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(um));
+      else if (st == 2) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(um));
       else if (st == 3) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(um));
       else asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(um));
     };
@@ -371,25 +371,25 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
     for (int g = 0; g < 16; ++g) { V[g] = rstat0[g]; V[16 + g] = rstat1[g]; }
     asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
-    for (int m = 0; m < 16; ++m) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(V[2 * m]), "+v"(V[2 * m + 1]));
+    for (int m = 0; m < 16; ++m) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(V[2 * m]), "+v"(V[2 * m + 1]));
     int W[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) W[m] = max(V[2 * m], V[2 * m + 1]);
     asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
     for (int m = 0; m < 8; ++m)
-      asm volatile("v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3" : "+v"(W[2 * m]));
+      asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3" : "+v"(W[2 * m]));
 #pragma unroll
     for (int m = 0; m < 8; ++m)
-      asm volatile("v_max_i32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(W[2 * m]) : "v"(W[2 * m + 1]));
+      asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(W[2 * m]) : "v"(W[2 * m + 1]));
     asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      asm volatile("v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5" : "+v"(W[4 * m]));
+      asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5" : "+v"(W[4 * m]));
     asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      asm volatile("v_max_i32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(W[4 * m]) : "v"(W[4 * m + 2]));
+      asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(W[4 * m]) : "v"(W[4 * m + 2]));
     asm volatile("s_nop 1" ::: "memory");
     const bool b1 = (lane >> 1) & 1, b0 = lane & 1;
     int S[2];

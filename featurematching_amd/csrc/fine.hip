@@ -390,29 +390,29 @@ __device__ __forceinline__ float transpose_reduce(float (&p)[NP], int lane) {
   constexpr int H1 = NP / 2, H2 = NP / 4, H3 = NP / 8, H4 = NP / 16, H5 = NP / 32;
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
-  for (int k = 0; k < H1; ++k) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(p[k]), "+v"(p[k + H1]));
+  for (int k = 0; k < H1; ++k) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p[k]), "+v"(p[k + H1]));
 #pragma unroll
   for (int k = 0; k < H1; ++k) p[k] += p[k + H1];
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
-  for (int k = 0; k < H2; ++k) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(p[k]), "+v"(p[k + H2]));
+  for (int k = 0; k < H2; ++k) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p[k]), "+v"(p[k + H2]));
 #pragma unroll
   for (int k = 0; k < H2; ++k) p[k] += p[k + H2];
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
   for (int k = 0; k < H3; ++k)
-    asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3" : "+v"(p[k]));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3" : "+v"(p[k]));
 #pragma unroll
   for (int k = 0; k < H3; ++k)
-    asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(p[k]) : "v"(p[k + H3]));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(p[k]) : "v"(p[k + H3]));
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
   for (int k = 0; k < H4; ++k)
-    asm volatile("v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5" : "+v"(p[k]));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5" : "+v"(p[k]));
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
   for (int k = 0; k < H4; ++k)
-    asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(p[k]) : "v"(p[k + H4]));
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(p[k]) : "v"(p[k + H4]));
   const bool b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
 #pragma unroll
   for (int k = 0; k < H5; ++k) {                 // lane 3 - i of the quad: quad_perm [3,2,1,0]
@@ -434,25 +434,69 @@ __device__ __forceinline__ int tr_index(int lane) {
   else return 16 * b5 + 8 * b4 + 4 * b3 + 2 * b2 + b1;
 }
 
-// pos = window position this lane holds (sim is that position's similarity), on = lane takes part
+// Soft-argmax of BOTH directions at once.  pos = window position this lane holds (sim0 / sim1 are that position's
+// similarities), on = lane takes part.  Per direction: heat = softmax(sim / sqrt(C)), expectation and variance of the
+// normalised grid coordinates under it (kornia spatial_expectation2d on create_meshgrid) -> five sums each
+// (sum e, sum gx e, sum gy e, sum gx^2 e, sum gy^2 e); the ten sums go through ONE partial transpose-reduce (16 values,
+// four two-instruction levels, then two plain levels) instead of ten 6-level butterflies.
 template <int W>
-__device__ __forceinline__ void soft_argmax(float sim, int pos, bool on, int lane, float inv_sqrt_c, float scale_f,
-                                            float kx, float ky, float* out) {
-  const float x = on ? sim * inv_sqrt_c : -INFINITY;
-  const float mx = wave_max(x);
-  const float e = on ? __expf(x - mx) : 0.f;
-  const float heat = e / wave_sum(e);
+__device__ __forceinline__ void soft_argmax2(float sim0, float sim1, int pos, bool on, int lane, float inv_sqrt_c,
+                                             float scale_f, float k0x, float k0y, float k1x, float k1y, float* out0,
+                                             float* out1) {
+  const float x0 = on ? sim0 * inv_sqrt_c : -INFINITY, x1 = on ? sim1 * inv_sqrt_c : -INFINITY;
+  const float m0 = wave_max(x0), m1 = wave_max(x1);
+  const float e0 = on ? __expf(x0 - m0) : 0.f, e1 = on ? __expf(x1 - m1) : 0.f;
   const int wy = pos / W, wx = pos - wy * W;
   const float gx = ((float)wx / (float)(W - 1) - 0.5f) * 2.f;     // kornia create_meshgrid, normalised
   const float gy = ((float)wy / (float)(W - 1) - 0.5f) * 2.f;
-  const float cx = wave_sum(gx * heat), cy = wave_sum(gy * heat);
-  const float vx = wave_sum(gx * gx * heat) - cx * cx;
-  const float vy = wave_sum(gy * gy * heat) - cy * cy;
+  float q[16] = {e0, gx * e0, gy * e0, gx * gx * e0, gy * gy * e0, e1, gx * e1, gy * e1, gx * gx * e1, gy * gy * e1,
+                 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 8; ++k) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(q[k]), "+v"(q[k + 8]));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q[k] += q[k + 8];
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(q[k]), "+v"(q[k + 4]));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] += q[k + 4];
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0x3" : "+v"(q[k]));
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(q[k]) : "v"(q[k + 2]));
+  asm volatile("s_nop 1" ::: "memory");
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5" : "+v"(q[0]));
+  asm volatile("s_nop 1" ::: "memory");
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(q[0]) : "v"(q[1]));
+  float t = q[0];                                    // lane bits b5 b4 b3 b2 -> sum 8 b5 + 4 b4 + 2 b3 + b2; fold b1, b0
+  // (hipcc's hazard recogniser does not see the asm above as the vector write it is: the wait states the DPP read
+  // below needs are given by hand)
+  asm volatile("s_nop 1" : "+v"(t));
+  t += dpp_mov<0x4E, 0xf>(t, t);                     // lane ^ 2
+  t += dpp_mov<0xB1, 0xf>(t, t);                     // lane ^ 1
+  // (the sums are read from OTHER lanes below: without this hipcc sinks the last add into the lane-0 branch, where only
+  // lane 0 executes it)
+  asm volatile("" : "+v"(t));
+  auto sum_k = [&](int k) {                          // (wave-uniform: a scalar)
+    const int src = 32 * ((k >> 3) & 1) + 16 * ((k >> 2) & 1) + 8 * ((k >> 1) & 1) + 4 * (k & 1);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), src));
+  };
   if (lane == 0) {
-    const float sd = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
-    out[0] = kx + (cx * (float)(W / 2) * scale_f + (float)(W / 2));
-    out[1] = ky + (cy * (float)(W / 2) * scale_f + (float)(W / 2));
-    out[2] = sd;
+    float* const outs[2] = {out0, out1};
+    const float kx[2] = {k0x, k1x}, ky[2] = {k0y, k1y};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float inv = 1.0f / sum_k(5 * d);
+      const float cx = sum_k(5 * d + 1) * inv, cy = sum_k(5 * d + 2) * inv;
+      const float vx = sum_k(5 * d + 3) * inv - cx * cx, vy = sum_k(5 * d + 4) * inv - cy * cy;
+      outs[d][0] = kx[d] + (cx * (float)(W / 2) * scale_f + (float)(W / 2));
+      outs[d][1] = ky[d] + (cy * (float)(W / 2) * scale_f + (float)(W / 2));
+      outs[d][2] = sqrtf(fmaxf(vx, 1e-10f)) + sqrtf(fmaxf(vy, 1e-10f));
+    }
   }
 }
 
@@ -484,8 +528,7 @@ __device__ __forceinline__ void fine_core(const float (&f0)[W * W], const float 
 
   const int pos = tr_index<NP>(lane);
   const bool on = pos < WW && (NP == 64 || !(lane & 1));      // NP = 32: the even lane of the pair that holds a sum
-  soft_argmax<W>(sim0, pos, on, lane, inv_sqrt_c, scale_f, k0x, k0y, out0);
-  soft_argmax<W>(sim1, pos, on, lane, inv_sqrt_c, scale_f, k1x, k1y, out1);
+  soft_argmax2<W>(sim0, sim1, pos, on, lane, inv_sqrt_c, scale_f, k0x, k0y, k1x, k1y, out0, out1);
 }
 
 template <int W>
