@@ -54,20 +54,28 @@ constexpr int kTfLayerFloats = 4 * 64;                            // norm1.weigh
 // Operands carry exact power-of-two scales: the lo half of a value below 2^-3 would otherwise be a float16
 // SUBNORMAL (|lo| ~ 2^-12 |x| < 2^-14), which the matrix cores flush - the weights of a 64..128-wide Linear layer
 // are all below that (measured: 3e-4 instead of 1e-6).  Every tile that feeds a product is therefore KEPT in the
-// operand scale (kActScale times its value) from the window load to the window store: the accumulators are scaled
+// operand scale (the wave's ActScale times its value) from the window load to the window store: the accumulators are scaled
 // back by the weight scale only, LayerNorm runs on scaled values with a scaled epsilon (it is scale invariant
 // otherwise), relu commutes with the scale, and elu(x)+1 folds it into its constants.
-constexpr float kActScale = 256.f;          // activations: |x| < 256 stays inside float16
+constexpr float kLog2ActScale = 8.f;        // activations: the first attempt's scale 2^8 (|x| < 256 stays inside float16; see ActScale)
 constexpr float kWgtScale = 4096.f;         // weights (xavier bound <= 0.31)
 constexpr float kSumScale = 32.f;           // sum_s K (up to ~1e3)
 
+// The activation scale of a wave (= of its match): 2^8 at first; a match whose operands leave float16 at that scale
+// is recomputed with 2^4, 2^0, 2^-4 (k_fine_tf: the four layer calls start again from the input windows).  At a
+// smaller scale the lo halves of values below 2^-3 / scale are flushed (float16 subnormals), i.e. elements three
+// orders of magnitude below the ones that forced the scale down lose their last 11 bits - against an answer that was
+// not available at all before (the call reported FM_DEV_RANGE and the module ran its float32 layers, 20x slower).
+struct ActScale {
+  float a, inv, log2a;       // scale, 1 / scale, log2(scale)
+};
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // x = hi + lo in float16 (round-toward-zero packs: the remainder x - hi is exact in float32, and the scheme only
 // needs hi + lo = x to 22 bits, not nearest rounding): 3 VALU operations per element.  The tile is ALREADY in the
 // operand scale (see above), so there is no multiply here.
-// RANGE: the scales are fixed, so a value beyond float16 (|x| * kActScale > 65504: a window value, a projection or a
+// RANGE: a value beyond float16 at the wave's scale (|x| * scale > 65504: a window value, a projection or a
 // hidden-layer value above 255.9) would be clamped silently by the round-toward-zero pack.  `amax` follows the largest
 // magnitude that ever went into an operand (one v_max3 per pair of elements); the kernel reports FM_DEV_RANGE through
 // its status word when it exceeded the float16 range, and the caller falls back to float32 layers.
@@ -111,9 +119,8 @@ __device__ __forceinline__ float other_half(float v) {            // v(lane ^ 32
 }
 
 // elu(x) + 1 of a tile in the operand scale, result in the operand scale: xs = A x -> A (x > 0 ? x + 1 : exp(x))
-__device__ __forceinline__ float elu1_scaled(float xs) {
-  constexpr float kL2A = 8.0f;                          // log2(kActScale)
-  return xs > 0.f ? xs + kActScale : __builtin_amdgcn_exp2f(__builtin_fmaf(xs, kLog2e / kActScale, kL2A));
+__device__ __forceinline__ float elu1_scaled(float xs, const ActScale& A) {
+  return xs > 0.f ? xs + A.a : __builtin_amdgcn_exp2f(__builtin_fmaf(xs, kLog2e * A.inv, A.log2a));
 }
 
 // completion of the LDS-DMA fragment copies of stage_frags_n (every wave waits for its own, then the barrier)
@@ -134,12 +141,15 @@ struct KvState {
 };                        // normaliser's operand Kd is rebuilt from ksum in LDS where it is used)
 
 // Kd fragment of k-step s: row = head r (< 8), element j = sum_s K of feature d = 16 s + 8 (j>>2) + 4 h + (j&3) if in head r
-__device__ __forceinline__ void kd_fragment(const float* ksum_lds, int s, int r, int h, half8& dh, half8& dl, float& amax) {
+__device__ __forceinline__ void kd_fragment(const float* ksum_lds, int s, int r, int h, half8& dh, half8& dl, float& amax,
+                                            const ActScale& A) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int d = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-    const float val = (r == (d >> 3)) ? ksum_lds[d] * (kSumScale / kActScale) : 0.f;     // ksum_lds is in the operand scale
-    amax = fmaxf(amax, val);                  // sum_s (elu(k) + 1) of a head feature must stay below 65504 / kSumScale = 2047
+    // (ksum_lds is in the operand scale; the sum's own scale follows the activation scale - kSumScale at 2^8 - so that
+    // a match whose activations forced a smaller scale gets room for its sums as well)
+    const float val = (r == (d >> 3)) ? ksum_lds[d] * (kSumScale / 256.f) : 0.f;
+    amax = fmaxf(amax, val);                  // sum_s (elu(k) + 1) of a head feature must stay below 2047 at scale 2^8
     const _Float16 hh = (_Float16)val;
     dh[j] = hh;
     dl[j] = (_Float16)(val - (float)hh);
@@ -166,7 +176,8 @@ __device__ __forceinline__ void gemm_T1(f32x16 (&out)[OT], const f32x16* const (
   for (int ot = 0; ot < OT; ++ot) rescale(out[ot], 1.0f / kWgtScale);
 }
 
-__device__ __forceinline__ void layer_norm_T1(f32x16 (&y)[2], const float* __restrict__ gamma, const float* __restrict__ beta, int h) {
+__device__ __forceinline__ void layer_norm_T1(f32x16 (&y)[2], const float* __restrict__ gamma, const float* __restrict__ beta, int h,
+                                              const ActScale& A) {
   float s = 0.f;
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -178,7 +189,7 @@ __device__ __forceinline__ void layer_norm_T1(f32x16 (&y)[2], const float* __res
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
     for (int g = 0; g < 16; ++g) { const float d = y[rt][g] - mean; v += d * d; }
-  const float rstd = 1.0f / sqrtf(swap_halves_add(v) * (1.0f / 64.0f) + 1e-5f * kActScale * kActScale);   // scaled eps
+  const float rstd = A.a / sqrtf(swap_halves_add(v) * (1.0f / 64.0f) + 1e-5f * A.a * A.a);   // scaled eps; x the output's scale
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -187,13 +198,13 @@ __device__ __forceinline__ void layer_norm_T1(f32x16 (&y)[2], const float* __res
       const float4 be = *reinterpret_cast<const float4*>(beta + 32 * rt + 8 * q + 4 * h);
       const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[rt][4 * q + e] = (y[rt][4 * q + e] - mean) * rstd * gg[e] + bb[e];
+      for (int e = 0; e < 4; ++e) y[rt][4 * q + e] = __builtin_fmaf((y[rt][4 * q + e] - mean) * rstd, gg[e], bb[e] * A.a);
     }
 }
 
 // slice ct of a window [WW, 64] (token-major) <-> T layout: lane (token r, half h) holds features 32 rt + 8 q + 4 h + 0..3
 template <int WW>
-__device__ __forceinline__ void load_slice(f32x16 (&x)[2], const float* win, int ct, int lane) {
+__device__ __forceinline__ void load_slice(f32x16 (&x)[2], const float* win, int ct, int lane, const ActScale& A) {
   const int tok = 32 * ct + (lane & 31), h = lane >> 5;
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -201,12 +212,12 @@ __device__ __forceinline__ void load_slice(f32x16 (&x)[2], const float* win, int
     for (int q = 0; q < 4; ++q) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tok < WW) v = *reinterpret_cast<const float4*>(win + tok * 64 + 32 * rt + 8 * q + 4 * h);
-      x[rt][4 * q] = v.x * kActScale; x[rt][4 * q + 1] = v.y * kActScale;      // into the operand scale
-      x[rt][4 * q + 2] = v.z * kActScale; x[rt][4 * q + 3] = v.w * kActScale;
+      x[rt][4 * q] = v.x * A.a; x[rt][4 * q + 1] = v.y * A.a;      // into the operand scale
+      x[rt][4 * q + 2] = v.z * A.a; x[rt][4 * q + 3] = v.w * A.a;
     }
 }
 template <int WW>
-__device__ __forceinline__ void store_slice(const f32x16 (&x)[2], float* win, int ct, int lane) {
+__device__ __forceinline__ void store_slice(const f32x16 (&x)[2], float* win, int ct, int lane, const ActScale& A) {
   const int tok = 32 * ct + (lane & 31), h = lane >> 5;
   if (tok >= WW) return;
 #pragma unroll
@@ -214,13 +225,13 @@ __device__ __forceinline__ void store_slice(const f32x16 (&x)[2], float* win, in
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(win + tok * 64 + 32 * rt + 8 * q + 4 * h) =
-          make_float4(x[rt][4 * q] * (1.0f / kActScale), x[rt][4 * q + 1] * (1.0f / kActScale),
-                      x[rt][4 * q + 2] * (1.0f / kActScale), x[rt][4 * q + 3] * (1.0f / kActScale));
+          make_float4(x[rt][4 * q] * A.inv, x[rt][4 * q + 1] * A.inv, x[rt][4 * q + 2] * A.inv, x[rt][4 * q + 3] * A.inv);
 }
 
 // kv phase: region B holds [K hi 8 | V hi 8 | K lo 8 | V lo 8] fragments
 template <int WW>
-__device__ __forceinline__ void kv_phase(const float* src, const half8* lb, float* ksum_lds, KvState& st, int lane, float& amax) {
+__device__ __forceinline__ void kv_phase(const float* src, const half8* lb, float* ksum_lds, KvState& st, int lane, float& amax,
+                                         const ActScale& A) {
   constexpr int NCT = (WW + 31) / 32;
   const int r = lane & 31, h = lane >> 5;
   const half8 *wk = lb, *wv_ = lb + 8 * 64, *wkl = lb + 16 * 64, *wvl = lb + 24 * 64;
@@ -233,7 +244,7 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
     // their loads out of the slice loop and spills them)
     asm volatile("" : "+v"(lane));
     f32x16 x[2];
-    load_slice<WW>(x, src, ct, lane);
+    load_slice<WW>(x, src, ct, lane, A);
     // K, V [32 tokens x 64] = S . W^T: the T-layout registers of S as operand A, N layout out (tokens in registers,
     // features on lanes)
     f32x16 k[2], v[2];
@@ -254,7 +265,7 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const bool tok_ok = 32 * ct + (g & 3) + 8 * (g >> 2) + 4 * h < WW;      // padded tokens stay out of the sums
-        k[ot][g] = tok_ok ? elu1_scaled(k[ot][g] * (1.0f / kWgtScale)) : 0.f;
+        k[ot][g] = tok_ok ? elu1_scaled(k[ot][g] * (1.0f / kWgtScale), A) : 0.f;
         v[ot][g] = v[ot][g] * (1.0f / kWgtScale) * (1.0f / (float)WW);          // values / S (attentions.py:41-42)
         ks[ot] += k[ot][g];
       }
@@ -279,7 +290,7 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 16; ++g)            // keep d / 8 == v / 8 (rows d = (g&3) + 8 (g>>2) + 4 h, column v = r)
-      kv[dt][g] = ((g >> 2) != (r >> 3)) ? 0.f : kv[dt][g] * (1.0f / kActScale);     // back to the operand scale
+      kv[dt][g] = ((g >> 2) != (r >> 3)) ? 0.f : kv[dt][g] * A.inv;     // back to the operand scale
 #pragma unroll
   for (int s = 0; s < 4; ++s) split8(kv[s >> 1], s & 1, st.ah[s], st.al[s], amax);
 }
@@ -288,7 +299,7 @@ __device__ __forceinline__ void kv_phase(const float* src, const half8* lb, floa
 template <int WW>
 __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool store, const KvState& st,
                                              const float* ksum_lds, const half8* la, const half8* lb,
-                                             const float* __restrict__ ln, int lane, float& amax) {
+                                             const float* __restrict__ ln, int lane, float& amax, const ActScale& A) {
   constexpr int NCT = (WW + 31) / 32;
   const int r = lane & 31, h = lane >> 5;
   const half8 *lal = la + 32 * 64, *lbl = lb + 32 * 64;
@@ -296,7 +307,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
   for (int ct = 0; ct < NCT; ++ct) {
     asm volatile("" : "+v"(lane));          // see kv_phase
     f32x16 x[2];
-    load_slice<WW>(x, xin, ct, lane);
+    load_slice<WW>(x, xin, ct, lane, A);
     f32x16 q[2];
     {
       const f32x16* const rows[2] = {&x[0], &x[1]};
@@ -305,7 +316,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) q[rt][g] = elu1_scaled(q[rt][g]);
+      for (int g = 0; g < 16; ++g) q[rt][g] = elu1_scaled(q[rt][g], A);
     // msg^T = KV^T . Q^T and den^T = Kd . Q^T (both sum over d, the row index of KV and of Q^T)
     f32x16 msg[2], den;
     zero(msg[0]); zero(msg[1]); zero(den);
@@ -313,18 +324,19 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
     for (int s = 0; s < 4; ++s) {
       half8 bh, bl, dh, dl;
       split8(q[s >> 1], s & 1, bh, bl, amax);
-      kd_fragment(ksum_lds, s, r, h, dh, dl, amax);
+      kd_fragment(ksum_lds, s, r, h, dh, dl, amax, A);
       mma3(msg[s >> 1], st.ah[s], st.al[s], bh, bl);     // KV[dt] only reaches output rows v in tile dt
       mma3(den, dh, dl, bh, bl);
     }
-    rescale(msg[0], 1.0f / kActScale);
-    rescale(msg[1], 1.0f / kActScale);
+    rescale(msg[0], A.inv);
+    rescale(msg[1], A.inv);
     {
       // Z[token][head] = 1 / (den + eps): den rows 0..3 sit in registers 0..3 of half 0, rows 4..7 in half 1
       float z[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float mine = den[e] * (1.0f / (kSumScale * kActScale)), theirs = other_half(den[e]) * (1.0f / (kSumScale * kActScale));
+        const float dsc = A.inv * A.inv * (256.f / kSumScale);        // 1 / (sum scale x activation scale)
+        const float mine = den[e] * dsc, theirs = other_half(den[e]) * dsc;
         z[e] = h ? theirs : mine;             // heads 0..3
         z[4 + e] = h ? mine : theirs;         // heads 4..7
       }
@@ -340,7 +352,7 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
       const f32x16* const rows[2] = {&msg[0], &msg[1]};
       gemm_T1<2, 4, 4>(m1, rows, la + 8 * 64, lal + 8 * 64, lane, amax);
     }
-    layer_norm_T1(m1, ln, ln + 64, h);
+    layer_norm_T1(m1, ln, ln + 64, h, A);
     // MLP in two halves of the hidden layer (64 of its 128 features at a time: 32 registers instead of 64):
     // m2 = sum over halves of W2[:, half] . relu(W1[half, :] . [x | m1])
     f32x16 m2[2];
@@ -369,12 +381,12 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
     }
     rescale(m2[0], 1.0f / kWgtScale);
     rescale(m2[1], 1.0f / kWgtScale);
-    layer_norm_T1(m2, ln + 128, ln + 192, h);
+    layer_norm_T1(m2, ln + 128, ln + 192, h, A);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int g = 0; g < 16; ++g) x[rt][g] += m2[rt][g];
-    if (store) store_slice<WW>(x, xout, ct, lane);
+    if (store) store_slice<WW>(x, xout, ct, lane, A);
   }
 }
 
@@ -411,29 +423,46 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
   float* xout[4] = {out1 + off, out0 + off, out0 + off, out1 + off};
   const float* src[4] = {win1 + off, win0 + off, out1 + off, out0 + off};
   float amax = 0.f;                     // largest magnitude that went into a float16 operand (operand scale)
+  // A match whose operands leave float16 at the current activation scale starts again from its input windows with a
+  // 16x smaller one (the calls read win0 / win1 first and run in place on the outputs afterwards, so a restart is
+  // clean).  The waves of a workgroup share the staged weights and their barriers: all of them repeat the pass when any
+  // of them has to, the ones that were inside the range with their own scale (and the same result).
+  int e2 = (int)kLog2ActScale;          // (scalar registers: the exponent and the three floats made from it)
 #pragma unroll 1
-  for (int c = 0; c < 4; ++c) {
-    const half8* wl = wpack + (c >> 1) * kTfLayerHalf8;
-    const float* ln = lnp + (c >> 1) * kTfLayerFloats;
-    __syncthreads();                    // every wave is past the previous call's use of both regions (and its stores)
-    if ((c & 1) == 0) {                 // a new layer: q, merge, second MLP matrix -> region A
-      stage_frags_n<NW>(ra, wl + kTfFragQ * 64, 8, wv, lane);
-      stage_frags_n<NW>(ra + 8 * 1024, wl + kTfFragM * 64, 8, wv, lane);
-      stage_frags_n<NW>(ra + 16 * 1024, wl + kTfFrag2 * 64, 16, wv, lane);
-      stage_frags_n<NW>(ra + 32 * 1024, wl + (kTfFrags + kTfFragQ) * 64, 8, wv, lane);
-      stage_frags_n<NW>(ra + 40 * 1024, wl + (kTfFrags + kTfFragM) * 64, 8, wv, lane);
-      stage_frags_n<NW>(ra + 48 * 1024, wl + (kTfFrags + kTfFrag2) * 64, 16, wv, lane);
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    ActScale A;
+    e2 = __builtin_amdgcn_readfirstlane(e2);
+    A.a = __builtin_bit_cast(float, (127 + e2) << 23);
+    A.inv = __builtin_bit_cast(float, (127 - e2) << 23);
+    A.log2a = e2 == 8 ? 8.f : (e2 == 4 ? 4.f : (e2 == 0 ? 0.f : -4.f));
+    amax = 0.f;
+  #pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      const half8* wl = wpack + (c >> 1) * kTfLayerHalf8;
+      const float* ln = lnp + (c >> 1) * kTfLayerFloats;
+      __syncthreads();                    // every wave is past the previous call's use of both regions (and its stores)
+      if ((c & 1) == 0) {                 // a new layer: q, merge, second MLP matrix -> region A
+        stage_frags_n<NW>(ra, wl + kTfFragQ * 64, 8, wv, lane);
+        stage_frags_n<NW>(ra + 8 * 1024, wl + kTfFragM * 64, 8, wv, lane);
+        stage_frags_n<NW>(ra + 16 * 1024, wl + kTfFrag2 * 64, 16, wv, lane);
+        stage_frags_n<NW>(ra + 32 * 1024, wl + (kTfFrags + kTfFragQ) * 64, 8, wv, lane);
+        stage_frags_n<NW>(ra + 40 * 1024, wl + (kTfFrags + kTfFragM) * 64, 8, wv, lane);
+        stage_frags_n<NW>(ra + 48 * 1024, wl + (kTfFrags + kTfFrag2) * 64, 16, wv, lane);
+      }
+      stage_frags_n<NW>(rb, wl + kTfFragK * 64, 16, wv, lane);                          // K, V hi
+      stage_frags_n<NW>(rb + 16 * 1024, wl + (kTfFrags + kTfFragK) * 64, 16, wv, lane);    // K, V lo
+      stage_wait();
+      KvState st;
+      kv_phase<WW>(src[c], lb, ksum[wv], st, lane, amax, A);
+      __syncthreads();                    // every wave has read K, V: the first MLP matrix takes region B
+      stage_frags_n<NW>(rb, wl + kTfFrag1 * 64, 32, wv, lane);
+      stage_frags_n<NW>(rb + 32 * 1024, wl + (kTfFrags + kTfFrag1) * 64, 32, wv, lane);
+      stage_wait();
+      update_phase<WW>(xin[c], xout[c], store, st, ksum[wv], la, lb, ln, lane, amax, A);
     }
-    stage_frags_n<NW>(rb, wl + kTfFragK * 64, 16, wv, lane);                          // K, V hi
-    stage_frags_n<NW>(rb + 16 * 1024, wl + (kTfFrags + kTfFragK) * 64, 16, wv, lane);    // K, V lo
-    stage_wait();
-    KvState st;
-    kv_phase<WW>(src[c], lb, ksum[wv], st, lane, amax);
-    __syncthreads();                    // every wave has read K, V: the first MLP matrix takes region B
-    stage_frags_n<NW>(rb, wl + kTfFrag1 * 64, 32, wv, lane);
-    stage_frags_n<NW>(rb + 32 * 1024, wl + (kTfFrags + kTfFrag1) * 64, 32, wv, lane);
-    stage_wait();
-    update_phase<WW>(xin[c], xout[c], store, st, ksum[wv], la, lb, ln, lane, amax);
+    const bool over = __any(!(amax <= 65504.f));       // wave-uniform
+    if (!__syncthreads_or(over ? 1 : 0)) break;
+    if (over) e2 -= 4;
   }
   // an operand left the float16 range (or is not finite), or a packed weight did (|w| >= 16): the results of this
   // match are not trustworthy - report it instead of clamping silently
@@ -497,8 +526,8 @@ extern "C" int fm_fine_tf_pack_weights(const float* const* layer0, const float* 
       hipLaunchKernelGGL(k_tf_pack, dim3((n + 255) / 256), dim3(256), 0, st, w[i], outf[i], inf[i],
                          frag + (size_t)l * kTfLayerHalf8 + base[i] * 64, pstat);
     }
-    for (int i = 0; i < 4; ++i)        // gamma and beta pre-multiplied by the operand scale
-      hipLaunchKernelGGL(k_tf_scale_copy, dim3(1), dim3(64), 0, st, w[6 + i], ln + l * kTfLayerFloats + 64 * i, kActScale);
+    for (int i = 0; i < 4; ++i)        // gamma and beta as they are (k_fine_tf applies the wave's activation scale)
+      hipLaunchKernelGGL(k_tf_scale_copy, dim3(1), dim3(64), 0, st, w[6 + i], ln + l * kTfLayerFloats + 64 * i, 1.0f);
   }
   return (int)hipGetLastError();
 }

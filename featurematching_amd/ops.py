@@ -486,8 +486,8 @@ def pack_fine_transformer(state_dict: dict, device) -> torch.Tensor:
 def fine_transformer(win0: torch.Tensor, win1: torch.Tensor, packed: torch.Tensor, count: Optional[torch.Tensor] = None,
                      status: Optional[torch.Tensor] = None):
     """The fine context layers (network/net.py:79-80) on the windows [M, WW, 64] of both images, WW in {25, 49}.
-    `status` = a zeroed int32 device tensor: the kernel ORs FM_DEV_RANGE into element 0 when a value left the range
-    of its fixed float16 operand scales (see fmatch.h) - the outputs must then be discarded."""
+    `status` = a zeroed int32 device tensor: the kernel ORs FM_DEV_RANGE into element 0 when a value did not fit its
+    float16 operand halves at any of its activation scales (see fmatch.h) - the outputs must then be discarded."""
     lib = _lib.load()
     win0, win1 = _f32c(win0, "win0"), _f32c(win1, "win1")
     m, ww, cf = win0.shape

@@ -59,9 +59,10 @@ class EncoderLayer(nn.Module):
 class LocalFeatureTransformer(nn.Module):
     """Alternating self / cross layers over the two images' token sets (transformer.py:78-96).  config =
     {'d_model', 'nhead', 'layer_names': ['self', 'cross', ...], 'attention': 'linear'}.  use_hip=False keeps the torch ops
-    in eval mode too (tools that time one against the other).  The fine kernel works with fixed float16 operand scales
-    (|activation| < 255.9, see fmatch.h) and reports when an input left them: with check_range (default) the module
-    reads that report (one host sync per call) and redoes such a call with the float32 torch layers."""
+    in eval mode too (tools that time one against the other).  The fine kernel splits its operands into float16 halves
+    at a per-match power-of-two scale that it lowers itself when a match needs it (see fmatch.h); what does not fit at
+    its smallest scale either (|activation| ~ 1e6, NaN / Inf, a weight >= 16) it reports: with check_range (default) the
+    module reads that report (one host sync per call) and redoes such a call with the float32 torch layers."""
 
     def __init__(self, config, use_hip: bool = True, check_range: bool = True):
         super().__init__()

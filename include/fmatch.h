@@ -287,12 +287,15 @@ int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, 
  * fm_fine_tf_pack_weights(layer0, layer1, ...): each a HOST array of 10 DEVICE pointers in state-dict order -
  * q_proj, k_proj, v_proj, merge .weight [64,64]; mlp.0.weight [128,128]; mlp.2.weight [64,128]; norm1.weight,
  * norm1.bias, norm2.weight, norm2.bias [64] - of layers.0 ('self') and layers.1 ('cross').
- * Operand scales are fixed (activations x 2^8, weights x 2^12, the per-head sums of elu(k)+1 x 2^5 in float16): window
- * values, their projections and the MLP's hidden layer must stay below 255.9 in magnitude, weights below 16 and
- * sum_s (elu(k)+1) of a head feature below 2047 (LayerNorm-ed activations of a trained network are O(1)).  The kernel
- * FOLLOWS the largest magnitude that enters a float16 operand and fm_fine_tf_pack_weights the largest weight:
- * fm_fine_transformer_status ORs FM_DEV_RANGE into *d_status ([dev] int32, zeroed by the caller) when a limit was
- * exceeded for any match - the outputs are then not trustworthy and the caller must use float32 layers for this input
+ * Operand scales: weights x 2^12 (fixed: |w| < 16, checked by fm_fine_tf_pack_weights), activations x 2^8 and the
+ * per-head sums of elu(k)+1 x 2^5 in float16 at the FIRST attempt - window values, their projections and the MLP's
+ * hidden layer below 255.9 in magnitude, sum_s (elu(k)+1) of a head feature below 2047 (LayerNorm-ed activations of a
+ * trained network are O(1)).  The kernel FOLLOWS the largest magnitude that enters a float16 operand, per match; a
+ * match that left the range is recomputed inside the kernel from its input windows with activation (and sum) scales
+ * 16x, 256x, 4096x smaller (elements below 2^-3 / scale then lose the lo half of their split: three orders of
+ * magnitude below the values that forced the scale down).  Only what does not fit at 2^-4 either (|activation| ~ 1e6,
+ * NaN / Inf) or a weight >= 16 is reported: fm_fine_transformer_status ORs FM_DEV_RANGE into *d_status ([dev] int32,
+ * zeroed by the caller) - the outputs are then not trustworthy and the caller must use float32 layers for this input
  * (the Python module does).  fm_fine_transformer is the same call without the report.  fm_coarse_transformer has no
  * such limit (its scales follow the data).
  */

@@ -816,12 +816,13 @@ def test_fine_transformer_vs_oracle(w):
         tf.eval()(t0, t1, torch.ones(m, ww, dtype=torch.bool, device=DEV), None)
 
 
-@pytest.mark.parametrize("gain,expect_flag", [(1e-3, False), (8.0, False), (120.0, True), (300.0, True)])
-def test_fine_transformer_reports_values_beyond_its_operand_scales(gain, expect_flag):
-    """fm_fine_transformer works with fixed float16 operand scales (|activation| < 255.9, fmatch.h).  Inside them it
-    keeps float32-level accuracy at any magnitude; beyond them it must SAY so (FM_DEV_RANGE in the status word)
-    instead of clamping silently, and the module then answers with its float32 layers.  Window values of magnitude
-    `gain` x N(0,1): 8 -> |x| up to ~35 and projections up to ~60, inside the range; 120 and 300 leave it."""
+@pytest.mark.parametrize("gain,expect_flag", [(1e-3, False), (8.0, False), (120.0, False), (300.0, False), (3e5, True)])
+def test_fine_transformer_follows_the_data_and_reports_what_it_cannot_hold(gain, expect_flag):
+    """fm_fine_transformer splits its operands into float16 halves at a power-of-two activation scale: 2^8 at first
+    (|activation| < 255.9); a match whose operands leave float16 there is recomputed inside the kernel with 2^4, 2^0,
+    2^-4 (k_fine_tf), and only beyond that (|activation| ~ 1e6) does the call SAY so (FM_DEV_RANGE in the status word)
+    instead of clamping silently - the module then answers with its float32 layers.  Window values of magnitude
+    `gain` x N(0,1): 8 -> |x| up to ~35, projections up to ~60: first attempt; 120 and 300: a smaller scale; 3e5: out."""
     from featurematching_amd.transformer import LocalFeatureTransformer
     ww, m = 49, 21
     wts = synth.transformer_weights(77, 64, 2)
@@ -846,9 +847,10 @@ def test_fine_transformer_reports_values_beyond_its_operand_scales(gain, expect_
     assert (a0.cpu() - r0).abs().max().item() <= tol and (a1.cpu() - r1).abs().max().item() <= tol
 
 
-def test_fine_transformer_reports_weights_and_sums_beyond_its_scales():
-    """The two other limits of the fixed scales: a weight of magnitude >= 16 (caught when the weights are packed) and
-    per-head sums of elu(k)+1 >= 2047 (caught where the sum becomes an operand)."""
+def test_fine_transformer_weights_beyond_the_scale_are_reported_and_large_sums_are_held():
+    """The two other limits of the first attempt's scales: a weight of magnitude >= 16 (fixed weight scale: caught when
+    the weights are packed, reported) and per-head sums of elu(k)+1 >= 2047 with activations inside the range - the
+    sum's scale follows the activation scale, so the kernel repeats such a match at a smaller scale and holds it."""
     ww, m = 49, 9
     x0 = synth.normal(80, 1, (m, ww, 64)).astype(np.float32)
     x1 = synth.normal(80, 2, (m, ww, 64)).astype(np.float32)
@@ -865,8 +867,14 @@ def test_fine_transformer_reports_weights_and_sums_beyond_its_scales():
             t0, t1 = t0.abs(), t1.abs()
         packed = ops.pack_fine_transformer({k: torch.as_tensor(v) for k, v in wts.items()}, DEV)
         status = torch.zeros(1, dtype=torch.int32, device=DEV)
-        ops.fine_transformer(t0, t1, packed, status=status)
-        assert int(status.item()) & _lib.FM_DEV_RANGE, what
+        g0, g1 = ops.fine_transformer(t0, t1, packed, status=status)
+        if what == "weight":
+            assert int(status.item()) & _lib.FM_DEV_RANGE, what
+        else:
+            assert int(status.item()) == 0
+            r0, r1 = orc.local_feature_transformer(t0.cpu().numpy(), t1.cpu().numpy(), wts, 8, ['self', 'cross'])
+            tol = 2e-5 * max(1.0, float(r0.abs().max()))
+            assert (g0.cpu() - r0).abs().max().item() <= tol and (g1.cpu() - r1).abs().max().item() <= tol
 
 
 # ------------------------------------------------------------------ coarse context layers in HIP (8(f) row 1)
