@@ -436,7 +436,8 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
     A.inv = __builtin_bit_cast(float, (127 - e2) << 23);
     A.log2a = e2 == 8 ? 8.f : (e2 == 4 ? 4.f : (e2 == 0 ? 0.f : -4.f));
     amax = 0.f;
-  #pragma unroll 1
+    bool again = false;
+#pragma unroll 1
     for (int c = 0; c < 4; ++c) {
       const half8* wl = wpack + (c >> 1) * kTfLayerHalf8;
       const float* ln = lnp + (c >> 1) * kTfLayerFloats;
@@ -459,10 +460,19 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
       stage_frags_n<NW>(rb + 32 * 1024, wl + (kTfFrags + kTfFrag1) * 64, 32, wv, lane);
       stage_wait();
       update_phase<WW>(xin[c], xout[c], store, st, ksum[wv], la, lb, ln, lane, amax, A);
+      // checked after the first call and after the last: a match that needs a smaller scale usually shows it in the
+      // first call, and then costs a quarter of a pass more, not a whole one (a check after every call costs the matches
+      // that need none 7 %)
+      if (c == 0 || c == 3) {
+        const bool over = __any(!(amax <= 65504.f));       // wave-uniform
+        again = __syncthreads_or(over ? 1 : 0) != 0;
+        if (again) {
+          if (over) e2 -= 4;
+          break;
+        }
+      }
     }
-    const bool over = __any(!(amax <= 65504.f));       // wave-uniform
-    if (!__syncthreads_or(over ? 1 : 0)) break;
-    if (over) e2 -= 4;
+    if (!again) break;
   }
   // an operand left the float16 range (or is not finite), or a packed weight did (|w| >= 16): the results of this
   // match are not trustworthy - report it instead of clamping silently
