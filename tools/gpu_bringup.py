@@ -135,6 +135,16 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
         ec = np.abs(colA[b, :s] - dot_hi.max(0)).max() / max(1.0, np.abs(dot_hi).max())
         print(f"   [b={b}] passA rel err rows {ea:.2e} cols {ec:.2e}")
         ok &= ea < 1e-5 and ec < 1e-5
+        # unit maxima of the integer product (what the sparse kernel decides liveness from): valid entries only
+        nunits = Sp // 32
+        um = view(ws, base, lay["umax"], n * (Lp // 32) * nunits, torch.float32).reshape(n, Lp // 32, nunits)[b]
+        qq = q0[b, :l] @ q1[b, :s].T
+        eu = 0.0
+        for rbk in range((l + 31) // 32):
+            for u in range((s + 31) // 32):
+                eu = max(eu, abs(float(um[rbk, u]) - float(qq[32 * rbk: 32 * rbk + 32, 32 * u: 32 * u + 32].max())))
+        print(f"   [b={b}] unit maxima: max |difference| {eu:.1f} (integers: must be 0)")
+        ok &= eu == 0.0
         mhat_r = -nmr[b, :l] / log2e
         mhat_c = -nmc[b, :s] / log2e
         gap_r = sim.max(1) - mhat_r
