@@ -230,7 +230,8 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   if (e != hipSuccess) return (int)e;
   // sparse sum kernel: stabilisers, live units, exact terms of the few significant entries, candidates (listed per row
   // and per column); flags the samples with too many significant entries per unit (flat similarity)
-  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, st);
+  // (dead-row certificates only when nobody reads every row's denominator: the dense conf_matrix does)
+  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, conf_matrix ? 0 : 1, st);
   if (e != hipSuccess) return (int)e;
   if (dense) {
     // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or
@@ -298,7 +299,7 @@ extern "C" int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, c
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  return (int)launch_sum_sparse(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, 1,
+  return (int)launch_sum_sparse(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, 1, 1,
                                 (hipStream_t)stream);
 }
 

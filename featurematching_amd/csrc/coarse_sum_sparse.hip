@@ -54,6 +54,7 @@ struct SparseArgs {
   int* cand_count; int* cand_j; float* cand_x;         // candidates per row: columns, exact dot products
   int* ccand_count; int* ccand_i; float* ccand_x;      // the same candidates per column: rows, exact dot products
   int L, S, Lp, Sp, panels, splits, units_s, slots, pgroup, dense_enabled;
+  int allow_dead;                                      // 0: every row / column keeps its stabiliser and its full sum (conf_matrix)
   float k, lt, inv_ct, cpad;
 };
 
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
   // within 2^32 of the row's (tiny) maximum, i.e. significant, and one textureless patch sends the whole sample to the
   // dense kernel - 24x the time.  Columns likewise.  (1.001, 1e-3: the float roundings of B.)
   const float ln2 = 0.69314718f;
-  const bool dead_row = 2.002f * rl1 * infB * a.inv_ct + 1e-3f < (a.lt + __builtin_log2f((float)a.S)) * ln2;
+  const bool dead_row = a.allow_dead && 2.002f * rl1 * infB * a.inv_ct + 1e-3f < (a.lt + __builtin_log2f((float)a.S)) * ln2;
   const float nm_lane = dead_row ? -INFINITY
                                  : neg_stabiliser_log2(ss * q_decode(rmax_u),
                                                        q8_margin_raw(sig0, rl1, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     float nm = -INFINITY;
     if (c < U * 32) {
       const long gj = (long)b * a.Sp + u0 * 32 + c;
-      const bool dead_col = 2.002f * cl1[k] * infA * a.inv_ct + 1e-3f < (a.lt + __builtin_log2f((float)a.L)) * ln2;
+      const bool dead_col = a.allow_dead && 2.002f * cl1[k] * infA * a.inv_ct + 1e-3f < (a.lt + __builtin_log2f((float)a.L)) * ln2;
       nm = dead_col ? -INFINITY
                     : neg_stabiliser_log2(ss * q_decode(cmax_u[k]),
                                           q8_margin_raw(sig0, l1A_max, clipA, sig1, cl1[k], clipB, a.cpad), a.inv_ct);
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
 }
 
 hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                             float inv_ct, float thr, int dense_enabled, hipStream_t st) {
+                             float inv_ct, float thr, int dense_enabled, int allow_dead, hipStream_t st) {
   SparseArgs a;
   a.in_dtype = in_dtype;
   a.q0 = (const signed char*)(base + w.q0); a.q1 = (const signed char*)(base + w.q1);
@@ -550,7 +551,7 @@ hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype,
   a.cand_count = (int*)(base + w.cand_count); a.cand_j = (int*)(base + w.cand_j); a.cand_x = (float*)(base + w.cand_x);
   a.ccand_count = (int*)(base + w.ccand_count); a.ccand_i = (int*)(base + w.ccand_i); a.ccand_x = (float*)(base + w.ccand_x);
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.splits = w.splits_s; a.units_s = w.units_s;
-  a.slots = w.slots; a.dense_enabled = dense_enabled;
+  a.slots = w.slots; a.dense_enabled = dense_enabled; a.allow_dead = allow_dead;
   {
     const int blocks_all = w.N * a.splits * w.panels;
     const float share = fmaxf(1.f, (float)blocks_all / 8.f);

@@ -542,6 +542,28 @@ def test_matcher_end_to_end_on_warped_images():
 
 
 # ------------------------------------------------------------------ dense conf_matrix + training ids
+def test_dense_conf_matrix_keeps_the_rows_of_textureless_cells():
+    """The dead-row certificate of the sparse sum kernel (no match possible -> nobody reads the row's denominator) must
+    not be used when the dense conf_matrix is requested: the training loss reads EVERY entry, also the ~1/S^2 ones of
+    near-zero descriptors."""
+    f0, f1 = synth.coarse_descriptors(47, 1, 20 * 30, 128, "peaky")
+    f0[:, ::3] *= 1e-4
+    f1[:, 1::3] *= 1e-4
+    ref = orc.coarse_match(f0, f1, (160, 240), (20, 30), (20, 30), 0.2, 2, 0.1, return_conf=True)
+    out = ops.coarse_match(torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV), (20, 30), (20, 30), 8.0,
+                           conf_matrix=True)
+    _assert_coarse(out, ref)
+    got = out['conf_matrix'].cpu()
+    assert torch.isfinite(got).all()
+    # the dense matrix comes from the hi/lo-split float16 product (22 significant bits): at similarities of ~160 (these
+    # peaked descriptors) an entry of a peakless row - conf between 0 and 1, not saturated - carries 2^-22 |sim| ~ 4e-5
+    smax = float(np.abs(f0[0].astype(np.float64) @ f1[0].astype(np.float64).T).max()) / (128 * 0.1)
+    assert (got - ref['conf_matrix']).abs().max().item() <= max(1e-5, 2.0 ** -22 * smax)
+    # relative accuracy where the certificate would have dropped the row: conf ~ 1 / (L S) there
+    tiny = ref['conf_matrix'][0, 0]
+    assert float(tiny.max()) < 1e-4 and ((got[0, 0] - tiny).abs() <= 1e-3 * tiny.abs() + 1e-12).all()
+
+
 def test_dense_conf_matrix_and_training_ids():
     f0, f1 = synth.coarse_descriptors(91, 2, 23 * 31, 256, "borderline")       # ragged L = S = 713
     hw_c, hw_i = (23, 31), (184, 248)
