@@ -428,8 +428,9 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
   // clean).  The waves of a workgroup share the staged weights and their barriers: all of them repeat the pass when any
   // of them has to, the ones that were inside the range with their own scale (and the same result).
   int e2 = (int)kLog2ActScale;          // (scalar registers: the exponent and the three floats made from it)
+  // (every pass in which some wave lowers its scale is followed by another: at most 3 lowerings per wave)
 #pragma unroll 1
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  for (;;) {
     ActScale A;
     e2 = __builtin_amdgcn_readfirstlane(e2);
     A.a = __builtin_bit_cast(float, (127 + e2) << 23);
@@ -464,10 +465,12 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
       // first call, and then costs a quarter of a pass more, not a whole one (a check after every call costs the matches
       // that need none 7 %)
       if (c == 0 || c == 3) {
-        const bool over = __any(!(amax <= 65504.f));       // wave-uniform
-        again = __syncthreads_or(over ? 1 : 0) != 0;
+        // (a wave that is over the range at the smallest scale cannot be helped: it finishes the pass and the call
+        // reports FM_DEV_RANGE; the pass is repeated only while somebody can still lower its scale)
+        const bool lower = __any(!(amax <= 65504.f)) && e2 > -4;       // wave-uniform
+        again = __syncthreads_or(lower ? 1 : 0) != 0;
         if (again) {
-          if (over) e2 -= 4;
+          if (lower) e2 -= 4;
           break;
         }
       }

@@ -838,15 +838,16 @@ def test_fine_transformer_vs_oracle(w):
         tf.eval()(t0, t1, torch.ones(m, ww, dtype=torch.bool, device=DEV), None)
 
 
-@pytest.mark.parametrize("gain,expect_flag", [(1e-3, False), (8.0, False), (120.0, False), (300.0, False), (3e5, True)])
-def test_fine_transformer_follows_the_data_and_reports_what_it_cannot_hold(gain, expect_flag):
+@pytest.mark.parametrize("gain,expect_flag,ww", [(1e-3, False, 49), (8.0, False, 49), (120.0, False, 49), (300.0, False, 49),
+                                                 (3e5, True, 49), (300.0, False, 25), (3e5, True, 25)])
+def test_fine_transformer_follows_the_data_and_reports_what_it_cannot_hold(gain, expect_flag, ww):
     """fm_fine_transformer splits its operands into float16 halves at a power-of-two activation scale: 2^8 at first
     (|activation| < 255.9); a match whose operands leave float16 there is recomputed inside the kernel with 2^4, 2^0,
     2^-4 (k_fine_tf), and only beyond that (|activation| ~ 1e6) does the call SAY so (FM_DEV_RANGE in the status word)
     instead of clamping silently - the module then answers with its float32 layers.  Window values of magnitude
     `gain` x N(0,1): 8 -> |x| up to ~35, projections up to ~60: first attempt; 120 and 300: a smaller scale; 3e5: out."""
     from featurematching_amd.transformer import LocalFeatureTransformer
-    ww, m = 49, 21
+    m = 21
     wts = synth.transformer_weights(77, 64, 2)
     x0 = (gain * synth.normal(79, 1, (m, ww, 64))).astype(np.float32)
     x1 = (gain * synth.normal(79, 2, (m, ww, 64))).astype(np.float32)
