@@ -219,7 +219,8 @@ def _repetitive_texture():
     return f0, f1
 
 
-def test_textureless_cells_are_certified_dead():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_textureless_cells_are_certified_dead(dtype):
     """Half of the cells of BOTH images carry almost no signal (near-zero descriptors).  Every entry of such a row is
     within e^-32 of the row's tiny maximum - formally significant, and every (textureless, textureless) entry passes
     the candidate test (360 k candidates against 8 slots per row: FM_E_CANDIDATES, the exact screening pass) - but
@@ -229,9 +230,10 @@ def test_textureless_cells_are_certified_dead():
     f0, f1 = synth.coarse_descriptors(43, 2, 30 * 40, 128, "peaky")
     f0[:, ::2] *= 1e-4
     f1[:, ::2] *= 1e-4
-    ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
+    h0, h1 = torch.as_tensor(f0).to(dtype), torch.as_tensor(f1).to(dtype)      # (half precision: exact in float32)
+    ref = orc.coarse_match(h0.float().numpy(), h1.float().numpy(), (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
     assert 100 < ref['i_ids'].shape[0] < 900
-    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    t0, t1 = h0.to(DEV), h1.to(DEV)
     buf = ops.coarse_match_async(t0, t1, (30, 40), (30, 40), 8.0, dense=True, exact_screening=False)
     m = buf.read_count()                 # (raises FM_E_CANDIDATES if a slot list had overflowed)
     assert m == ref['i_ids'].shape[0]
