@@ -522,6 +522,130 @@ def context_layer_times(wl, dev, iters=10):
     return res
 
 
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process per
+    GPU under torch.distributed.run (the launcher of the reference's training glue, utils/comm.py:113-176 assumes the
+    same RANK / WORLD_SIZE environment), and pass rank 0's JSON line through.  Called before this process has made any
+    GPU call: nothing that has initialised the GPU is ever replaced or forked."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(world, backend, dev=None):
+    """Process group of the bench's ranks: RCCL ("nccl") on the GPUs, "gloo" to rehearse the protocol on CPUs."""
+    if world <= 1:
+        return
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+
+
+def timed_region(run, steps, reps, sync, world, coll_dev):
+    """The contract's timed region, `reps` times: barrier + device synchronise, K steps, barrier + device synchronise;
+    every repetition's duration is the MAXIMUM over the ranks.  Returns (durations, host enqueue times)."""
+    import torch.distributed as dist
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    dts, enq = [], []
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run(i)
+        enq.append(time.perf_counter() - t0)      # host time to enqueue the K steps (diagnostic: host- or GPU-bound?)
+        barrier()
+        dts.append(time.perf_counter() - t0)
+    if world > 1:      # every repetition: the slowest rank
+        td = torch.tensor(dts, device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dts = [float(x) for x in td.tolist()]
+    return dts, enq
+
+
+def agree_max(value, world, coll_dev):
+    """the same integer on every rank (the largest any rank proposes)"""
+    if world <= 1:
+        return int(value)
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], device=coll_dev, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def timed_gather(rec, world, sync, coll_dev, iters=10):
+    """cfg#4's exchange: this rank's records (pair order) -> every rank holds all of them (dist.gather_match_lists:
+    all-gather of counts + padded records).  Returns (ms per exchange, max over ranks; records gathered)."""
+    import torch.distributed as dist
+    full = fdist.gather_match_lists(rec)      # warm-up (communicator set-up)
+    sync()
+    dist.barrier()
+    tg = time.perf_counter()
+    for _ in range(iters):
+        full = fdist.gather_match_lists(rec)
+    sync()
+    gather_ms = (time.perf_counter() - tg) / iters * 1e3
+    ids = fdist.unpack_records(full)[0]
+    assert bool((ids[1:] >= ids[:-1]).all()), "gathered records are not in pair order"
+    t = torch.tensor([gather_ms], device=coll_dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0].item()), int(full.shape[0])
+
+
+def main_stub(a, world, rank):
+    """--stub-step: the launcher / rank protocol of this file (self-launch, process group, pair blocks, timed region
+    with barriers and the max over ranks, match-list gather, rank 0's JSON line) with a CPU stand-in for the HIP step -
+    what tests/test_dist.py drives on a machine without a GPU.  Its `value` is NOT a measurement of anything."""
+    cpu = torch.device("cpu")
+    init_ranks(world, "gloo")
+    n = 1
+    lo, hi = fdist.shard_range(world * n, rank, world)
+
+    def fake(i):           # a deterministic 'match list' of this rank's pair block
+        g = torch.Generator().manual_seed(1234 + lo)
+        m = 50 + 7 * lo
+        return (torch.zeros(m, dtype=torch.int64), torch.rand(m, 2, generator=g) * 640, torch.rand(m, 2, generator=g) * 640,
+                torch.rand(m, generator=g))
+
+    last = [None]
+
+    def run(i):
+        last[0] = fake(i)
+
+    reps = agree_max(3, world, cpu)
+    dts, _ = timed_region(run, a.steps, reps, lambda: None, world, cpu)
+    dt = float(np.median(dts))
+    out = {"metric": "STUB (no GPU work): rank protocol of bench.py only", "stub": True, "value": None, "unit": "image-pairs/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 6),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+           "config": {"workload": "stub step", "pair_block": [lo, hi]}}
+    if world > 1:
+        import torch.distributed as dist
+        b, k0, k1, c = last[0]
+        rec = fdist.pack_records(b, k0, k1, c, pair_offset=lo)
+        out["gather_ms"], out["gathered_records"] = timed_gather(rec, world, lambda: None, cpu, iters=3)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -547,22 +671,30 @@ def main():
                     help="diagnostic: pairs per launch (overrides the workload's batch; the JSON line is then not the metric's config)")
     ap.add_argument("--stages", default="all", choices=["all", "coarse", "fine"],
                     help="diagnostic: time only a part of the step (the JSON line is then not the metric)")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="test hook: run the launcher / rank protocol with a CPU stand-in for the HIP step (no GPU needed; "
+                         "the JSON line is marked as a stub and carries no measurement)")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` (N > 1) without a launcher: this process becomes the launcher of N ranks.  Decided
+    # before any GPU call of this process (torch is imported, nothing is initialised).
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.stub_step:
+        return main_stub(a, world, rank)
     ndev = torch.cuda.device_count()
     backend = os.environ.get("FM_BENCH_BACKEND", "nccl")     # "gloo" to rehearse N ranks on one GPU
+    if world > 1 and backend == "nccl" and ndev < world:
+        sys.exit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {ndev} visible (FM_BENCH_BACKEND=gloo rehearses "
+                 f"the ranks on fewer)")
     dev = torch.device("cuda", local % max(ndev, 1))
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    init_ranks(world, backend, dev)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -619,7 +751,8 @@ def main():
     barrier()
     # A short --steps alone is a sample of a millisecond: the timed K-step region (barrier + synchronise on both
     # sides, as the contract says) is repeated R times and the MEDIAN repetition is reported, with the spread.
-    # R from a probe of the step time: >= 120 ms of GPU work in total, at least 3, at most 400 repetitions.
+    # R from a probe of the step time: >= 1.2 s of GPU work in total (long enough for a once-per-second utilisation
+    # sampler outside this process to see the GPU busy), at least 3, at most 2000 repetitions.
     reps = a.reps
     if reps <= 0:
         tp = time.perf_counter()
@@ -628,24 +761,11 @@ def main():
             run(i)
         torch.cuda.synchronize()
         est = (time.perf_counter() - tp) / nprobe
-        reps = int(max(3, min(400, math.ceil(0.12 / max(a.steps * est, 1e-6)))))
-        if world > 1:      # every rank must run the same number of repetitions
-            tr = torch.tensor([reps], device=coll_dev, dtype=torch.int64)
-            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-            reps = int(tr.item())
-    dts, enq = [], []
-    for _ in range(reps):
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            run(i)
-        enq.append(time.perf_counter() - t0)      # host time to enqueue the K steps (diagnostic: host- or GPU-bound?)
-        barrier()
-        dts.append(time.perf_counter() - t0)
-    if world > 1:      # every repetition: the slowest rank
-        td = torch.tensor(dts, device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
-        dts = [float(x) for x in td.tolist()]
+        reps = int(max(3, min(2000, math.ceil(1.2 / max(a.steps * est, 1e-6)))))
+        reps = agree_max(reps, world, coll_dev)      # every rank must run the same number of repetitions
+    t_region0 = time.perf_counter()
+    dts, enq = timed_region(run, a.steps, reps, torch.cuda.synchronize, world, coll_dev)
+    t_region = time.perf_counter() - t_region0
     dt = float(np.median(dts))
     t_enq = float(np.median(enq))
 
@@ -667,17 +787,7 @@ def main():
                 recs.append(fdist.pack_records(buf.b_ids[:m], k0[:m, :2], k1[:m, :2], buf.mconf[:m], pair_offset=pair_lo))
             rec = torch.cat(recs).to(coll_dev)
             rec = rec[torch.argsort(fdist.unpack_records(rec)[0], stable=True)]      # pair order inside the rank
-            full = fdist.gather_match_lists(rec)      # warm-up (communicator set-up)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter()
-            for _ in range(10):
-                full = fdist.gather_match_lists(rec)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - tg) / 10 * 1e3
-            gathered = int(full.shape[0])
-            ids = fdist.unpack_records(full)[0]
-            assert bool((ids[1:] >= ids[:-1]).all()), "gathered records are not in pair order"
+            gather_ms, gathered = timed_gather(rec, world, torch.cuda.synchronize, coll_dev)
 
         tk = ver = None
         if rank == 0:
@@ -687,10 +797,6 @@ def main():
             ver = verify(pairs[0])
             tk = time_kernels(pairs[0])
 
-    if world > 1:
-        t = torch.tensor([gather_ms], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gather_ms = float(t[0].item())
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -720,7 +826,7 @@ def main():
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4),
         "ms_per_step_spread": {"repetitions": reps, "min": round(min(dts) / a.steps * 1e3, 4),
-                               "max": round(max(dts) / a.steps * 1e3, 4),
+                               "max": round(max(dts) / a.steps * 1e3, 4), "timed_regions_total_s": round(t_region, 3),
                                "note": "the K-step region (barrier + synchronise on both sides) repeated; value and "
                                        "ms_per_step are the median repetition"},
         "higher_is_better": True, "scaling": "weak",

@@ -108,3 +108,25 @@ def test_single_process_passthrough():
     b, k0, k1, c = _fake_matches(0, 5)
     rec = fdist.pack_records(b, k0, k1, c)
     assert fdist.gather_match_lists(rec) is rec
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks (torch.distributed.run) before
+    any GPU call and passes rank 0's ONE JSON line through.  --stub-step replaces the HIP step with a CPU stand-in, so
+    the launcher, the process group, the pair blocks, the barrier-bracketed timed region with its max over ranks and
+    the match-list gather run here; the line is marked as a stub (no measurement)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step", "--steps", "4",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["stub"] is True and out["value"] is None
+    assert out["gather_ms"] > 0
+    # two ranks, pair blocks [0,1) and [1,2): 50 + 57 stand-in records, gathered on every rank in pair order
+    assert out["gathered_records"] == 107 and out["config"]["pair_block"] == [0, 1]
