@@ -65,6 +65,9 @@ SIGNATURES = {
     "fm_epipolar_errors": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
     "fm_fine_maps_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),
+    "fm_fine_maps_scratch_bytes_dtype": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "fm_fine_match_maps_dtype": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p,
+                                      _p, _p, _f, _p, _p, _p, _p]),
     "fm_fine_match_maps": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p,
                                 _p, _p, _f, _p, _p, _p, _p]),
 }

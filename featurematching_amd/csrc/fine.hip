@@ -1,6 +1,6 @@
 // Fine stage: window crop (network/module/fine_preprocess.py:43-50) and the dual-direction
 // local-window correlation + soft-argmax (network/utils/fine_matching_new.py:50-79).
-#include "fm_internal.h"
+#include "fm_device.h"
 
 namespace fm {
 
@@ -607,7 +607,9 @@ __global__ __launch_bounds__(256) void k_gather_nhwc64(const float* __restrict__
 // NCHW0: image 0 is still in the reference's NCHW layout - its windows are visited in raster order here (the match list
 // is sorted by the image-0 cell), which is the access pattern the NCHW loader of the cell-ordered crop copes with, so only
 // image 1 (whose windows land wherever the partners are) needs the channels-last copy.
-template <int W, bool NCHW0>
+// DT = element type of the maps (FM_F32; FM_F16 / FM_BF16: channels-last maps of 2-byte elements, every value exact in
+// float32, so the arithmetic - and the result - equals the float32 call on the up-cast maps).
+template <int W, bool NCHW0, int DT = FM_F32>
 __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map0, const float* __restrict__ map1, int Hf0,
                                                    int Wf0, int Hf1, int Wf1, int stride, int pad, int w0c, int w1c,
                                                    const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
@@ -635,36 +637,41 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
   // below the map), one vector offset per window COLUMN (pixel x, this lane's channel; a negative x gets an offset
   // beyond any row): the unfold's zero padding on all four sides then comes from the hardware's range check - no
   // per-position conditions, ~10 scalar instructions per window row instead of ~12 per window position.
-  const float* base0 = map0 + (long)b * Hf0 * Wf0 * 64;
-  const float* base1 = map1 + (long)b * Hf1 * Wf1 * 64;
+  constexpr int EB = DT == FM_F32 ? 4 : 2;          // bytes per element
+  constexpr int PXB = 64 * EB;                      // bytes per pixel (64 channels)
+  static_assert(!(NCHW0 && DT != FM_F32), "half-precision maps are read channels-last");
+  const char* base0 = reinterpret_cast<const char*>(map0) + (long)b * Hf0 * Wf0 * PXB;
+  const char* base1 = reinterpret_cast<const char*>(map1) + (long)b * Hf1 * Wf1 * PXB;
   unsigned vo0[W], vo1[W];
 #pragma unroll
   for (int wx = 0; wx < W; ++wx) {
     const int x0 = ox0 + wx, x1 = ox1 + wx;
-    vo0[wx] = x0 >= 0 ? (unsigned)(x0 * 256 + lane * 4) : 0x80000000u;
-    vo1[wx] = x1 >= 0 ? (unsigned)(x1 * 256 + lane * 4) : 0x80000000u;
+    vo0[wx] = x0 >= 0 ? (unsigned)(x0 * PXB + lane * EB) : 0x80000000u;
+    vo1[wx] = x1 >= 0 ? (unsigned)(x1 * PXB + lane * EB) : 0x80000000u;
   }
+  auto load_elem = [](const __amdgpu_buffer_rsrc_t r, unsigned vo) -> float {
+    if constexpr (DT == FM_F32) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, 0, 0));
+    else return half_bits_to_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, 0, 0), DT);
+  };
   float f0[WW], f1[WW];
 #pragma unroll
   for (int wy = 0; wy < W; ++wy) {
     const int y0 = oy0 + wy, y1 = oy1 + wy;
     const bool ok0 = y0 >= 0 && y0 < Hf0, ok1 = y1 >= 0 && y1 < Hf1;          // wave-uniform
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(base1 + (long)(ok1 ? y1 : 0) * Wf1 * 64), 0, ok1 ? Wf1 * 256 : 0, 0x00020000);
+        const_cast<char*>(base1 + (long)(ok1 ? y1 : 0) * Wf1 * PXB), 0, ok1 ? Wf1 * PXB : 0, 0x00020000);
     if (!NCHW0) {
       const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(base0 + (long)(ok0 ? y0 : 0) * Wf0 * 64), 0, ok0 ? Wf0 * 256 : 0, 0x00020000);
+          const_cast<char*>(base0 + (long)(ok0 ? y0 : 0) * Wf0 * PXB), 0, ok0 ? Wf0 * PXB : 0, 0x00020000);
 #pragma unroll
-      for (int wx = 0; wx < W; ++wx)
-        f0[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, vo0[wx], 0, 0));
+      for (int wx = 0; wx < W; ++wx) f0[wy * W + wx] = load_elem(r0, vo0[wx]);
     }
 #pragma unroll
-    for (int wx = 0; wx < W; ++wx)
-      f1[wy * W + wx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, vo1[wx], 0, 0));
+    for (int wx = 0; wx < W; ++wx) f1[wy * W + wx] = load_elem(r1, vo1[wx]);
   }
   if (NCHW0) {      // image 0 straight from the NCHW map: the crop's loader into a wave-private tile, read back by channel
     float* tile = tile_all + wv * kGatherTileFloats(W);
-    wave_load_window64<W>(base0, Hf0, Wf0, oy0, ox0, tile, lane);
+    wave_load_window64<W>(reinterpret_cast<const float*>(base0), Hf0, Wf0, oy0, ox0, tile, lane);
 #pragma unroll
     for (int r = 0; r < WW; ++r) f0[r] = tile[r * 68 + lane];
   }
@@ -676,26 +683,29 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
 // [N, 64, Hf, Wf] -> [N, Hf, Wf, 64]: one workgroup per (sample, row y, 64 pixels of the row); reads 64 channel
 // segments of 256 bytes (16-byte loads along x), writes one contiguous 16 KiB block; the transpose goes through an
 // LDS tile with an odd pitch.  grid (ceil(Wf / 64), Hf, N).
-__global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const float* __restrict__ src, float* __restrict__ dst, int Hf, int Wf,
+// T = float, or unsigned short for float16 / bfloat16 maps (2-byte elements moved as they are: half the bytes).
+template <typename T>
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const T* __restrict__ src, T* __restrict__ dst, int Hf, int Wf,
                                                         int N) {
-  __shared__ float tile[64 * 65];              // [x][c], pitch 65
+  struct alignas(4 * sizeof(T)) V4 { T x, y, z, w; };
+  __shared__ T tile[64 * 65];                  // [x][c], pitch 65
   const int tid = threadIdx.x;
   const int tx = (Wf + 63) / 64;
   const long total = (long)tx * Hf * N;        // (sample, row, 64-pixel piece) in a flat order walked in grid strides
   for (long t = blockIdx.x; t < total; t += gridDim.x) {
   const int x0 = (int)(t % tx) * 64, y = (int)((t / tx) % Hf), b = (int)(t / ((long)tx * Hf));
-  const float* in = src + ((long)b * 64 * Hf + y) * Wf + x0;      // + c * Hf * Wf
+  const T* in = src + ((long)b * 64 * Hf + y) * Wf + x0;      // + c * Hf * Wf
   const long plane = (long)Hf * Wf;
   const int nx = min(64, Wf - x0);
-  const bool vec = (Wf & 3) == 0;              // 16-byte aligned rows
-  float4 v[4];
+  const bool vec = (Wf & 3) == 0;              // rows aligned to 4 elements
+  V4 v[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {                // channel c = 16 p + tid / 16, pixels 4 (tid % 16) .. + 3
     const int c = 16 * p + (tid >> 4), xq = (tid & 15) * 4;
-    const float* row = in + c * plane;
-    if (vec && xq + 3 < nx) v[p] = *reinterpret_cast<const float4*>(row + xq);
-    else v[p] = make_float4(xq < nx ? row[xq] : 0.f, xq + 1 < nx ? row[xq + 1] : 0.f, xq + 2 < nx ? row[xq + 2] : 0.f,
-                            xq + 3 < nx ? row[xq + 3] : 0.f);
+    const T* row = in + c * plane;
+    if (vec && xq + 3 < nx) v[p] = *reinterpret_cast<const V4*>(row + xq);
+    else v[p] = V4{xq < nx ? row[xq] : T(0), xq + 1 < nx ? row[xq + 1] : T(0), xq + 2 < nx ? row[xq + 2] : T(0),
+                   xq + 3 < nx ? row[xq + 3] : T(0)};
   }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -704,12 +714,12 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const float* __restrict_
     tile[(xq + 2) * 65 + c] = v[p].z; tile[(xq + 3) * 65 + c] = v[p].w;
   }
   __syncthreads();
-  float4* out = reinterpret_cast<float4*>(dst + (((long)b * Hf + y) * Wf + x0) * 64);
+  V4* out = reinterpret_cast<V4*>(dst + (((long)b * Hf + y) * Wf + x0) * 64);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {                // pixel x = 16 p + tid / 16, channels 4 (tid % 16) .. + 3
     const int x = 16 * p + (tid >> 4), c4 = (tid & 15) * 4;
     if (x < nx)
-      out[x * 16 + (tid & 15)] = make_float4(tile[x * 65 + c4], tile[x * 65 + c4 + 1], tile[x * 65 + c4 + 2], tile[x * 65 + c4 + 3]);
+      out[x * 16 + (tid & 15)] = V4{tile[x * 65 + c4], tile[x * 65 + c4 + 1], tile[x * 65 + c4 + 2], tile[x * 65 + c4 + 3]};
   }
   __syncthreads();                             // the tile is rewritten by the next piece
   }
@@ -901,9 +911,69 @@ static bool maps64_ok(int Cf, int Hf, int Wf, int W) {
   return Cf == 64 && (W == 5 || W == 7) && (long)Hf * Wf * 256 < (1L << 31);
 }
 
-extern "C" size_t fm_fine_maps_scratch_bytes(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout) {
+extern "C" size_t fm_fine_maps_scratch_bytes_dtype(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout, int map_dtype) {
   if (layout != 0 || N <= 0 || Cf <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0) return 0;
-  return (size_t)N * Cf * 4 * (size_t)Hf1 * Wf1;      // the channels-last copy of image 1
+  if (map_dtype == FM_F32) return (size_t)N * Cf * 4 * (size_t)Hf1 * Wf1;      // the channels-last copy of image 1
+  // half-precision maps: channels-last copies of BOTH images (2-byte elements), image 0's first, 256-byte aligned
+  const size_t b0 = (size_t)N * Cf * 2 * (size_t)Hf0 * Wf0, b1 = (size_t)N * Cf * 2 * (size_t)Hf1 * Wf1;
+  return align256(b0) + b1;
+}
+extern "C" size_t fm_fine_maps_scratch_bytes(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout) {
+  return fm_fine_maps_scratch_bytes_dtype(N, Cf, Hf0, Wf0, Hf1, Wf1, layout, FM_F32);
+}
+
+extern "C" int fm_fine_match_maps_dtype(const void* feat_f0, const void* feat_f1, int map_dtype, int layout, int N, int Cf,
+                                        int Hf0, int Wf0, int Hf1, int Wf1, int W, int stride, int pad, int w0c, int w1c,
+                                        const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids,
+                                        const int32_t* d_count, int m_max, const float* mix0, const float* mix1,
+                                        const float* mkpts0_c, const float* mkpts1_c, float scale_f, void* scratch,
+                                        float* out0, float* out1, void* stream) {
+  if (m_max == 0) return FM_OK;
+  if (!feat_f0 || !feat_f1 || !b_ids || !i_ids || !j_ids || !mix0 || !mix1 || !mkpts0_c || !mkpts1_c || !out0 || !out1)
+    return FM_E_NULL;
+  if (N <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0 || stride <= 0 || w0c <= 0 || w1c <= 0 || m_max < 0)
+    return FM_E_SHAPE;
+  if (map_dtype != FM_F32 && map_dtype != FM_F16 && map_dtype != FM_BF16) return FM_E_UNSUPPORTED;
+  if ((layout != 0 && layout != 1) || !maps64_ok(Cf, Hf0, Wf0, W) || !maps64_ok(Cf, Hf1, Wf1, W)) return FM_E_UNSUPPORTED;
+  if (layout == 0 && !scratch) return FM_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const float* m0 = (const float*)feat_f0;
+  const float* m1 = (const float*)feat_f1;
+  int grid_cap = kFineGridCap;
+#ifdef FM_TUNE_ENV
+  if (const char* e = getenv("FM_FINE_GRID")) grid_cap = atoi(e) > 0 ? atoi(e) / 8 * 8 : kFineGridCap;
+#endif
+  const bool half = map_dtype != FM_F32;
+  if (layout == 0 && !half) {   // NCHW: a channels-last copy of image 1 (coalesced on both sides); image 0 is read as it is
+    float* s1 = (float*)scratch;
+    const long pieces = (long)((Wf1 + 63) / 64) * Hf1 * N;
+    hipLaunchKernelGGL(k_nchw_to_nhwc64<float>, dim3((unsigned)(pieces < grid_cap ? pieces : grid_cap)), dim3(256), 0, st,
+                       (const float*)feat_f1, s1, Hf1, Wf1, N);
+    m1 = s1;
+  } else if (layout == 0) {     // NCHW float16 / bfloat16: channels-last copies of both maps, element type kept
+    unsigned short* s0 = (unsigned short*)scratch;
+    unsigned short* s1 = (unsigned short*)((char*)scratch + align256((size_t)N * Cf * 2 * (size_t)Hf0 * Wf0));
+    const long p0 = (long)((Wf0 + 63) / 64) * Hf0 * N, p1 = (long)((Wf1 + 63) / 64) * Hf1 * N;
+    hipLaunchKernelGGL(k_nchw_to_nhwc64<unsigned short>, dim3((unsigned)(p0 < grid_cap ? p0 : grid_cap)), dim3(256), 0, st,
+                       (const unsigned short*)feat_f0, s0, Hf0, Wf0, N);
+    hipLaunchKernelGGL(k_nchw_to_nhwc64<unsigned short>, dim3((unsigned)(p1 < grid_cap ? p1 : grid_cap)), dim3(256), 0, st,
+                       (const unsigned short*)feat_f1, s1, Hf1, Wf1, N);
+    m0 = (const float*)s0;
+    m1 = (const float*)s1;
+  }
+  const int blocks = list_blocks(m_max) < grid_cap ? list_blocks(m_max) : grid_cap;
+#define FM_FINE_MAPS_LAUNCH(WQ, N0, DTQ)                                                                                 \
+  hipLaunchKernelGGL((k_fine_maps<WQ, N0, DTQ>), dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, \
+                     w0c, w1c, b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1)
+#define FM_FINE_MAPS_W(WQ)                                                        \
+  if (map_dtype == FM_F16) FM_FINE_MAPS_LAUNCH(WQ, false, FM_F16);                \
+  else if (map_dtype == FM_BF16) FM_FINE_MAPS_LAUNCH(WQ, false, FM_BF16);         \
+  else if (layout == 0) FM_FINE_MAPS_LAUNCH(WQ, true, FM_F32);                    \
+  else FM_FINE_MAPS_LAUNCH(WQ, false, FM_F32)
+  if (W == 5) { FM_FINE_MAPS_W(5); } else { FM_FINE_MAPS_W(7); }
+#undef FM_FINE_MAPS_W
+#undef FM_FINE_MAPS_LAUNCH
+  return (int)hipGetLastError();
 }
 
 extern "C" int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, int layout, int N, int Cf, int Hf0, int Wf0,
@@ -911,33 +981,7 @@ extern "C" int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, in
                                   const int64_t* i_ids, const int64_t* j_ids, const int32_t* d_count, int m_max,
                                   const float* mix0, const float* mix1, const float* mkpts0_c, const float* mkpts1_c,
                                   float scale_f, void* scratch, float* out0, float* out1, void* stream) {
-  if (m_max == 0) return FM_OK;
-  if (!feat_f0 || !feat_f1 || !b_ids || !i_ids || !j_ids || !mix0 || !mix1 || !mkpts0_c || !mkpts1_c || !out0 || !out1)
-    return FM_E_NULL;
-  if (N <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0 || stride <= 0 || w0c <= 0 || w1c <= 0 || m_max < 0)
-    return FM_E_SHAPE;
-  if ((layout != 0 && layout != 1) || !maps64_ok(Cf, Hf0, Wf0, W) || !maps64_ok(Cf, Hf1, Wf1, W)) return FM_E_UNSUPPORTED;
-  if (layout == 0 && !scratch) return FM_E_NULL;
-  hipStream_t st = (hipStream_t)stream;
-  const float* m0 = feat_f0;
-  const float* m1 = feat_f1;
-  int grid_cap = kFineGridCap;
-#ifdef FM_TUNE_ENV
-  if (const char* e = getenv("FM_FINE_GRID")) grid_cap = atoi(e) > 0 ? atoi(e) / 8 * 8 : kFineGridCap;
-#endif
-  if (layout == 0) {       // NCHW: a channels-last copy of image 1 (coalesced on both sides); image 0 is read as it is
-    float* s1 = (float*)scratch;
-    const long pieces = (long)((Wf1 + 63) / 64) * Hf1 * N;
-    hipLaunchKernelGGL(k_nchw_to_nhwc64, dim3((unsigned)(pieces < grid_cap ? pieces : grid_cap)), dim3(256), 0, st, feat_f1, s1,
-                       Hf1, Wf1, N);
-    m1 = s1;
-  }
-  const int blocks = list_blocks(m_max) < grid_cap ? list_blocks(m_max) : grid_cap;
-#define FM_FINE_MAPS_LAUNCH(WQ, N0)                                                                                      \
-  hipLaunchKernelGGL((k_fine_maps<WQ, N0>), dim3(blocks), dim3(256), 0, st, m0, m1, Hf0, Wf0, Hf1, Wf1, stride, pad, w0c,  \
-                     w1c, b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, out0, out1)
-  if (W == 5) { if (layout == 0) FM_FINE_MAPS_LAUNCH(5, true); else FM_FINE_MAPS_LAUNCH(5, false); }
-  else { if (layout == 0) FM_FINE_MAPS_LAUNCH(7, true); else FM_FINE_MAPS_LAUNCH(7, false); }
-#undef FM_FINE_MAPS_LAUNCH
-  return (int)hipGetLastError();
+  return fm_fine_match_maps_dtype(feat_f0, feat_f1, FM_F32, layout, N, Cf, Hf0, Wf0, Hf1, Wf1, W, stride, pad, w0c, w1c,
+                                  b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, scratch,
+                                  out0, out1, stream);
 }

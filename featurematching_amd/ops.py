@@ -148,11 +148,63 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     return out
 
 
-# Shapes / thresholds whose candidate screening overflowed once (or whose similarity was flat once) start later calls
-# with the exact screening pass (the dense sum kernel) switched on: flat similarity - an untrained network, a tiny
-# thr, textureless images - would otherwise pay for the coarse stage twice on every forward.
-_NEEDS_EXACT_SCREENING = set()
-_NEEDS_DENSE = set()
+class ModeMemory:
+    """Which optional passes of the coarse stage a problem shape needed the last time it was seen.
+
+    `coarse_match` starts on the common path (four launches) and repeats a call with FM_MODE_DENSE / the exact
+    screening pass when the device reports FM_E_DENSE / FM_E_CANDIDATES.  Flat similarity - an untrained network, a
+    tiny thr, textureless images - would pay for the coarse stage twice on every forward, so the shape's flags are
+    remembered.  The memory is explicit and bounded:
+      * keyed by (shapes, thr, temperature); at most `capacity` keys, least recently used dropped first;
+      * it DECAYS: every `reprobe`-th call of a remembered shape runs on the common path again; when that call succeeds
+        the flags are forgotten (one flat sample does not tax a shape forever), when it fails it is repeated as before;
+      * guarded by a lock (module callers may run on several threads / streams);
+      * visible: `snapshot()` lists what is remembered and how often each flag was learnt, `clear()` forgets it.
+    Callers that know their data pass dense= / exact_screening= themselves and never touch it."""
+
+    def __init__(self, capacity: int = 64, reprobe: int = 64):
+        import threading
+        from collections import OrderedDict
+        self._lock = threading.Lock()
+        self._d = OrderedDict()          # key -> {'dense': bool, 'exact': bool, 'calls': int, 'learnt': int}
+        self.capacity, self.reprobe = capacity, reprobe
+
+    def start(self, key):
+        """(dense, exact_screening, probing) to begin a call with"""
+        with self._lock:
+            e = self._d.get(key)
+            if e is None:
+                return False, False, False
+            self._d.move_to_end(key)
+            e['calls'] += 1
+            if e['calls'] % self.reprobe == 0:
+                return False, False, True
+            return e['dense'], e['exact'], False
+
+    def learn(self, key, dense=False, exact=False):
+        with self._lock:
+            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'calls': 0, 'learnt': 0})
+            e['dense'] |= bool(dense)
+            e['exact'] |= bool(exact)
+            e['learnt'] += 1
+            self._d.move_to_end(key)
+            while len(self._d) > self.capacity:
+                self._d.popitem(last=False)
+
+    def forget(self, key):
+        with self._lock:
+            self._d.pop(key, None)
+
+    def clear(self):
+        with self._lock:
+            self._d.clear()
+
+    def snapshot(self):
+        with self._lock:
+            return {k: dict(v) for k, v in self._d.items()}
+
+
+MODE_MEMORY = ModeMemory()
 
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
@@ -160,18 +212,23 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
                  dense: Optional[bool] = None) -> dict:
     """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
     N*min(L,S)), with the dense sum kernel (FM_E_DENSE), with the exact screening pass, then with more candidate
-    slots when the device reports the corresponding condition.  exact_screening=None: on when conf_matrix is
+    slots when the device reports the corresponding condition, and once more when the assignment kernel's bounded
+    wait ran out (FM_E_INTERNAL: "call again", fmatch.h).  exact_screening=None: on when conf_matrix is
     requested (that path already runs the denominator reduction the exact screening needs, and it is the training /
-    untrained-network mode in which flat rows occur) or when this shape needed it before; dense=None likewise."""
+    untrained-network mode in which flat rows occur) or when MODE_MEMORY holds it for this shape; dense=None likewise."""
     lib = _lib.load()
     key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
+    mem_dense, mem_exact, probing = (False, False, False)
+    if exact_screening is None or dense is None:
+        mem_dense, mem_exact, probing = MODE_MEMORY.start(key)
     if exact_screening is None:
-        exact_screening = bool(conf_matrix) or key in _NEEDS_EXACT_SCREENING
+        exact_screening = bool(conf_matrix) or mem_exact
     if dense is None:
-        dense = key in _NEEDS_DENSE
+        dense = mem_dense
     kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening),
               dense=bool(dense))
-    for _ in range(7):
+    retried_internal = False
+    for _ in range(8):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
                                  scale0, scale1, conf_matrix=conf_matrix, **kw)
         try:
@@ -182,16 +239,23 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
                 continue
             if e.status == _lib.FM_E_DENSE and not kw['dense']:
                 kw['dense'] = True
-                _NEEDS_DENSE.add(key)
+                MODE_MEMORY.learn(key, dense=True)
+                probing = False
                 continue
             if e.status == _lib.FM_E_CANDIDATES and not kw['exact_screening']:
                 kw['exact_screening'] = True
-                _NEEDS_EXACT_SCREENING.add(key)
+                MODE_MEMORY.learn(key, exact=True)
+                probing = False
                 continue
             if e.status == _lib.FM_E_CANDIDATES and kw['cand_slots'] < 64:
                 kw['cand_slots'] = min(64, kw['cand_slots'] * 2)
                 continue
+            if e.status == _lib.FM_E_INTERNAL and not retried_internal:
+                retried_internal = True
+                continue
             raise
+        if probing:                      # the common path served a shape that once needed more: forget the flags
+            MODE_MEMORY.forget(key)
         out = buf.sliced(m)
         if conf_matrix:
             out['conf_matrix'] = buf.conf_matrix
@@ -368,8 +432,9 @@ def fine_match(win0: torch.Tensor, win1: torch.Tensor, mix0: torch.Tensor, mix1:
 
 
 def _map_layout(t: torch.Tensor):
-    """(tensor, layout) of a logical [N,Cf,Hf,Wf] fine map: 0 = NCHW-contiguous, 1 = channels-last storage"""
-    if t.dtype != torch.float32:
+    """(tensor, layout) of a logical [N,Cf,Hf,Wf] fine map: 0 = NCHW-contiguous, 1 = channels-last storage.  float32,
+    float16 and bfloat16 maps are taken as they are (fm_fine_match_maps_dtype: no up-cast pass)."""
+    if t.dtype not in _DTYPES:
         t = t.float()
     if t.is_contiguous():
         return t, 0
@@ -382,32 +447,38 @@ def fine_match_maps(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, 
                     w1c: int, mix0: torch.Tensor, mix1: torch.Tensor, mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor,
                     scale_f: float, pad: int = 2, count: Optional[torch.Tensor] = None,
                     scratch: Optional[torch.Tensor] = None):
-    """Window crop + fine stage from the maps in one call (fm_fine_match_maps; fine_preprocess.py:43-50 with plain
-    windows + fine_matching_new.py:50-79): no window tensors.  Channels-last maps are read in place; NCHW maps are
-    first copied to channels-last storage in `scratch` (allocated when not given).  Returns (mkpts0_f, mkpts1_f)."""
+    """Window crop + fine stage from the maps in one call (fm_fine_match_maps_dtype; fine_preprocess.py:43-50 with plain
+    windows + fine_matching_new.py:50-79): no window tensors.  Channels-last maps are read in place; of NCHW float32
+    maps image 1 is first copied to channels-last storage in `scratch` (allocated when not given), of NCHW float16 /
+    bfloat16 maps (an autocast backbone, network/net.py:56-57) both images are, in their own element type.
+    Returns (mkpts0_f, mkpts1_f), float32."""
     lib = _lib.load()
     if not feat_f0.is_cuda:
         raise RuntimeError("feat_f0 must live on the GPU: the HIP path has no CPU fallback")
     f0, lay0 = _map_layout(feat_f0)
     f1, lay1 = _map_layout(feat_f1)
+    if f1.dtype != f0.dtype:
+        f1 = f1.to(f0.dtype)
     if lay0 != lay1:                                 # one layout per call
         f1, lay1 = (f1.contiguous(), 0) if lay0 == 0 else (f1.contiguous(memory_format=torch.channels_last), 1)
     n, cf, hf0, wf0 = f0.shape
     hf1, wf1 = f1.shape[2:]
     dev = f0.device
+    dt = _DTYPES[f0.dtype]
     m_max = int(b_ids.shape[0])
     out0 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
     out1 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
     if m_max == 0:
         return out0, out1
-    need = int(lib.fm_fine_maps_scratch_bytes(n, cf, hf0, wf0, hf1, wf1, lay0))
+    need = int(lib.fm_fine_maps_scratch_bytes_dtype(n, cf, hf0, wf0, hf1, wf1, lay0, dt))
     if need and (scratch is None or scratch.numel() * scratch.element_size() < need):
         scratch = torch.empty(need, dtype=torch.uint8, device=dev)
-    st = lib.fm_fine_match_maps(_ptr(f0), _ptr(f1), lay0, n, cf, hf0, wf0, hf1, wf1, w, stride, pad, int(w0c), int(w1c),
-                                _ptr(b_ids), _ptr(i_ids), _ptr(j_ids), _ptr(count), m_max, _ptr(_f32c(mix0, "mix0")),
-                                _ptr(_f32c(mix1, "mix1")), _ptr(_f32c(mkpts0_c, "mkpts0_c")), _ptr(_f32c(mkpts1_c, "mkpts1_c")),
-                                float(scale_f), _ptr(scratch) if need else None, _ptr(out0), _ptr(out1), _stream(dev))
-    _lib.check(st, "fm_fine_match_maps")
+    st = lib.fm_fine_match_maps_dtype(_ptr(f0), _ptr(f1), dt, lay0, n, cf, hf0, wf0, hf1, wf1, w, stride, pad, int(w0c),
+                                      int(w1c), _ptr(b_ids), _ptr(i_ids), _ptr(j_ids), _ptr(count), m_max,
+                                      _ptr(_f32c(mix0, "mix0")), _ptr(_f32c(mix1, "mix1")), _ptr(_f32c(mkpts0_c, "mkpts0_c")),
+                                      _ptr(_f32c(mkpts1_c, "mkpts1_c")), float(scale_f), _ptr(scratch) if need else None,
+                                      _ptr(out0), _ptr(out1), _stream(dev))
+    _lib.check(st, "fm_fine_match_maps_dtype")
     out0._keep = (f0, f1, scratch)
     return out0, out1
 

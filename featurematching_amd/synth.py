@@ -126,6 +126,8 @@ CONFIGS = {
     "cfg2": dict(n=1, h=480, w=640, c=256, cf=64, seed=1),
     "cfg3": dict(n=64, h=480, w=640, c=256, cf=64, seed=2),
     "cfg5": dict(n=1, h=1024, w=1024, c=256, cf=64, seed=5),
+    # the 9600 x 9600 cost volume BASELINE.json's config 5 mentions in passing: 640 x 960 -> 80 x 120 cells
+    "l9600": dict(n=1, h=640, w=960, c=256, cf=64, seed=6),
 }
 
 

@@ -21,11 +21,19 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-def linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
-    """"Transformers are RNNs" attention with the elu(x)+1 feature map (attentions.py:19-46, no masks).
-    q [N,L,H,D], k,v [N,S,H,D] -> [N,L,H,D].  Per head: out_l = phi(q_l) (sum_s phi(k_s) v_s^T) / (phi(q_l).sum_s phi(k_s))."""
+def linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: float = 1e-6, q_mask=None,
+                     kv_mask=None) -> torch.Tensor:
+    """"Transformers are RNNs" attention with the elu(x)+1 feature map (attentions.py:19-46).
+    q [N,L,H,D], k,v [N,S,H,D] -> [N,L,H,D].  Per head: out_l = phi(q_l) (sum_s phi(k_s) v_s^T) / (phi(q_l).sum_s phi(k_s)).
+    q_mask [N,L] / kv_mask [N,S] zero the padded positions of phi(q) / of phi(k) and v (:35-40); the values are divided
+    by the PADDED length S either way, as in the reference."""
     q = F.elu(q) + 1
     k = F.elu(k) + 1
+    if q_mask is not None:
+        q = q * q_mask[:, :, None, None]
+    if kv_mask is not None:
+        k = k * kv_mask[:, :, None, None]
+        v = v * kv_mask[:, :, None, None]
     s = v.shape[1]
     kv = torch.einsum("nshd,nshv->nhdv", k, v / s)            # values are pre-divided by S, as in the reference
     z = 1.0 / (torch.einsum("nlhd,nhd->nlh", q, k.sum(dim=1)) + eps)
@@ -47,10 +55,11 @@ class EncoderLayer(nn.Module):
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
 
-    def forward(self, x: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, source: torch.Tensor, x_mask=None, source_mask=None) -> torch.Tensor:
         n, l, _ = x.shape
         heads = lambda t: t.view(n, -1, self.nhead, self.dim)
-        msg = linear_attention(heads(self.q_proj(x)), heads(self.k_proj(source)), heads(self.v_proj(source)))
+        msg = linear_attention(heads(self.q_proj(x)), heads(self.k_proj(source)), heads(self.v_proj(source)),
+                               q_mask=x_mask, kv_mask=source_mask)
         msg = self.norm1(self.merge(msg.reshape(n, l, -1)))
         msg = self.norm2(self.mlp(torch.cat([x, msg], dim=2)))
         return x + msg
@@ -62,12 +71,21 @@ class LocalFeatureTransformer(nn.Module):
     in eval mode too (tools that time one against the other).  The fine kernel splits its operands into float16 halves
     at a per-match power-of-two scale that it lowers itself when a match needs it (see fmatch.h); what does not fit at
     its smallest scale either (|activation| ~ 1e6, NaN / Inf, a weight >= 16) it reports: with check_range (default) the
-    module reads that report (one host sync per call) and redoes such a call with the float32 torch layers."""
+    module reads that report (one host sync per call) and redoes such a call with the float32 torch layers.  The read is
+    skipped while a hipGraph is being captured (a capture cannot synchronise the host) and with check_range=False
+    (callers that know their value ranges); the kernel's report then stays in `last_status` (an int32 device tensor the
+    caller may read when it synchronises anyway: bit _lib.FM_DEV_RANGE = discard the outputs).  `range_fallbacks`
+    counts the calls that were redone.
+    inference_only=True (default) lets the eval-mode HIP path run even when the layers' own parameters require grad -
+    the outputs then carry no graph through the parameters (a warning says so once); False sends such calls through
+    the torch layers, as a fine-tuning run that freezes batch norm with .eval() needs."""
 
-    def __init__(self, config, use_hip: bool = True, check_range: bool = True):
+    def __init__(self, config, use_hip: bool = True, check_range: bool = True, inference_only: bool = True):
         super().__init__()
-        self.use_hip, self.check_range = use_hip, check_range
+        self.use_hip, self.check_range, self.inference_only = use_hip, check_range, inference_only
         self.range_fallbacks = 0
+        self.last_status = None
+        self._warned_detached = False
         if config.get('attention', 'linear') != 'linear':
             raise NotImplementedError("only the reference's default linear attention is provided")
         self.d_model, self.layer_names = config['d_model'], list(config['layer_names'])
@@ -82,6 +100,17 @@ class LocalFeatureTransformer(nn.Module):
         cross sequence), None = the torch ops below.  Eval mode on float32 GPU tensors that do not ask for a gradient;
         grad MODE alone does not matter (the reference's demo calls the eval-mode matcher without no_grad)."""
         wants_grad = torch.is_grad_enabled() and (feat0.requires_grad or feat1.requires_grad)
+        if not wants_grad and not self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # eval mode, grad mode on, trainable parameters, inputs without grad (a frozen backbone under no_grad, or
+            # .eval() used to freeze batch norm while fine-tuning): the reference would build a graph through the
+            # layers' parameters here; the HIP kernels do not
+            if not self.inference_only:
+                wants_grad = True
+            elif self.use_hip and feat0.is_cuda and not self._warned_detached:
+                self._warned_detached = True
+                import warnings
+                warnings.warn("LocalFeatureTransformer: eval-mode HIP kernels return tensors without a graph through the "
+                              "layers' parameters; pass inference_only=False (or call .train()) to fine-tune them")
         if not self.use_hip or self.training or wants_grad or not feat0.is_cuda or feat0.dtype != torch.float32 \
                 or feat1.dtype != torch.float32 or self.layers[0].nhead != 8 or feat0.shape[0] != feat1.shape[0]:
             return None
@@ -110,29 +139,36 @@ class LocalFeatureTransformer(nn.Module):
         """network/module/transformer.py:78 (`net.forward` passes mask0 = mask1 = None, net.py:73-74)"""
         assert feat0.shape[2] == self.d_model, "the feature number of src and transformer must be equal"
         if mask0 is not None or mask1 is not None:
-            raise NotImplementedError("padding masks are not provided (the reference's net.forward passes None)")
+            # padding masks (transformer.py:89-95, attentions.py:35-40): `net.forward` passes None (net.py:73-74); a
+            # caller that pads its batches gets the torch layers
+            return self._torch_layers(feat0, feat1, mask0, mask1)
         kind = self._hip_kind(feat0, feat1)
         if kind is not None:
-            from . import ops
+            from . import _lib, ops
             with torch.no_grad():
                 packed = self._packed(feat0.device, kind)
                 if kind == 'coarse':
                     return ops.coarse_transformer(feat0, feat1, packed, self.layer_names)
-                status = torch.zeros(1, dtype=torch.int32, device=feat0.device) if self.check_range else None
+                status = torch.zeros(1, dtype=torch.int32, device=feat0.device)
                 out = ops.fine_transformer(feat0, feat1, packed, status=status)
-                if status is None or not (int(status.item()) & 4):       # FM_DEV_RANGE
+                self.last_status = status
+                if not self.check_range or torch.cuda.is_current_stream_capturing():
+                    return out
+                if not (int(status.item()) & _lib.FM_DEV_RANGE):
                     return out
                 self.range_fallbacks += 1          # values beyond the kernel's float16 operand scales: float32 layers
                 return self._torch_layers(feat0, feat1)
         return self._torch_layers(feat0, feat1)
 
-    def _torch_layers(self, feat0, feat1):
+    def _torch_layers(self, feat0, feat1, mask0=None, mask1=None):
+        m0 = None if mask0 is None else mask0.to(feat0.dtype)
+        m1 = None if mask1 is None else mask1.to(feat1.dtype)
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
-                feat0, feat1 = layer(feat0, feat0), layer(feat1, feat1)
+                feat0, feat1 = layer(feat0, feat0, m0, m0), layer(feat1, feat1, m1, m1)
             elif name == 'cross':
-                feat0 = layer(feat0, feat1)
-                feat1 = layer(feat1, feat0)          # sees the UPDATED feat0, as in the reference (:93-94)
+                feat0 = layer(feat0, feat1, m0, m1)
+                feat1 = layer(feat1, feat0, m1, m0)  # sees the UPDATED feat0, as in the reference (:93-94)
             else:
                 raise KeyError(name)
         return feat0, feat1

@@ -258,6 +258,21 @@ int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, int layout, i
                        void* scratch, float* out0, float* out1, void* stream);
 
 /*
+ * The same with the element type of the maps as an argument (enum fm_dtype): FM_F16 / FM_BF16 maps - what a backbone
+ * under autocast hands over (network/net.py:56-57) - are read as they are, no up-cast pass.  Every float16 /
+ * bfloat16 value is exact in float32 and the arithmetic is the float32 call's, so the result equals
+ * fm_fine_match_maps on the up-cast maps bit for bit.  layout 1: the 2-byte channels-last maps are read in place
+ * (128 bytes per pixel).  layout 0 (NCHW): BOTH maps get channels-last copies in `scratch`, in their own element type
+ * (half the bytes of the float32 route's copy); fm_fine_maps_scratch_bytes_dtype sizes it.
+ */
+size_t fm_fine_maps_scratch_bytes_dtype(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout, int map_dtype);
+int fm_fine_match_maps_dtype(const void* feat_f0, const void* feat_f1, int map_dtype, int layout, int N, int Cf, int Hf0,
+                             int Wf0, int Hf1, int Wf1, int W, int stride, int pad, int w0c, int w1c,
+                             const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, const int32_t* d_count,
+                             int m_max, const float* mix0, const float* mix1, const float* mkpts0_c,
+                             const float* mkpts1_c, float scale_f, void* scratch, float* out0, float* out1, void* stream);
+
+/*
  * Coarse-level context layers in front of the coarse matching (network/net.py:74): the reference's
  * LocalFeatureTransformer (network/module/transformer.py:34-57,78-96, attentions.py:19-46) in its default coarse
  * configuration - d_model 256, 8 heads, linear attention, no masks, any sequence of 'self' / 'cross' layers - on

@@ -403,9 +403,36 @@ def kat_cases_round2():
     np.savez_compressed(os.path.join(HERE, "kats_r2.npz"), **cases)
 
 
+def masked_transformer_case(name="tf_masked_small"):
+    """The reference's LocalFeatureTransformer WITH padding masks (network/module/transformer.py:78-96,
+    attentions.py:35-40) on a small seeded problem: d_model 64, 8 heads, ['self', 'cross'], N = 2, L = 40, S = 36, the
+    last positions of each sample masked out.  Inputs and weights come from the portable RNG (the test regenerates
+    them); stored: the outputs."""
+    from network.module.transformer import LocalFeatureTransformer
+    seed, n, l, s_, d = 41, 2, 40, 36, 64
+    names = ['self', 'cross']
+    tf = LocalFeatureTransformer(dict(d_model=d, nhead=8, layer_names=names, attention='linear')).eval()
+    tf.load_state_dict({k: torch.as_tensor(v) for k, v in synth.transformer_weights(seed, d, 2).items()})
+    x0 = torch.as_tensor(synth.normal(seed, 1, (n, l, d)))
+    x1 = torch.as_tensor(synth.normal(seed, 2, (n, s_, d)))
+    m0 = torch.ones(n, l, dtype=torch.bool); m0[0, 33:] = False; m0[1, 25:] = False
+    m1 = torch.ones(n, s_, dtype=torch.bool); m1[0, 30:] = False
+    with torch.no_grad():
+        y0, y1 = tf(x0, x1, m0, m1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), out0=y0.numpy(), out1=y1.numpy(),
+                        mask0=m0.numpy(), mask1=m1.numpy(), meta=np.array([seed, n, l, s_, d], np.int64))
+    print(f"{name}: out0 {tuple(y0.shape)} |max| {float(y0.abs().max()):.3f}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "r4":     # the fixtures added in round 4 only
+        masked_transformer_case()
+        full_case("l9600_peaky", "l9600", "peaky")
+        full_case("l9600_borderline", "l9600", "borderline", with_fine=False)
+        full_case("cfg5_peaky", "cfg5", "peaky")         # now with the fine stage (W = 7)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r2":       # only the round-2 cases (the others are unchanged)
         kat_cases_round2()
         net_tail_case()
@@ -430,7 +457,7 @@ if __name__ == "__main__":
     full_case("cfg2_peaky", "cfg2", "peaky")
     full_case("cfg2_borderline", "cfg2", "borderline")
     full_case("cfg3_first2_peaky", "cfg3", "peaky", n=2)
-    full_case("cfg5_peaky", "cfg5", "peaky", with_fine=False)
+    full_case("cfg5_peaky", "cfg5", "peaky")
     merge_case("merge_cfg1_w7", "cfg1", "peaky", 7)
     merge_case("merge_cfg2_w5", "cfg2", "borderline", 5)
     # round 3: the reference's dual softmax at S = 16384 and at batch size on data whose conf values are NOT all 1.0,
@@ -438,3 +465,7 @@ if __name__ == "__main__":
     full_case("cfg2_mixed", "cfg2", "mixed")
     full_case("cfg3_first2_borderline", "cfg3", "borderline", with_fine=False, n=2)
     full_case("cfg5_borderline", "cfg5", "borderline", with_fine=False)
+    # round 4: padding masks in the context layers, the L = 9600 cost volume (cfg#5 above now with its fine stage)
+    masked_transformer_case()
+    full_case("l9600_peaky", "l9600", "peaky")
+    full_case("l9600_borderline", "l9600", "borderline", with_fine=False)

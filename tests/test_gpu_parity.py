@@ -85,6 +85,75 @@ def test_full_path_against_reference_fixture(name, dist):
     np.testing.assert_allclose(k1.cpu().numpy()[gi, 2], g['mkpts1_f'][ri, 2], atol=1e-4)
 
 
+def _common_rows(out, g):
+    gk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(out['b_ids'].tolist(), out['i_ids'].tolist(), out['j_ids'].tolist()))}
+    rk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(g['b_ids'], g['i_ids'], g['j_ids']))}
+    common = [k for k in gk if k in rk]
+    return np.array([gk[k] for k in common]), np.array([rk[k] for k in common]), len(rk)
+
+
+def _mix_tensors(mix):
+    w0, b0, w1, b1 = mix
+    return (torch.as_tensor(np.concatenate([w0, [b0]]).astype(np.float32), device=DEV),
+            torch.as_tensor(np.concatenate([w1, [b1]]).astype(np.float32), device=DEV))
+
+
+def _maps(inp, layout):
+    ff0, ff1 = torch.as_tensor(inp['ff0'], device=DEV), torch.as_tensor(inp['ff1'], device=DEV)
+    if layout == "nhwc":
+        ff0, ff1 = ff0.contiguous(memory_format=torch.channels_last), ff1.contiguous(memory_format=torch.channels_last)
+    return ff0, ff1
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("name,dist", [("cfg2_peaky", "peaky"), ("cfg2_borderline", "borderline"),
+                                       ("l9600_peaky", "peaky"), ("cfg5_peaky", "peaky")])
+def test_bench_path_against_reference_fixture(name, dist, layout):
+    """The entry points the bench times - fm_coarse_match, then crop + fine straight from the maps (fm_fine_match_maps;
+    NCHW maps as the reference hands them over, and channels-last storage) - at the bench's sizes (640x480, 640x960 =
+    the L = 9600 cost volume, 1024x1024) against the REFERENCE's own outputs, W = 7 (fine_matching_new.py fixes WW = 49)."""
+    g = load_golden(name)
+    inp = case_inputs(g['meta'], dist)
+    out = _run_coarse(inp['f0'], inp['f1'], inp['hw_i'], inp['hw_c'], inp['hw_c'])
+    ndiff = _assert_coarse(out, g)
+    assert ndiff <= 4, f"{ndiff} guard-band flips"
+    gi, ri, nref = _common_rows(out, g)
+    assert len(gi) >= nref - 4
+    ff0, ff1 = _maps(inp, layout)
+    mix0, mix1 = _mix_tensors(inp['mix'])
+    wc = inp['hw_c'][1]
+    k0, k1 = ops.fine_match_maps(ff0, ff1, out['b_ids'], out['i_ids'], out['j_ids'], 7, 4, wc, wc, mix0, mix1,
+                                 out['mkpts0_c'], out['mkpts1_c'], inp['hw_i'][0] / inp['hw_f'][0])
+    assert np.abs(k0.cpu().numpy()[gi, :2] - g['mkpts0_f'][ri, :2]).max() <= FINE_TOL_PX
+    assert np.abs(k1.cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= FINE_TOL_PX
+    np.testing.assert_allclose(k0.cpu().numpy()[gi, 2], g['mkpts0_f'][ri, 2], atol=1e-4)
+    np.testing.assert_allclose(k1.cpu().numpy()[gi, 2], g['mkpts1_f'][ri, 2], atol=1e-4)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_headline_step_w5_at_cfg2_against_oracle(layout):
+    """The metric's own configuration - one 640x480 pair, 5x5 fine window (BASELINE.json configs[1]) - through the
+    calls bench.py times.  The reference's fine_matching_new.py cannot run W = 5 (nn.Linear(49, 1)); the oracle (pinned
+    at W = 7 by the fixtures, W a parameter of the same code) is the checker."""
+    cfg = synth.CONFIGS["cfg2"]
+    sh = synth.config_shapes(cfg)
+    f0, f1 = synth.coarse_descriptors(cfg['seed'], 1, sh['l'], cfg['c'], "peaky")
+    ff0, ff1 = synth.fine_maps(cfg['seed'], 1, cfg['cf'], sh['hf'], sh['wf'])
+    mix = synth.mix_weights(cfg['seed'], 25)
+    hw_i, hw_c = (cfg['h'], cfg['w']), (sh['hc'], sh['wc'])
+    ref = {k: v.numpy() for k, v in orc.match_features(f0, f1, ff0, ff1, hw_i, mix, w=5).items()}
+    out = _run_coarse(f0, f1, hw_i, hw_c, hw_c)
+    _assert_coarse(out, ref)
+    gi, ri, nref = _common_rows(out, ref)
+    assert len(gi) == nref and nref > 3000
+    t0, t1 = _maps(dict(ff0=ff0, ff1=ff1), layout)
+    mix0, mix1 = _mix_tensors(mix)
+    k0, k1 = ops.fine_match_maps(t0, t1, out['b_ids'], out['i_ids'], out['j_ids'], 5, 4, hw_c[1], hw_c[1], mix0, mix1,
+                                 out['mkpts0_c'], out['mkpts1_c'], hw_i[0] / sh['hf'])
+    assert np.abs(k0.cpu().numpy()[gi] - ref['mkpts0_f'][ri]).max() <= FINE_TOL_PX
+    assert np.abs(k1.cpu().numpy()[gi] - ref['mkpts1_f'][ri]).max() <= FINE_TOL_PX
+
+
 def test_cfg5_coarse_against_reference_fixture():
     g = load_golden("cfg5_peaky")                       # 1024x1024 -> L = S = 16384
     inp = case_inputs(g['meta'], "peaky", with_fine=False)
@@ -92,7 +161,7 @@ def test_cfg5_coarse_against_reference_fixture():
     _assert_coarse(out, g)
 
 
-@pytest.mark.parametrize("name", ["cfg3_first2_borderline", "cfg5_borderline"])
+@pytest.mark.parametrize("name", ["cfg3_first2_borderline", "cfg5_borderline", "l9600_borderline"])
 def test_coarse_on_non_degenerate_data_against_reference_fixture(name):
     """The reference's own outputs on 'borderline' data (conf spread over (0.2, 1)) for two samples of the cfg#3 batch
     and at S = 16384 (cfg#5), where the sparse kernel's S * 2^-32 truncation and the dense kernel's 22-bit products
@@ -275,12 +344,27 @@ def test_flat_rows_with_conf_matrix_run_the_coarse_stage_once(monkeypatch):
     _assert_coarse(out, ref)
     # and a shape that overflowed once starts with the exact screening (and the dense sum kernel) the next time
     calls.clear()
-    ops._NEEDS_EXACT_SCREENING.clear()
-    ops._NEEDS_DENSE.clear()
+    ops.MODE_MEMORY.clear()
     ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
     n_first = len(calls)
     ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
     assert 2 <= n_first <= 3 and calls[0] is False and calls[n_first - 1] is True and calls[n_first:] == [True]
+    # the memory is visible, bounded and decays: the `reprobe`-th call of the shape starts on the common path again,
+    # fails there for this data and is repeated with the flags; peaked data of the same shape makes it forget them
+    snap = ops.MODE_MEMORY.snapshot()
+    assert len(snap) == 1 and list(snap.values())[0]['exact']
+    monkeypatch.setattr(ops.MODE_MEMORY, "reprobe", 2)
+    calls.clear()
+    ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)            # 2nd remembered call: a probe of the common path
+    assert calls[0] is False and calls[-1] is True
+    p0, p1 = synth.coarse_descriptors(77, f0.shape[0], 1200, f0.shape[2], "peaky")
+    q0, q1 = torch.as_tensor(p0, device=DEV), torch.as_tensor(p1, device=DEV)
+    calls.clear()
+    ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)            # remembered flags
+    ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)            # probe: succeeds on this data, the shape is forgotten
+    ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)
+    assert calls == [True, False, False] and not ops.MODE_MEMORY.snapshot()
+    ops.MODE_MEMORY.clear()
 
 
 def test_coarse_without_cell_maps_gives_the_same_matches():
@@ -377,6 +461,34 @@ def test_fine_match_from_the_maps(w, channels_last):
     assert torch.equal(win0.cpu(), orc.crop_windows(ff0, bt, it, w, 4, w0c))            # (the 16-byte-chunk crop is exact)
     h0, h1 = ops.fine_match(win0, win1, mix0, mix1, k0d, k1d, 2.0)
     assert torch.equal(g0[:m - 7], h0[:m - 7]) and torch.equal(g1[:m - 7], h1[:m - 7])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("w", [5, 7])
+def test_half_precision_fine_maps_need_no_upcast(w, channels_last, dtype):
+    """float16 / bfloat16 fine maps (an autocast backbone's hand-over, network/net.py:56-57) go to
+    fm_fine_match_maps_dtype as they are: every such value is exact in float32 and the arithmetic is the float32
+    call's, so the result equals the call on the up-cast maps bit for bit.  Odd map widths, cells on the borders."""
+    n, (h0c, w0c), (h1c, w1c) = 2, (9, 13), (11, 10)
+    ff0 = torch.as_tensor(np.stack([synth.normal(271 + b, 1, (64, h0c * 4, w0c * 4)) for b in range(n)]), device=DEV).to(dtype)
+    ff1 = torch.as_tensor(np.stack([synth.normal(271 + b, 2, (64, h1c * 4, w1c * 4)) for b in range(n)]), device=DEV).to(dtype)
+    m = 120
+    b = torch.as_tensor(np.sort((synth.uniform(271, 3, m) * n).astype(np.int64)), device=DEV)
+    i = (synth.uniform(271, 4, m) * h0c * w0c).astype(np.int64)
+    j = (synth.uniform(271, 5, m) * h1c * w1c).astype(np.int64)
+    i[:4] = [0, w0c - 1, (h0c - 1) * w0c, h0c * w0c - 1]
+    j[:4] = [h1c * w1c - 1, 0, w1c - 1, (h1c - 1) * w1c]
+    kc0 = torch.as_tensor(np.stack([(i % w0c) * 8.0, (i // w0c) * 8.0], 1).astype(np.float32), device=DEV)
+    kc1 = torch.as_tensor(np.stack([(j % w1c) * 8.0, (j // w1c) * 8.0], 1).astype(np.float32), device=DEV)
+    it, jt = torch.as_tensor(i, device=DEV), torch.as_tensor(j, device=DEV)
+    mix0, mix1 = _mix_tensors(synth.mix_weights(271, w * w))
+    if channels_last:
+        ff0, ff1 = ff0.contiguous(memory_format=torch.channels_last), ff1.contiguous(memory_format=torch.channels_last)
+    g0, g1 = ops.fine_match_maps(ff0, ff1, b, it, jt, w, 4, w0c, w1c, mix0, mix1, kc0, kc1, 2.0)
+    h0, h1 = ops.fine_match_maps(ff0.float(), ff1.float(), b, it, jt, w, 4, w0c, w1c, mix0, mix1, kc0, kc1, 2.0)
+    assert g0.dtype == torch.float32 and torch.equal(g0, h0) and torch.equal(g1, h1)
+    assert torch.isfinite(g0).all() and (g0[:, :2] - kc0).abs().max() < 16
 
 
 # ------------------------------------------------------------------ drop-in modules

@@ -63,3 +63,41 @@ def test_default_config_is_the_reference_s():
     assert c['coarse']['d_model'] == 256 and c['fine']['d_model'] == 64
     assert c['match_coarse']['thr'] == 0.2 and c['match_coarse']['border_rm'] == 2
     assert c['match_coarse']['dsmax_temperature'] == 0.1
+
+
+def test_context_layers_with_padding_masks_match_the_reference():
+    """network/module/transformer.py:78-96 with mask0 / mask1 (attentions.py:35-40 zeroes the padded positions of
+    phi(q), phi(k) and v): the module's torch layers - the route a masked call takes - against outputs of the
+    reference's own LocalFeatureTransformer (tests/golden/make_golden.py:masked_transformer_case)."""
+    import numpy as np
+    import torch
+    from featurematching_amd import synth
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    from helpers import load_golden
+    g = load_golden("tf_masked_small")
+    seed, n, l, s, d = [int(v) for v in g['meta']]
+    tf = LocalFeatureTransformer(dict(d_model=d, nhead=8, layer_names=['self', 'cross'], attention='linear')).eval()
+    tf.load_state_dict({k: torch.as_tensor(v) for k, v in synth.transformer_weights(seed, d, 2).items()})
+    x0, x1 = torch.as_tensor(synth.normal(seed, 1, (n, l, d))), torch.as_tensor(synth.normal(seed, 2, (n, s, d)))
+    with torch.no_grad():
+        y0, y1 = tf(x0, x1, torch.as_tensor(g['mask0']), torch.as_tensor(g['mask1']))
+        z0, _ = tf(x0, x1)
+    np.testing.assert_allclose(y0.numpy(), g['out0'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(y1.numpy(), g['out1'], rtol=0, atol=2e-5)
+    assert (y0 - z0).abs().max() > 1e-2          # the masks matter
+
+
+def test_mode_memory_is_bounded_decays_and_forgets():
+    """ops.ModeMemory: which optional coarse passes a shape needed before - LRU-bounded, re-probing every k-th call,
+    forgettable, behind a lock (no GPU involved)."""
+    from featurematching_amd.ops import ModeMemory
+    m = ModeMemory(capacity=2, reprobe=3)
+    assert m.start('a') == (False, False, False)
+    m.learn('a', dense=True); m.learn('b', exact=True); m.learn('c', dense=True)
+    assert set(m.snapshot()) == {'b', 'c'}                       # 'a' was the least recently used
+    assert m.start('b') == (False, True, False) and m.start('b') == (False, True, False)
+    assert m.start('b') == (False, False, True)                 # third remembered call: probe the common path
+    m.forget('b')
+    assert m.start('b') == (False, False, False)
+    m.clear()
+    assert not m.snapshot()

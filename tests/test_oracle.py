@@ -19,7 +19,7 @@ def _check_coarse(out, g):
 
 @pytest.mark.parametrize("name,dist", [("cfg1_peaky", "peaky"), ("cfg1_borderline", "borderline"),
                                        ("cfg2_peaky", "peaky"), ("cfg2_borderline", "borderline"),
-                                       ("cfg2_mixed", "mixed")])
+                                       ("cfg2_mixed", "mixed"), ("l9600_peaky", "peaky"), ("cfg5_peaky", "peaky")])
 def test_full_path_matches_reference(name, dist):
     g = load_golden(name)
     inp = case_inputs(g['meta'], dist)
@@ -44,10 +44,11 @@ def test_batch_case_matches_reference():
     np.testing.assert_allclose(out['mkpts1_f'].numpy(), g['mkpts1_f'], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["cfg3_first2_borderline", "cfg5_borderline"])
+@pytest.mark.parametrize("name", ["cfg3_first2_borderline", "cfg5_borderline", "l9600_borderline"])
 def test_coarse_on_non_degenerate_data_at_batch_and_large_size(name):
     """Round-3 fixtures: the reference's dual softmax on 'borderline' data (conf spread over (0.2, 1), not all 1.0) for
-    two samples of the cfg#3 batch and at S = 16384 (cfg#5)."""
+    two samples of the cfg#3 batch and at S = 16384 (cfg#5); round 4: the 640 x 960 pair (L = S = 9600, the "9600 x 9600
+    cost volume" of BASELINE.json's config 5)."""
     g = load_golden(name)
     inp = case_inputs(g['meta'], "borderline", with_fine=False)
     torch.set_num_threads(8)
