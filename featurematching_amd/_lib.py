@@ -19,8 +19,9 @@ FM_E_CANDIDATES = -6
 FM_E_RANGE = -7
 FM_E_DENSE = -8
 FM_E_INTERNAL = -9
+FM_E_STEP = -10
 FM_DEV_RANGE = 4                                    # device status bit
-FM_MODE_EXACT_SCREENING, FM_MODE_DENSE, FM_MODE_NO_CELL_MAPS = 1, 2, 4      # `mode` bits of fm_coarse_match
+FM_MODE_EXACT_SCREENING, FM_MODE_DENSE, FM_MODE_NO_CELL_MAPS, FM_MODE_EXACT_STEP = 1, 2, 4, 8   # `mode` bits of fm_coarse_match
 
 _lib = None
 

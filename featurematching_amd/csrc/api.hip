@@ -85,6 +85,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.zero_end = o;
   w.q0 = take(rows * C); w.q1 = take(cols * C);
   w.sigimg = take((size_t)N * 2 * 4);
+  w.amax_u = take((size_t)N * 2 * 4);
   w.l1_0 = take(rows * 4); w.l1_1 = take(cols * 4);
   w.bstat0 = take(rows / 32 * 16); w.bstat1 = take(cols / 32 * 16);
   w.emarg = take((size_t)N * 4);
@@ -125,6 +126,7 @@ extern "C" const char* fm_strerror(int s) {
     case FM_E_RANGE: return "descriptor not finite or |x| >= 32768, or similarities of several thousand (screening margin >= 2^60)";
     case FM_E_DENSE: return "flat similarity in a sample: call again with FM_MODE_DENSE";
     case FM_E_INTERNAL: return "assignment kernel: bounded wait for predecessor workgroups ran out; call again";
+    case FM_E_STEP: return "int8 screening step too small for a descriptor outside the sampled rows: call again with FM_MODE_EXACT_STEP";
     default: return s > 0 ? hipGetErrorString((hipError_t)s) : "unknown fmatch status";
   }
 }
@@ -149,7 +151,7 @@ extern "C" int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int ca
   if (!bytes) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS)) return FM_E_UNSUPPORTED;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP)) return FM_E_UNSUPPORTED;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   *bytes = needs_dense_region(mode, want_conf_matrix != 0) ? w.total : w.common_total;
   return FM_OK;
@@ -212,7 +214,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS)) return FM_E_UNSUPPORTED;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP)) return FM_E_UNSUPPORTED;
   const bool exact = (mode & FM_MODE_EXACT_SCREENING) != 0;
   const bool dense = needs_dense_region(mode, conf_matrix != nullptr);      // exact screening and conf_matrix read the planes too
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
@@ -223,7 +225,8 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
 
   // The common path is four launches: prep -> max pass -> sparse sum kernel -> assignment.
   // one dispatch: clear the per-call counters, quantise both images (one int8 step per image), L1 norms
-  hipError_t e = launch_prep(feat0, feat1, in_dtype, C, w, base, st);
+  // (FM_MODE_EXACT_STEP: the images' largest |x| first - a memset node and one small kernel - and the int8 step from them)
+  hipError_t e = launch_prep(feat0, feat1, in_dtype, C, w, base, (mode & FM_MODE_EXACT_STEP) ? 1 : 0, st);
   if (e != hipSuccess) return (int)e;
   // max pass: row / column / unit maxima of the integer screening product (atomicMax: no partials, no reduction kernel)
   e = launch_max_i8(w, base, st);
@@ -311,7 +314,7 @@ extern "C" int fm_debug_launch_prep(void* workspace, const float* feat0, const f
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  return (int)launch_prep(feat0, feat1, FM_F32, C, w, (char*)workspace, (hipStream_t)stream);
+  return (int)launch_prep(feat0, feat1, FM_F32, C, w, (char*)workspace, 0, (hipStream_t)stream);
 }
 
 // Diagnostic: launch the float16 plane kernel alone (force = 1: every sample; 0: the samples flagged for the dense
@@ -348,6 +351,7 @@ extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, vo
   *m_out = h[0];
   if (h[1] & FM_DEV_INTERNAL) return FM_E_INTERNAL;
   if (h[1] & FM_DEV_RANGE) return FM_E_RANGE;
+  if (h[1] & FM_DEV_STEP) return FM_E_STEP;
   if (h[1] & FM_DEV_DENSE) return FM_E_DENSE;
   if (h[1] & FM_DEV_CANDIDATES) return FM_E_CANDIDATES;
   if (h[1] & FM_DEV_CAPACITY) return FM_E_CAPACITY;

@@ -14,12 +14,12 @@
 // Maxima are published as biased integer codes with atomicMax (exact, order independent): no partial arrays and no
 // reduction kernel.
 //
-// Structure (as the dense sum kernel k_corr): one workgroup = 8 waves = a 256-row panel of image 0 x a range of
-// 64-column tiles of image 1; each wave keeps its 32 rows as A fragments in 32 VGPRs for the whole sweep; image-1
-// tiles (16 KiB at C = 256) stream through a 4-deep LDS ring by LDS-DMA (global_load_lds_dwordx4, 1 KiB fragment
-// block per instruction), handed over by counted vmcnt + raw s_barrier; B fragments are read ahead through
-// inline-asm ds_read_b128 + counted lgkmcnt.  The LDS footprint (64 KiB) and < 100 VGPRs leave room for two
-// workgroups per CU.
+// Structure: one workgroup = 4 waves = a 256-row panel of image 0 x a range of 64-column tiles of image 1; each wave
+// keeps its 64 rows (two 32-row blocks) as A fragments in 64 VGPRs for the whole sweep, so every B fragment read from
+// LDS feeds two MFMAs on two independent accumulators; image-1 tiles (16 KiB at C = 256) stream through a 4-deep LDS
+// ring by LDS-DMA (global_load_lds_dwordx4, 1 KiB fragment block per instruction, refill pieces issued between MFMAs),
+// handed over by counted vmcnt + raw s_barrier; B fragments are read ahead through inline-asm ds_read_b128 + counted
+// lgkmcnt.  __launch_bounds__(256, 2): 213 VGPRs and 64 KiB of LDS leave room for two workgroups per CU.
 #include <type_traits>
 
 #include "fm_device.h"

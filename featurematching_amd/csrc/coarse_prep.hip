@@ -23,6 +23,7 @@ struct PrepArgs {
   const float4* bstat0r; const float4* bstat1r; int N;
   signed char* q0; signed char* q1;   // int8 screening planes (fragment-major for v_mfma_i32_32x32x32_i8)
   float* sigimg;                      // [N][2] the quantisation step of image 0 / image 1 of every sample
+  unsigned* amax_u;                   // FM_MODE_EXACT_STEP: [N][2] ord_encode'd largest |x| of every image (k_prep_amax), else NULL
   float* l1_0; float* l1_1;           // L1 norm of every descriptor
   float4* bstat0; float4* bstat1;     // per 32-row block: {largest L1 norm (+inf: the block holds a bad value), largest
                                       // clipped L1 mass of a descriptor, largest |x|, 0}
@@ -113,7 +114,12 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   // workgroup of the image: max is order independent, so all of them arrive at the same step).  <= 8 loads per
   // thread, all in flight together and ahead of the block's own rows ----
   float amax_s = 0.f;
-  {
+  const bool exact_step = a.amax_u != nullptr;       // (uniform)
+  if (exact_step) {
+    // FM_MODE_EXACT_STEP: the image's true maximum (k_prep_amax ran before this kernel); a hair of headroom so that the
+    // roundings of x / sigma cannot push the largest element beyond +-127: nothing is clipped
+    amax_s = ord_decode(a.amax_u[b * 2 + (img1 ? 1 : 0)]) * (1.0f + 1e-5f) / kPrepHeadroom;
+  } else {
     const int ns = min(kPrepSampleRows, rows);
     const int vpr = a.c_in >> 2;                       // 4-channel vectors per row (c_in % 4 == 0)
     const int total = ns * vpr;                        // <= 32 * 64
@@ -248,6 +254,36 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
 // split: the matrix cores flush float16 SUBNORMAL inputs, so without it the lo half of every value below 2^-3 -
 // |lo| ~ 2^-12 |x| < 2^-14 - would be lost (such elements would carry 11 instead of 22 bits).  f16inv[b] = 1 / (scale0
 // scale1) turns the accumulator back into the dot product.
+// FM_MODE_EXACT_STEP: the largest |x| of every image of every sample (one atomicMax per workgroup on an order-preserving
+// code; the array is cleared by a memset node in front of this kernel).  Same grid as k_prep_split: one workgroup per
+// 32-row block.  NaN never wins a maximum (k_prep_split reports it), Inf does and is reported there too.
+__global__ __launch_bounds__(256) void k_prep_amax(PrepArgs a) {
+  const int tid = threadIdx.x;
+  const bool img1 = (int)blockIdx.x >= a.blocks0;
+  const long rb = img1 ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;
+  const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
+  const int b = (int)(rb * 32 / rows_pad);
+  const int first = (int)(rb * 32 - (long)b * rows_pad);
+  const int nrows = max(0, min(32, rows - first));
+  const long n4 = (long)nrows * (a.c_in >> 2);                  // 4-element vectors of this block (c_in % 4 == 0)
+  const void* const src = img1 ? a.src1 : a.src0;
+  const long e0 = ((long)b * rows + first) * a.c_in;
+  float amax = 0.f;
+  for (long v = tid; v < n4; v += 256) {
+    float4 x;
+    if (a.in_dtype == FM_F32) x = *reinterpret_cast<const float4*>((const float*)src + e0 + v * 4);
+    else x = half4_to_float4(*reinterpret_cast<const uint2*>((const unsigned short*)src + e0 + v * 4), a.in_dtype);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+  __shared__ float wred[4];
+  if ((tid & 63) == 0) wred[tid >> 6] = amax;
+  __syncthreads();
+  if (tid == 0 && nrows > 0)
+    atomicMax(&a.amax_u[b * 2 + (img1 ? 1 : 0)], ord_encode(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]))));
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void k_prep_f16(PrepArgs a) {
   constexpr int KSTEPS = C / 16;
@@ -325,6 +361,7 @@ static void fill_prep_args(PrepArgs& a, const void* feat0, const void* feat1, in
   a.hi1 = (_Float16*)(base + w.hi1); a.lo1 = (_Float16*)(base + w.lo1);
   a.q0 = (signed char*)(base + w.q0); a.q1 = (signed char*)(base + w.q1);
   a.sigimg = (float*)(base + w.sigimg);
+  a.amax_u = nullptr;
   a.l1_0 = (float*)(base + w.l1_0); a.l1_1 = (float*)(base + w.l1_1);
   a.bstat0 = (float4*)(base + w.bstat0); a.bstat1 = (float4*)(base + w.bstat1);
   a.zero = (uint4*)(base + w.zero_begin); a.zero_vec = (int)((w.zero_end - w.zero_begin) / 16);
@@ -351,10 +388,16 @@ hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, i
 }
 
 hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                       hipStream_t st) {
+                       int exact_step, hipStream_t st) {
   PrepArgs a;
   fill_prep_args(a, feat0, feat1, in_dtype, c_in, w, base);
   const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / 32);
+  if (exact_step) {
+    a.amax_u = (unsigned*)(base + w.amax_u);
+    hipError_t e = hipMemsetAsync(a.amax_u, 0, (size_t)w.N * 2 * sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prep_amax, dim3(blocks), dim3(256), 0, st, a);
+  }
   switch (w.C) {
     case 64: hipLaunchKernelGGL(k_prep_split<64>, dim3(blocks), dim3(256), 0, st, a); break;
     case 128: hipLaunchKernelGGL(k_prep_split<128>, dim3(blocks), dim3(256), 0, st, a); break;

@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   SEL_STAMP(3)
   // exclusive prefix of the totals of the blocks before this one (fixed order of integer adds)
   int pre = 0;
+  int polls = 0;                 // ONE budget per thread for all of its predecessors: the worst-case wait is 2^22 polls
   for (int k = threadIdx.x; k < blk; k += 256) {
-    int v, polls = 0;
+    int v;
     do {
       v = __hip_atomic_load(&a.blocktot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!(v & 0x40000000)) {
@@ -229,10 +230,11 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
       const int run = pre + incl;
       a.d_count[0] = run;
       // without the exact-screening pass an overflow of the sum kernels' candidate slots is final
-      unsigned fl = a.scal->flags;
+      // (other workgroups set bits with device-scope atomics until they exit: read at device scope, behind the look-back)
+      unsigned fl = __hip_atomic_load(&a.scal->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!a.exact && (fl & (unsigned)FM_INT_SCREEN_OVERFLOW)) fl |= (unsigned)FM_DEV_CANDIDATES;
       if (fl & (unsigned)FM_INT_LOOKBACK_TIMEOUT) fl |= (unsigned)FM_DEV_INTERNAL;
-      a.d_count[1] = (int)((fl & (15u | (unsigned)FM_DEV_INTERNAL) & ~(unsigned)FM_DEV_CAPACITY) |
+      a.d_count[1] = (int)((fl & (15u | (unsigned)FM_DEV_INTERNAL | (unsigned)FM_DEV_STEP) & ~(unsigned)FM_DEV_CAPACITY) |
                            (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
     }
   }

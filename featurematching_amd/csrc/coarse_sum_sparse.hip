@@ -225,7 +225,16 @@ __global__ __launch_bounds__(512) void k_sum_sparse(SparseArgs a) {
     a.emarg[b] = emarg;
     // a prep workgroup that met NaN/Inf/|x| >= 32768 reported +inf; descriptors so large that the screening margin
     // alone could overflow exp2 (similarities of several thousand) are out of range as well
-    if (!(l1A_max < INFINITY) || !(l1B_max < INFINITY) || !(emarg < 60.f)) atomicOr(&a.scal->flags, (unsigned)FM_DEV_RANGE);
+    // ... unless the margin is what it is because the int8 step, estimated from a sample of the image's rows, clipped a
+    // descriptor outside the sample (an outlier several times larger than the rest; a sample of textureless cells):
+    // then the inputs are fine and the call is to be repeated with the exact step (FM_MODE_EXACT_STEP), as it is when
+    // the clipped mass is more than half of the margin (every entry would look significant: the dense kernel's job for
+    // no reason)
+    const bool clipped = clipA > 0.f || clipB > 0.f;
+    const float emarg0 = margin_log2(q8_margin_raw(sig0, l1A_max, 0.f, sig1, l1B_max, 0.f, a.cpad), a.inv_ct);
+    if (!(l1A_max < INFINITY) || !(l1B_max < INFINITY)) atomicOr(&a.scal->flags, (unsigned)FM_DEV_RANGE);
+    else if (!(emarg < 60.f)) atomicOr(&a.scal->flags, (unsigned)(clipped ? FM_DEV_STEP : FM_DEV_RANGE));
+    else if (clipped && emarg > 2.0f * emarg0 + 1.0f) atomicOr(&a.scal->flags, (unsigned)FM_DEV_STEP);
   }
 
   // ---- stabilisers and integer thresholds: this wave's 32 rows, the workgroup's column range ----

@@ -387,6 +387,17 @@ __device__ __forceinline__ void update_phase(const float* xin, float* xout, bool
 #pragma unroll
       for (int g = 0; g < 16; ++g) x[rt][g] += m2[rt][g];
     if (store) store_slice<WW>(x, xout, ct, lane, A);
+    {
+      // NaN never wins v_max3 / fmaxf, so `amax` alone misses it: the sum of the slice about to be stored is NaN as soon
+      // as any of its values is NaN or Inf (a NaN anywhere in a window reaches every token of the match through the
+      // attention sums), and s - s != 0 then
+      float chk = 0.f;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) chk += x[rt][k];
+      if (!(chk - chk == 0.f)) amax = INFINITY;
+    }
   }
 }
 

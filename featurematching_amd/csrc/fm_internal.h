@@ -52,6 +52,7 @@ struct CoarseWs {
   // per-row / per-column statistics
   size_t q0, q1;                              // int8 screening planes
   size_t sigimg;                              // [N][2] the int8 step of image 0 / image 1 of every sample
+  size_t amax_u;                              // [N][2] FM_MODE_EXACT_STEP: ord_encode'd largest |x| of image 0 / image 1
   size_t l1_0, l1_1;                          // L1 norm per descriptor
   size_t bstat0, bstat1;                      // float4 per 32-row block: {largest L1 norm (+inf: a bad value), largest
                                               // clipped L1 mass sum_k max(|x_k| - 127 sigma, 0), largest |x|, 0}
@@ -86,7 +87,7 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
 hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                       hipStream_t st);
+                       int exact_step, hipStream_t st);
 hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                            int force, hipStream_t st);
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st);

@@ -94,7 +94,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
                        conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False,
-                       cell_maps: bool = True) -> CoarseBuffers:
+                       cell_maps: bool = True, exact_step: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
@@ -103,7 +103,9 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     it such samples report FM_E_DENSE through read_count), `exact_screening` (FM_MODE_EXACT_SCREENING) the two kernels
     that re-screen the candidates with exact softmax denominators (without it rows / columns that overflow their
     candidate slots report FM_E_CANDIDATES).  cell_maps=False (FM_MODE_NO_CELL_MAPS) skips the cell -> match maps the
-    cell-ordered window crops read (CoarseBuffers.cell_maps() is then meaningless)."""
+    cell-ordered window crops read (CoarseBuffers.cell_maps() is then meaningless).  `exact_step`
+    (FM_MODE_EXACT_STEP) derives the int8 screening step from the images' true maxima (one more small kernel) instead
+    of from a sample of rows: the answer to FM_E_STEP (an outlier descriptor outside the sample)."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -119,7 +121,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     if cand_slots is None:
         cand_slots = lib.fm_default_cand_slots(float(thr))
     mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
-           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS)
+           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_EXACT_STEP if exact_step else 0)
     nbytes = C.c_size_t(0)
     _lib.check(lib.fm_coarse_workspace_bytes_mode(n, l, s, c, cand_slots, mode, int(bool(conf_matrix)), C.byref(nbytes)),
                "fm_coarse_workspace_bytes_mode")
@@ -166,11 +168,11 @@ class ModeMemory:
         import threading
         from collections import OrderedDict
         self._lock = threading.Lock()
-        self._d = OrderedDict()          # key -> {'dense': bool, 'exact': bool, 'calls': int, 'learnt': int}
+        self._d = OrderedDict()          # key -> {'dense': bool, 'exact': bool, 'step': bool, 'calls': int, 'learnt': int}
         self.capacity, self.reprobe = capacity, reprobe
 
     def start(self, key):
-        """(dense, exact_screening, probing) to begin a call with"""
+        """(dense, exact_screening, probing) to begin a call with; `step(key)` tells the third flag"""
         with self._lock:
             e = self._d.get(key)
             if e is None:
@@ -181,11 +183,18 @@ class ModeMemory:
                 return False, False, True
             return e['dense'], e['exact'], False
 
-    def learn(self, key, dense=False, exact=False):
+    def step(self, key, probing=False):
+        """start the call with the exact int8 step (FM_MODE_EXACT_STEP)?"""
         with self._lock:
-            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'calls': 0, 'learnt': 0})
+            e = self._d.get(key)
+            return bool(e and e['step'] and not probing)
+
+    def learn(self, key, dense=False, exact=False, step=False):
+        with self._lock:
+            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'step': False, 'calls': 0, 'learnt': 0})
             e['dense'] |= bool(dense)
             e['exact'] |= bool(exact)
+            e['step'] |= bool(step)
             e['learnt'] += 1
             self._d.move_to_end(key)
             while len(self._d) > self.capacity:
@@ -209,24 +218,27 @@ MODE_MEMORY = ModeMemory()
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
                  scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None,
-                 dense: Optional[bool] = None) -> dict:
+                 dense: Optional[bool] = None, exact_step: Optional[bool] = None) -> dict:
     """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
     N*min(L,S)), with the dense sum kernel (FM_E_DENSE), with the exact screening pass, then with more candidate
-    slots when the device reports the corresponding condition, and once more when the assignment kernel's bounded
-    wait ran out (FM_E_INTERNAL: "call again", fmatch.h).  exact_screening=None: on when conf_matrix is
+    slots when the device reports the corresponding condition, with the exact int8 step when the sampled one clipped an
+    outlier (FM_E_STEP), and once more when the assignment kernel's bounded wait ran out (FM_E_INTERNAL: "call again",
+    fmatch.h).  exact_screening=None: on when conf_matrix is
     requested (that path already runs the denominator reduction the exact screening needs, and it is the training /
     untrained-network mode in which flat rows occur) or when MODE_MEMORY holds it for this shape; dense=None likewise."""
     lib = _lib.load()
     key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
     mem_dense, mem_exact, probing = (False, False, False)
-    if exact_screening is None or dense is None:
+    if exact_screening is None or dense is None or exact_step is None:
         mem_dense, mem_exact, probing = MODE_MEMORY.start(key)
+    if exact_step is None:
+        exact_step = MODE_MEMORY.step(key, probing)
     if exact_screening is None:
         exact_screening = bool(conf_matrix) or mem_exact
     if dense is None:
         dense = mem_dense
     kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening),
-              dense=bool(dense))
+              dense=bool(dense), exact_step=bool(exact_step))
     retried_internal = False
     for _ in range(8):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
@@ -236,6 +248,11 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
         except _lib.FMatchError as e:
             if e.status == _lib.FM_E_CAPACITY:
                 kw['cap'] = int(e.required)
+                continue
+            if e.status == _lib.FM_E_STEP and not kw['exact_step']:
+                kw['exact_step'] = True
+                MODE_MEMORY.learn(key, step=True)
+                probing = False
                 continue
             if e.status == _lib.FM_E_DENSE and not kw['dense']:
                 kw['dense'] = True

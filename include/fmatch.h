@@ -50,8 +50,15 @@ enum fm_status {
   FM_E_DENSE = -8,       /* (device status) a sample's similarity is flat (more significant entries per 32 x 32 unit
                             than the sparse sum kernel resolves: an untrained network, textureless images); its result
                             is incomplete: call again with mode | FM_MODE_DENSE */
-  FM_E_INTERNAL = -9     /* (device status) the assignment kernel's bounded wait for its predecessor workgroups ran
+  FM_E_INTERNAL = -9,    /* (device status) the assignment kernel's bounded wait for its predecessor workgroups ran
                             out (never observed; the outputs are incomplete): call again */
+  FM_E_STEP = -10        /* (device status) the int8 screening step of an image, estimated from a sample of its rows, is
+                            too small for some descriptor outside the sample (an outlier several times larger than the
+                            rest, or a sample that fell on textureless cells): what it clipped inflates every screening
+                            margin.  The inputs are fine: call again with mode | FM_MODE_EXACT_STEP.  (One step per
+                            image bounds the dynamic range the screening can serve: descriptors more than ~5x larger
+                            than the rest of their image at C = 256, T = 0.1 still end in FM_E_RANGE - the margin of
+                            their coarse codes alone would overflow the exponentials.) */
 };
 
 /* `mode` bits of fm_coarse_match / fm_coarse_workspace_bytes_mode (0 = the common path: 4 launches) */
@@ -60,6 +67,9 @@ enum fm_status {
                                      cores) for the samples the sparse sum kernel flags; both exit at once otherwise */
 #define FM_MODE_NO_CELL_MAPS 4    /* skip the cell -> match maps of fm_coarse_cell_maps (two returning atomics per match):
                                      for callers that do not use the cell-ordered window crops */
+#define FM_MODE_EXACT_STEP 8      /* one more (small) kernel finds the largest |x| of every image first, and the int8
+                                     screening step is derived from it instead of from a sample of rows: nothing is
+                                     clipped, whatever the data (answers FM_E_STEP) */
 
 /* element type of the coarse descriptors handed to fm_coarse_match_dtype */
 enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
@@ -70,6 +80,7 @@ enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
 #define FM_DEV_RANGE 4
 #define FM_DEV_DENSE 8
 #define FM_DEV_INTERNAL 32
+#define FM_DEV_STEP 128
 
 int fm_version(void);
 const char* fm_strerror(int status);

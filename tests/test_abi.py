@@ -31,7 +31,7 @@ def test_version_and_messages():
     lib = _lib.load()
     assert lib.fm_version() == 100
     assert lib.fm_strerror(0) == b"ok"
-    for code in range(-9, 0):
+    for code in range(-10, 0):
         assert lib.fm_strerror(code) not in (b"", b"unknown fmatch status")
     assert lib.fm_default_cand_slots(0.2) == 8
     assert lib.fm_default_cand_slots(0.05) == 32
@@ -52,7 +52,8 @@ def test_workspace_query_and_argument_checks():
     for mode, conf in ((1, 0), (2, 0), (3, 0), (0, 1)):
         assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, mode, conf, C.byref(n)) == 0
         assert n.value == per_pair > common
-    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 8, 0, C.byref(n)) == -3      # unknown mode bit
+    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 16, 0, C.byref(n)) == -3     # unknown mode bit
+    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 8, 0, C.byref(n)) == 0 and n.value == common   # FM_MODE_EXACT_STEP
     assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 4, 0, C.byref(n)) == 0 and n.value == common   # FM_MODE_NO_CELL_MAPS
     assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, None) == -1
     assert lib.fm_coarse_workspace_bytes(64, 4800, 4800, 256, 8, C.byref(n)) == 0

@@ -382,6 +382,49 @@ def test_coarse_without_cell_maps_gives_the_same_matches():
         b.cell_maps()
 
 
+@pytest.mark.parametrize("case", ["outlier_row", "outlier_row_both_images", "textureless_sample"])
+def test_int8_step_survives_outliers_outside_the_sampled_rows(case):
+    """The int8 screening step of an image comes from 32 sampled rows (k_prep_split); what it clips elsewhere widens
+    every margin.  (a) ONE descriptor 4x larger than the rest, outside the sample; (b) one in each image (3x / 2.5x); (c)
+    every SAMPLED row of image 0 nearly zero (a sample that fell on textureless cells).  The first call reports FM_E_STEP
+    - not FM_E_RANGE: the inputs are fine; not a silent detour through the dense kernel - and FM_MODE_EXACT_STEP (the
+    true maxima from one more small kernel) serves them; ops.coarse_match does that by itself and remembers the shape.
+    (An outlier row's noise entries are as large as other columns' peaks: such data legitimately needs the dense sum
+    kernel as well - the explicit call below switches it on, ops.coarse_match finds out.)"""
+    l, c, hw = 1200, 128, (30, 40)
+    f0, f1 = synth.coarse_descriptors(91, 1, l, c, "peaky")
+    sampled = sorted({(t * l) // 32 for t in range(32)})
+    free = [r for r in range(l) if r not in sampled]
+    if case == "outlier_row":
+        f0[0, free[5]] *= 4.0
+    elif case == "outlier_row_both_images":
+        f0[0, free[5]] *= 3.0
+        f1[0, free[77]] *= 2.5
+    else:
+        f0[0, sampled] *= 1e-3
+    ref = orc.coarse_match(f0, f1, (240, 320), hw, hw, 0.2, 2, 0.1)
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    with pytest.raises(_lib.FMatchError) as e:
+        ops.coarse_match_async(t0, t1, hw, hw, 8.0, dense=True, exact_screening=True).read_count()
+    assert e.value.status == _lib.FM_E_STEP
+    buf = ops.coarse_match_async(t0, t1, hw, hw, 8.0, exact_step=True, dense=True, exact_screening=True)
+    m = buf.read_count()
+    _assert_coarse(buf.sliced(m), ref)
+    assert m == ref['i_ids'].shape[0] > 700
+    if case == "textureless_sample":      # nothing but the step was wrong: the common path + the exact step suffice
+        assert ops.coarse_match_async(t0, t1, hw, hw, 8.0, exact_step=True).read_count() == m
+    ops.MODE_MEMORY.clear()
+    out = ops.coarse_match(t0, t1, hw, hw, 8.0)                  # retries by itself ...
+    _assert_coarse(out, ref)
+    snap = ops.MODE_MEMORY.snapshot()
+    assert len(snap) == 1 and list(snap.values())[0]['step']
+    ops.MODE_MEMORY.clear()
+    # ... and the exact step changes nothing for ordinary data (finer codes, same matches)
+    g0, g1 = synth.coarse_descriptors(92, 1, l, c, "borderline")
+    a = ops.coarse_match(torch.as_tensor(g0, device=DEV), torch.as_tensor(g1, device=DEV), hw, hw, 8.0, exact_step=True)
+    _assert_coarse(a, orc.coarse_match(g0, g1, (240, 320), hw, hw, 0.2, 2, 0.1))
+
+
 def test_non_finite_input_is_reported():
     f0, f1 = synth.coarse_descriptors(42, 1, 64, 64, "peaky")
     f0[0, 3, 5] = np.inf
@@ -948,8 +991,9 @@ def test_fine_transformer_vs_oracle(w):
     assert c0.requires_grad and not torch.equal(c0, g0) and (c0.detach() - g0).abs().max().item() <= 2e-5
     d0, _ = tf.train()(t0, t1)               # training mode: torch ops
     assert d0.requires_grad and (d0.detach() - g0).abs().max().item() <= 2e-5
-    with pytest.raises(NotImplementedError):
-        tf.eval()(t0, t1, torch.ones(m, ww, dtype=torch.bool, device=DEV), None)
+    # padding masks (transformer.py:89-95): the module's torch layers (all-ones masks change nothing)
+    e0, _ = tf.eval()(t0, t1, torch.ones(m, ww, dtype=torch.bool, device=DEV), None)
+    assert (e0.detach() - g0).abs().max().item() <= 2e-5
 
 
 @pytest.mark.parametrize("gain,expect_flag,ww", [(1e-3, False, 49), (8.0, False, 49), (120.0, False, 49), (300.0, False, 49),
@@ -982,6 +1026,33 @@ def test_fine_transformer_follows_the_data_and_reports_what_it_cannot_hold(gain,
     a0, a1 = tf(t0, t1)                       # the module: HIP kernel inside the range, float32 layers beyond it
     assert tf.range_fallbacks == (1 if expect_flag else 0)
     assert (a0.cpu() - r0).abs().max().item() <= tol and (a1.cpu() - r1).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_fine_transformer_reports_non_finite_windows(bad):
+    """fmatch.h: NaN / Inf activations are reported as FM_DEV_RANGE.  NaN never wins the kernel's running maximum, so
+    the outputs themselves are checked; the module answers with its float32 layers (NaN there too, as in the reference),
+    counts the call, and check_range=False leaves the report in `last_status` without a host sync."""
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    m, ww = 9, 49
+    x0 = synth.normal(83, 1, (m, ww, 64)).astype(np.float32)
+    x1 = synth.normal(83, 2, (m, ww, 64)).astype(np.float32)
+    x1[4, 17, 5] = bad
+    wts = {k: torch.as_tensor(v) for k, v in synth.transformer_weights(77, 64, 2).items()}
+    packed = ops.pack_fine_transformer(wts, DEV)
+    t0, t1 = torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    g0, g1 = ops.fine_transformer(t0, t1, packed, status=status)
+    assert int(status.item()) & _lib.FM_DEV_RANGE
+    ok = [k for k in range(m) if k != 4]
+    assert torch.isfinite(g0[ok]).all() and torch.isfinite(g1[ok]).all()      # the other matches are untouched
+    tf = LocalFeatureTransformer(dict(d_model=64, nhead=8, layer_names=['self', 'cross'], attention='linear')).to(DEV).eval()
+    tf.load_state_dict(wts)
+    a0, _ = tf(t0, t1)
+    assert tf.range_fallbacks == 1 and not torch.isfinite(a0[4]).all() and torch.isfinite(a0[ok]).all()
+    tf.check_range = False
+    tf(t0, t1)
+    assert tf.range_fallbacks == 1 and int(tf.last_status.item()) & _lib.FM_DEV_RANGE
 
 
 def test_fine_transformer_weights_beyond_the_scale_are_reported_and_large_sums_are_held():
