@@ -80,12 +80,13 @@ class LocalFeatureTransformer(nn.Module):
     the outputs then carry no graph through the parameters (a warning says so once); False sends such calls through
     the torch layers, as a fine-tuning run that freezes batch norm with .eval() needs."""
 
+    _warned_detached = False
+
     def __init__(self, config, use_hip: bool = True, check_range: bool = True, inference_only: bool = True):
         super().__init__()
         self.use_hip, self.check_range, self.inference_only = use_hip, check_range, inference_only
         self.range_fallbacks = 0
         self.last_status = None
-        self._warned_detached = False
         if config.get('attention', 'linear') != 'linear':
             raise NotImplementedError("only the reference's default linear attention is provided")
         self.d_model, self.layer_names = config['d_model'], list(config['layer_names'])
@@ -106,8 +107,8 @@ class LocalFeatureTransformer(nn.Module):
             # layers' parameters here; the HIP kernels do not
             if not self.inference_only:
                 wants_grad = True
-            elif self.use_hip and feat0.is_cuda and not self._warned_detached:
-                self._warned_detached = True
+            elif self.use_hip and feat0.is_cuda and not LocalFeatureTransformer._warned_detached:
+                LocalFeatureTransformer._warned_detached = True      # (once per process)
                 import warnings
                 warnings.warn("LocalFeatureTransformer: eval-mode HIP kernels return tensors without a graph through the "
                               "layers' parameters; pass inference_only=False (or call .train()) to fine-tune them")
