@@ -185,7 +185,7 @@ def _events(fn, iters=10, before=None, group=6):
 def time_kernels(pair):
     """Event-timed launches of the kernels of one step on a workspace the step has filled: the whole coarse stage (one
     fm_coarse_match call: all its launches with their in-stream gaps), its kernels k_prep_split, k_max_i8 and
-    k_sum_sparse alone (+ the float16 planes and the dense sum kernel when the pair runs with FM_MODE_DENSE), the
+    k_screen alone (+ the float16 planes and the dense sum kernel when the pair runs with FM_MODE_DENSE), the
     window crop and the fine kernel.  The assignment kernel cannot be re-run on its own outputs; its share is what
     remains of the coarse stage."""
     lib = _lib.load()
@@ -288,7 +288,7 @@ def committed_traffic(workload):
         return None, None
     tot = 0.0
     for name, c in d.get("kernels", {}).items():
-        if ("k_max_i8" in name or "k_sum_sparse" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        if ("k_max_i8" in name or "k_screen" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
     return (int(tot) if tot else None), "profiles/r03_pmc_fetch_write_cfg2.json"
 
@@ -851,7 +851,7 @@ def main():
         # (+ float16 planes and the dense sum kernel under FM_MODE_DENSE).  Priced against the int8 MFMA peak, the
         # matrix-core type the dominant kernel runs on.
         "roofline": {"bound": "mfma",
-                     "kernel": "coarse correlation: k_max_i8<256> + k_sum_sparse<256>"
+                     "kernel": "coarse correlation: k_max_i8<256> + k_screen<256>"
                                + (" + k_prep_f16 + k_corr<256,1>" if pairs[0].dense else "")
                                + " (every launch on the L x S product; v_mfma_i32_32x32x32_i8)",
                      "achieved": round(ach, 2), "peak": PEAK_I8_DENSE_TOPS, "unit": "TFLOP/s",

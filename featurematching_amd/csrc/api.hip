@@ -22,20 +22,18 @@ int choose_splits(int N, int panels, int tiles, int target) {
   return s;
 }
 
-// column splits of the sparse sum kernel.  Its waves are bound by a chain of memory round trips and leave the CUs
-// they sit on mostly idle, so the target is HALF a round of the chip's workgroup slots: alone the kernel then takes
-// 24 instead of 19 us at one 640x480 pair, but with several pairs in flight the other half of the chip runs another
-// pair's max pass meanwhile (16.4 k -> 17.5 k pairs/s; 48 .. 128 workgroups measured the same, 192+ lower).  When the
-// batch alone fills the chip a split covers up to kUnitsPerSplit 32-column units, which amortises the round trips
-// over more live units.
+// column splits of the screening kernel: one round of the chip's compute units (a workgroup is 8 waves with ~200
+// registers and up to 140 KB of LDS: one per CU), never more than kScreenUnits 32-column units per workgroup (the B
+// fragments of the range's live units share its LDS).
 static int choose_splits_sparse(int N, int panels, int nunits, int* units_per_split) {
-  constexpr int kUnitsPerSplitMax = kUnitsPerSplit;
-  int target = 128;
+  // (two workgroups per CU - ~100 registers, <= 64 KB of LDS at <= 8 units - measured best: 256 / 384 / 512 / 768
+  // workgroups at one 640x480 pair: 16.4 / 16.2 / 15.9 / 21.2 us alone, 24.3 / 25.9 / 25.6 / 24.5 k pairs/s on 4 streams)
+  int target = 512;
 #ifdef FM_TUNE_ENV
-  if (const char* e = getenv("FM_TARGET_WGS_S")) target = atoi(e) > 0 ? atoi(e) : 128;
+  if (const char* e = getenv("FM_TARGET_WGS_S")) target = atoi(e) > 0 ? atoi(e) : 512;
 #endif
   int s = target / (N * panels > 0 ? N * panels : 1);
-  const int smin = (nunits + kUnitsPerSplitMax - 1) / kUnitsPerSplitMax;
+  const int smin = (nunits + kScreenUnits - 1) / kScreenUnits;
   if (s < smin) s = smin;
   if (s > nunits) s = nunits;
   if (s < 1) s = 1;
@@ -86,10 +84,11 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.q0 = take(rows * C); w.q1 = take(cols * C);
   w.sigimg = take((size_t)N * 2 * 4);
   w.amax_u = take((size_t)N * 2 * 4);
+  w.imgstat = take((size_t)N * 8 * 4);
   w.l1_0 = take(rows * 4); w.l1_1 = take(cols * 4);
   w.bstat0 = take(rows / 32 * 16); w.bstat1 = take(cols / 32 * 16);
   w.emarg = take((size_t)N * 4);
-  w.rowS = take(rows * w.splits_s * 4); w.colS = take(cols * w.panels * 4);
+  w.rowS = take(0); w.colS = take(0);
   w.nmr = take(rows * 4); w.nmc = take(cols * 4);
   w.umax = take(rows / 32 * (cols / N / 32) * 4);
   w.cand_j = take(rows * slots * 4); w.cand_x = take(rows * slots * 4);

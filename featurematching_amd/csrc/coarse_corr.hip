@@ -204,7 +204,10 @@ __global__ __launch_bounds__(512) void k_corr(CorrArgs a) {
   const int t0 = split * a.tiles_per_split;
   const int t1 = min(t0 + a.tiles_per_split, a.tiles);
 
-  if (MODE == 1 && a.dense_cnt[b] == 0) return;      // uniform: this sample was handled by the sparse sum kernel
+  if (MODE == 1 && a.dense_cnt[b] == 0) return;      // uniform: this sample was handled by the screening kernel
+  // (its lists hold every significant entry and never overflow - a row or column with more than `slots` of them sends
+  // the sample here in MODE 1 - so the exact screening only ever refills the lists of samples the dense kernel redid)
+  if (MODE == 2 && a.dense_cnt[b] == 0) return;
   const float inv_sc = a.f16inv[b];                  // the planes carry exact power-of-two scales (k_prep_f16)
   const float kq = a.k * inv_sc;                     // accumulator -> log2-domain similarity
   // candidate set of this sample: the dense kernel's own for the samples it redoes

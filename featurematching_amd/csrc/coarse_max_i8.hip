@@ -32,6 +32,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 struct MaxArgs {
   const signed char* q0; const signed char* q1;
   unsigned* rowmax_u; unsigned* colmax_u; float* umax;
+  const float4* bstat0; const float4* bstat1; float* imgstat;   // block statistics of k_prep_split -> per-sample maxima
   float* diag;            // diagnostic build: stamp buffer
   int L, S, Lp, Sp, panels, tiles, splits, tiles_per_split, pgroup;
 };
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
   constexpr int PER_WAVE = PIECES / 4;              // C >= 64: every wave brings >= 1 block of a tile
   constexpr int PF = KS8 < 4 ? KS8 : 4;             // B-fragment read-ahead
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ unsigned s_colmax[3 * 64];             // per tile (mod 3): q_encode'd column maxima of 64 columns (ds_max_u32)
+  // per tile (mod 3): q_encode'd column maxima of 64 columns (ds_max_u32); words 192..197: the sample's statistics
+  __shared__ unsigned s_colmax[3 * 64 + 8];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -127,6 +129,24 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
 #pragma unroll
     for (int n = 0; n < PER_WAVE; ++n) stage_piece(t, buf, n);
   };
+  // The first workgroup of every sample also folds the block statistics of k_prep_split (largest L1 norm, largest
+  // clipped mass, largest |x| of the 32-row blocks of both images) into the sample's six maxima: the screening kernel's
+  // every wave needs them for its margins, and used to reduce the ~300 block records itself (16 loads and six wave
+  // reductions per wave).  The loads go out ahead of the tile prefetch (older in the vmcnt order), the fold runs
+  // behind the first barrier.
+  const bool stat_wg = panel == 0 && split == 0;         // (uniform)
+  float st6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (stat_wg) {
+    const int nb0 = a.Lp / 32;
+    for (int i = tid; i < nb0; i += 256) {
+      const float4 v = a.bstat0[(long)b * nb0 + i];
+      st6[0] = fmaxf(st6[0], v.x); st6[1] = fmaxf(st6[1], v.y); st6[2] = fmaxf(st6[2], v.z);
+    }
+    for (int i = tid; i < nunits; i += 256) {
+      const float4 v = a.bstat1[(long)b * nunits + i];
+      st6[3] = fmaxf(st6[3], v.x); st6[4] = fmaxf(st6[4], v.y); st6[5] = fmaxf(st6[5], v.z);
+    }
+  }
 #pragma unroll
   for (int d = 0; d < NBUF - 1; ++d)
     if (t0 + d < t1) stage(t0 + d, d);
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
     }
   }
   const unsigned colmax_a = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)s_colmax;
-  if (tid < 192) asm volatile("ds_write_b32 %0, %1" ::"v"(colmax_a + tid * 4), "v"(0u) : "memory");
+  if (tid < 200) asm volatile("ds_write_b32 %0, %1" ::"v"(colmax_a + tid * 4), "v"(0u) : "memory");
 
   int rstat0[16], rstat1[16];    // running maxima of q_i . q_j over the columns this lane has seen (row block 0 / 1)
 #pragma unroll
@@ -166,6 +186,17 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
   // for the tile prefetch) at their first use inside the loop
 #pragma unroll
   for (int ks = 0; ks < KS8; ++ks) { asm volatile("" ::"v"(aq0[ks])); asm volatile("" ::"v"(aq1[ks])); }
+  if (stat_wg) {
+    // non-negative floats (+inf = a block with a bad value) order like their bit patterns: ds_max_u32 (the words were
+    // cleared in front of the barrier above); read back and stored behind the sweep's barriers, at the end
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      float v = st6[q];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+      if (lane == 0) atomicMax(&s_colmax[192 + q], __float_as_uint(v));
+    }
+  }
 #ifdef FM_DIAG_CLOCK
   dg_pro = __builtin_amdgcn_s_memtime() - dg0;
 #endif
@@ -351,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
     __builtin_amdgcn_s_barrier();
     fold_columns(t1 - 1);
   }
+  if (stat_wg && tid < 6) a.imgstat[(long)b * 8 + tid] = __uint_as_float(s_colmax[192 + tid]);
 
 #ifdef FM_DIAG_CLOCK
   const unsigned long long dg_tail0 = __builtin_amdgcn_s_memtime();
@@ -424,6 +456,8 @@ hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st) {
   a.q0 = (const signed char*)(base + w.q0); a.q1 = (const signed char*)(base + w.q1);
   a.rowmax_u = (unsigned*)(base + w.rowmax_u); a.colmax_u = (unsigned*)(base + w.colmax_u);
   a.umax = (float*)(base + w.umax);
+  a.bstat0 = (const float4*)(base + w.bstat0); a.bstat1 = (const float4*)(base + w.bstat1);
+  a.imgstat = (float*)(base + w.imgstat);
   a.diag = (float*)(base + w.rowB);      // (diagnostic builds run on a full-size workspace)
   a.L = w.L; a.S = w.S; a.Lp = w.Lp; a.Sp = w.Sp; a.panels = w.panels; a.tiles = w.tiles;
   a.tiles_per_split = (w.tiles + w.splits0 - 1) / w.splits0;

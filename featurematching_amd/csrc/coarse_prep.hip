@@ -1,8 +1,8 @@
 // Coarse stage, kernels around the correlation sweeps:
 //   k_prep_split  : descriptors -> int8 screening plane (one step per image) + L1 norms, clipped mass, block maxima
 //   k_prep_f16    : two float16 planes (hi, lo = x - hi) for the samples the dense sum kernel redoes
-//   k_reduce_sums : partial sums of the sum kernels -> softmax denominators of every row / column
-//                   (exact screening and dense conf_matrix only)
+//   k_reduce_sums : lists of significant entries (k_screen) / partial sums (dense sum kernel) -> softmax denominators
+//                   of every row / column (exact screening and dense conf_matrix only)
 //
 // Reference arithmetic being reproduced: network/utils/coarse_matching_new.py:64-68
 // (sim = (f0/sqrt(C)) . (f1/sqrt(C)) / T, softmax over dim 1 and dim 2).  The float16
@@ -408,20 +408,22 @@ hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c
 }
 
 // Softmax denominators of EVERY row and column (only the exact screening pass and the dense conf_matrix need
-// them; the common path folds the denominators of its candidates in k_select).
+// them; the common path forms the denominators of its candidates in k_select).
 // grid (chunks, N, 2): z = 0 rows of image 0 (sum over j), z = 1 columns (over i).
-// The partial sums come from the sparse sum kernel (partS) or, for the samples it redid, from the dense one
-// (partB); out = their sum in a fixed order (deterministic), nm2 = nm - log2(out) the log-softmax offset.
+// A sample the screening kernel served: the sum of the row's / column's list of significant entries, in index order
+// (the order k_select uses: same bits).  A sample the dense sum kernel redid: its partial sums (partB) in a fixed order.
+// nm2 = nm - log2(out) is the log-softmax offset.
 // Workgroup = 16 consecutive entries x 16 part-groups: every thread folds ~nparts/16 partials (all
 // loads independent and in flight together), then the 16 groups are folded through LDS in a fixed order.
-__global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ rowS, const float* __restrict__ colS,
-                                                     const float* __restrict__ rowB, const float* __restrict__ colB,
+__global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ rowB, const float* __restrict__ colB,
                                                      float* __restrict__ rout, float* __restrict__ cout_, int Lp, int Sp,
-                                                     int rpartsS, int rpartsB, int cparts,
+                                                     int rpartsB, int cparts, int slots, float k,
                                                      const float* __restrict__ nm_r, const float* __restrict__ nm_c,
                                                      float* __restrict__ nm2_r, float* __restrict__ nm2_c,
-                                                     int* __restrict__ cand_count, int* __restrict__ cand_count_b,
-                                                     int* __restrict__ ccand_count, int* __restrict__ ccand_count_b,
+                                                     const int* __restrict__ cand_count, const int* __restrict__ cand_j,
+                                                     const float* __restrict__ cand_x, const int* __restrict__ ccand_count,
+                                                     const int* __restrict__ ccand_i, const float* __restrict__ ccand_x,
+                                                     int* __restrict__ cand_count_b, int* __restrict__ ccand_count_b,
                                                      const int* __restrict__ dense_cnt, const Scalars* __restrict__ scal) {
   const int side = blockIdx.z;
   const int b = blockIdx.y;
@@ -430,49 +432,59 @@ __global__ __launch_bounds__(256) void k_reduce_sums(const float* __restrict__ r
   const bool dense = dense_cnt[b] > 0;       // the dense sum kernel redid this sample
   const int cx = threadIdx.x & 15, pg = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + cx;       // len is a multiple of 64
+  const long gi = (long)b * len + idx;
   __shared__ float fold[16][17];
   float acc = 0.f;
-  if (!dense) {
-    const int nparts = side ? cparts : rpartsS;
-    const float* part = (side ? colS : rowS) + (long)b * nparts * len;
-#pragma unroll 4
-    for (int p = pg; p < nparts; p += 16) acc += part[(long)p * len + idx];
-  }
   if (dense) {
     const int nparts = side ? cparts : rpartsB;
     const float* part = (side ? colB : rowB) + (long)b * nparts * len;
 #pragma unroll 4
     for (int p = pg; p < nparts; p += 16) acc += part[(long)p * len + idx];
+  } else if (pg == 0) {
+    // list terms in index order: repeatedly take the smallest key above the last one taken (lists hold <= slots <= 64
+    // entries, usually one)
+    const int n = min((side ? ccand_count : cand_count)[gi], slots);
+    const int* key = (side ? ccand_i : cand_j) + gi * slots;
+    const float* xs = (side ? ccand_x : cand_x) + gi * slots;
+    const float nm = (side ? nm_c : nm_r)[gi];
+    int last = -1;
+    for (int t = 0; t < n; ++t) {
+      int best = 0x7fffffff, at = 0;
+      for (int q = 0; q < n; ++q) { const int kq = key[q]; if (kq > last && kq < best) { best = kq; at = q; } }
+      acc += __builtin_amdgcn_exp2f(__builtin_fmaf(xs[at], k, nm));
+      last = best;
+    }
   }
   fold[pg][cx] = acc;
   __syncthreads();
   if (pg != 0) return;
   float v = fold[0][cx];
+  if (dense) {
 #pragma unroll
-  for (int g = 1; g < 16; ++g) v += fold[g][cx];
+    for (int g = 1; g < 16; ++g) v += fold[g][cx];
+  }
   float* out = (side ? cout_ : rout) + (long)b * len;
   out[idx] = v;
   // log-softmax offset for the exact screening / dense conf_matrix sweeps: log2 P = x*k + (nm - log2(sum))
-  const long gi = (long)b * len + idx;
   (side ? nm2_c : nm2_r)[gi] = (side ? nm_c : nm_r)[gi] - __log2f(v);
-  // the sum kernels overflowed some row's candidate slots: the exact screening sweep refills the lists from scratch
-  // (both listings of the candidates: per row and per column)
-  if (scal->flags & FM_INT_SCREEN_OVERFLOW) {
-    if (side == 0) (dense ? cand_count_b : cand_count)[gi] = 0;
-    else (dense ? ccand_count_b : ccand_count)[gi] = 0;
+  // the dense sum kernel overflowed some row's candidate slots: the exact screening sweep refills the lists of the
+  // samples it redid from scratch (both listings of the candidates: per row and per column)
+  if (dense && (scal->flags & FM_INT_SCREEN_OVERFLOW)) {
+    if (side == 0) cand_count_b[gi] = 0;
+    else ccand_count_b[gi] = 0;
   }
 }
 
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st) {
-  (void)mode; (void)inv_ct;
+  (void)mode;
   const int chunks = (max(w.Lp, w.Sp) + 15) / 16;
   const dim3 grid(chunks, w.N, 2);
-  hipLaunchKernelGGL(k_reduce_sums, grid, dim3(256), 0, st, (const float*)(base + w.rowS), (const float*)(base + w.colS),
-                     (const float*)(base + w.rowB), (const float*)(base + w.colB), (float*)(base + w.rsum),
-                     (float*)(base + w.csum), w.Lp, w.Sp, w.splits_s, w.splits, w.panels,
-                     (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
-                     (float*)(base + w.nmc2), (int*)(base + w.cand_count), (int*)(base + w.cand_count_b),
-                     (int*)(base + w.ccand_count), (int*)(base + w.ccand_count_b),
+  hipLaunchKernelGGL(k_reduce_sums, grid, dim3(256), 0, st, (const float*)(base + w.rowB), (const float*)(base + w.colB),
+                     (float*)(base + w.rsum), (float*)(base + w.csum), w.Lp, w.Sp, w.splits, w.panels, w.slots,
+                     inv_ct * kLog2e, (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.nmr2),
+                     (float*)(base + w.nmc2), (const int*)(base + w.cand_count), (const int*)(base + w.cand_j),
+                     (const float*)(base + w.cand_x), (const int*)(base + w.ccand_count), (const int*)(base + w.ccand_i),
+                     (const float*)(base + w.ccand_x), (int*)(base + w.cand_count_b), (int*)(base + w.ccand_count_b),
                      (const int*)(base + w.dense_cnt), (const Scalars*)(base + w.scalars));
   return hipGetLastError();
 }

@@ -15,13 +15,12 @@ namespace fm {
 
 struct SelArgs {
   const float* nmr; const float* nmc;
-  const float* rowS; const float* colS;   // partial sums of the sparse sum kernel: rows [N][splits_s][Lp], columns [N][panels][Sp]
-  const float* rowB; const float* colB;   // ... of the dense sum kernel (valid when it had units): rows [N][splits][Lp]
+  const float* rowB; const float* colB;   // partial sums of the dense sum kernel (samples it redid): rows [N][splits][Lp], columns [N][panels][Sp]
   int exact;                              // exact screening ran: its overflow is then FM_DEV_CANDIDATES already
   int cell_maps;                          // write the cell -> match maps (two returning atomics per match)
   int dense_enabled;                      // the call runs the dense sum kernel (FM_MODE_DENSE): its regions exist
-  const int* cand_count; const int* cand_j; const float* cand_x;          // the sparse sum kernel's candidates, per row
-  const int* ccand_count; const int* ccand_i; const float* ccand_x;       // ... the same entries per column
+  const int* cand_count; const int* cand_j; const float* cand_x;          // the screening kernel's SIGNIFICANT entries, per row
+  const int* ccand_count; const int* ccand_i; const float* ccand_x;       // ... and per column (k_screen: (index, exact x) lists)
   const int* cand_count_b; const int* cand_j_b; const float* cand_x_b;    // the dense one's (samples with dense_cnt > 0)
   const int* ccand_count_b; const int* ccand_i_b; const float* ccand_x_b;
   const int* dense_cnt;
@@ -56,6 +55,28 @@ __device__ __forceinline__ float fold_partials(const float* p, int n, long pitch
     for (int q = 0; q < 32; ++q) v[q] = p[(long)min(q0 + q, n - 1) * pitch];
 #pragma unroll
     for (int q = 0; q < 32; ++q) t += (q0 + q < n) ? v[q] : 0.f;
+  }
+  return t;
+}
+
+// Sum of the terms e of a list's live entries in the order of their keys (the lists are appended to in arrival order:
+// sorting by key - the entry's column or row index, distinct inside a list - makes the float32 sum a function of the data
+// only, and equal lists give equal bits).  A list sits in the `slots` adjacent lanes of its row group; rank = number of
+// live entries with a smaller key; the r-th term is picked up by a group OR (every other lane contributes +0).  `maxcnt`
+// = the longest list of the wave (uniform): one round for the usual one-entry lists.
+__device__ __forceinline__ float list_sum(float e, int key, bool live, int slots, int base, int maxcnt) {
+  if (maxcnt <= 1) return __shfl(live ? e : 0.f, base);      // slot 0 holds the one entry (or the list is empty)
+  int rank = 0;
+  for (int q = 0; q < slots; ++q) {
+    const int ok = __shfl(key, base + q);
+    const int ol = __shfl(live ? 1 : 0, base + q);
+    rank += (ol && ok < key) ? 1 : 0;
+  }
+  float t = 0.f;
+  for (int rr = 0; rr < maxcnt; ++rr) {
+    unsigned v = (live && rank == rr) ? __float_as_uint(e) : 0u;
+    for (int m = 1; m < slots; m <<= 1) v |= (unsigned)__shfl_xor((int)v, m);
+    t += __uint_as_float(v);
   }
   return t;
 }
@@ -99,20 +120,19 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   // a sample is handled by ONE sum kernel: the dense one redid it if the sparse one flagged any of its units.  (Without
   // FM_MODE_DENSE a flagged sample has no valid result - the call reports FM_E_DENSE - and the dense kernel's regions
   // of the workspace do not exist: they must not be touched.)
-  const bool dense = a.dense_enabled && b < a.N && a.dense_cnt[b] > 0;
+  const bool dense = a.dense_enabled && b < a.N && a.dense_cnt[b] > 0;       // (uniform: a block never straddles samples)
   const int* cand_count = dense ? a.cand_count_b : a.cand_count;
   const int* cand_j = dense ? a.cand_j_b : a.cand_j;
   const float* cand_x = dense ? a.cand_x_b : a.cand_x;
   const int* ccand_count = dense ? a.ccand_count_b : a.ccand_count;
   const int* ccand_i = dense ? a.ccand_i_b : a.ccand_i;
   const float* ccand_x = dense ? a.ccand_x_b : a.ccand_x;
-  const float* rowP = dense ? a.rowB : a.rowS;
-  const float* colP = dense ? a.colB : a.colS;
-  const int rparts = dense ? a.splits : a.splits_s;
-  // The `slots` lanes of a row work TOGETHER on the row's candidates (usually one): lane s of the group loads the
-  // partial sums s, s + slots, ... of a denominator and the group adds the lanes' shares in lane order - one load per
-  // lane and round trip instead of every lane folding every partial (most lanes hold empty candidate slots), and a
-  // fixed order that every group evaluating the same row or column reproduces bit for bit.
+  // The `slots` lanes of a row work TOGETHER on the row's entries (usually one).
+  //  * dense samples: the lists hold CANDIDATES and the denominators come as partial sums of the dense kernel - lane s
+  //    of the group loads the partials s, s + slots, ... and the group adds the lanes' shares in lane order (one load
+  //    per lane and round trip, a fixed order that every group evaluating the same row or column reproduces);
+  //  * all other samples: the lists hold every SIGNIFICANT entry of the row / column with its exact dot product
+  //    (k_screen), and a denominator is the sum of its list's terms in index order (list_sum).
   const bool row_ok = b < a.N && i < a.L;
   const long grow_c = row_ok ? grow : 0;                      // (clamped: no load behind a branch)
   const int b_c = row_ok ? b : 0, i_c = row_ok ? i : 0;
@@ -127,44 +147,67 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
     for (int q = slot; q < n; q += a.slots) t += p[(long)q * pitch];
     return t;
   };
-  // round trip 1: candidate count, this lane's candidate slot (speculatively), stabiliser, the row's denominator
+  auto wave_max_int = [&](int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+  };
+  // the denominator of row `row` (of sample b_c): its list (lane s = entry s) or its partial sums
+  auto row_denominator = [&](int row, float nm) {
+    const long g = (long)b_c * a.Lp + row;
+    if (dense) return group_sum(share(a.rowB + (long)b_c * a.splits * a.Lp + row, a.splits, a.Lp));
+    const int c2 = min(cand_count[g], a.slots);
+    const int k2 = cand_j[g * a.slots + slot];
+    const float x2 = cand_x[g * a.slots + slot];
+    return list_sum(__builtin_amdgcn_exp2f(__builtin_fmaf(x2, a.k, nm)), k2, slot < c2, a.slots, base, wave_max_int(c2));
+  };
+  // round trip 1: entry count, this lane's entry (speculatively), stabiliser, the row's denominator
   const int cnt_raw = cand_count[grow_c];
   const int j_raw = cand_j[grow_c * a.slots + slot];
   const float x_raw = cand_x[grow_c * a.slots + slot];
   const float nmr_i = a.nmr[grow_c];
-  const float rs = group_sum(share(rowP + (long)b_c * rparts * a.Lp + i_c, rparts, a.Lp));
   const int cnt = row_ok ? min(cnt_raw, a.slots) : 0;
   const bool live = slot < cnt;
+  float rs;
+  if (dense) rs = group_sum(share(a.rowB + (long)b_c * a.splits * a.Lp + i_c, a.splits, a.Lp));
+  else rs = list_sum(__builtin_amdgcn_exp2f(__builtin_fmaf(x_raw, a.k, nmr_i)), j_raw, live, a.slots, base, wave_max_int(cnt));
   bool keep = false;
   int j = live ? j_raw : 0x7fffffff;
   float conf = 0.f, colbest = 0.f;
-  for (int t = 0; t < a.slots; ++t) {                         // candidate t of every row of the wave that has one
+  for (int t = 0; t < a.slots; ++t) {                         // entry t of every row of the wave that has one
     if (!__any(t < cnt)) break;                               // wave-uniform
-    if (t < cnt) {                                            // (a row's lanes take this branch together)
-      const int jt = __shfl(j_raw, base + t);
-      const float xt = __shfl(x_raw, base + t);
-      const long gcol = (long)b_c * a.Sp + jt;
-      // round trip 2: the column's denominator (shared fold), stabiliser, and its candidate list - lane s the s-th entry
-      const float cpart = share(colP + (long)b_c * a.panels * a.Sp + jt, a.panels, a.Sp);
-      const float nmc = a.nmc[gcol];
-      const int ccnt = min(ccand_count[gcol], a.slots);
-      const int ci = ccand_i[gcol * a.slots + slot];
-      const float cx = ccand_x[gcol * a.slots + slot];
-      const float cs = group_sum(cpart);
-      const float ct = entry_conf(xt, a.k, nmr_i, rs, nmc, cs);
-      float cb = 0.f;
-      for (int e = 0; e < ccnt; ++e) {                        // the column's candidates: this entry among them
-        const int i2 = __shfl(ci, base + e);
-        float c2 = ct;
-        if (i2 != i) {                                        // another row's entry (rare): that row's denominator
-          const float x2 = __shfl(cx, base + e);
-          const float rs2 = group_sum(share(rowP + (long)b_c * rparts * a.Lp + i2, rparts, a.Lp));
-          c2 = entry_conf(x2, a.k, a.nmr[(long)b_c * a.Lp + i2], rs2, nmc, cs);
-        }
-        cb = fmaxf(cb, c2);
+    const bool act = t < cnt;                                 // (a row's lanes agree)
+    const int jt = act ? __shfl(j_raw, base + t) : 0;
+    const float xt = __shfl(x_raw, base + t);
+    const long gcol = (long)b_c * a.Sp + jt;
+    // round trip 2: the column's denominator, stabiliser, and its list - lane s the s-th entry
+    const float nmc = a.nmc[gcol];
+    const int ccnt = act ? min(ccand_count[gcol], a.slots) : 0;
+    const int ci = ccand_i[gcol * a.slots + slot];
+    const float cx = ccand_x[gcol * a.slots + slot];
+    float cs;
+    if (dense) cs = group_sum(share(a.colB + (long)b_c * a.panels * a.Sp + jt, a.panels, a.Sp));
+    else cs = list_sum(__builtin_amdgcn_exp2f(__builtin_fmaf(cx, a.k, nmc)), ci, slot < ccnt, a.slots, base, wave_max_int(ccnt));
+    // (an entry that is negligible for its column - not in that column's list - has conf < 2^-32)
+    const bool col_sig = dense || __builtin_fmaf(xt, a.k, nmc) > -kSkipLog2;
+    const float ct = (act && col_sig) ? entry_conf(xt, a.k, nmr_i, rs, nmc, cs) : 0.f;
+    float cb = 0.f;
+    const int cmax = wave_max_int(ccnt);
+    for (int e = 0; e < cmax; ++e) {                          // the column's entries: this entry among them
+      const bool ea = e < ccnt;
+      const int i2 = ea ? __shfl(ci, base + e) : i_c;
+      const float x2 = __shfl(cx, base + e);
+      const bool other = ea && i2 != i;                       // another row's entry (rare): that row's denominator
+      if (__any(other)) {                                     // wave-uniform
+        const int i2c = other ? i2 : i_c;
+        const float nm2 = a.nmr[(long)b_c * a.Lp + i2c];
+        const float rs2 = row_denominator(i2c, nm2);
+        const float c2 = entry_conf(x2, a.k, nm2, rs2, nmc, cs);
+        if (other && (dense || __builtin_fmaf(x2, a.k, nm2) > -kSkipLog2)) cb = fmaxf(cb, c2);
       }
-      if (slot == t) { conf = ct; colbest = cb; }
+      if (ea && i2 == i) cb = fmaxf(cb, ct);
     }
+    if (act && slot == t) { conf = ct; colbest = cb; }
   }
   float rowbest = conf;
   for (int m = 1; m < a.slots; m <<= 1) rowbest = fmaxf(rowbest, __shfl_xor(rowbest, m));
@@ -288,7 +331,6 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   a.dense_enabled = (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) ? 1 : 0;
   a.cell_maps = (mode & FM_MODE_NO_CELL_MAPS) ? 0 : 1;
   a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
-  a.rowS = (const float*)(base + w.rowS); a.colS = (const float*)(base + w.colS);
   a.rowB = (const float*)(base + w.rowB); a.colB = (const float*)(base + w.colB);
   a.cand_count = (const int*)(base + w.cand_count); a.cand_j = (const int*)(base + w.cand_j);
   a.cand_x = (const float*)(base + w.cand_x);

@@ -13,7 +13,8 @@ constexpr int kPanelRows = 256;   // coarse rows (image-0 cells) one workgroup o
 constexpr int kColParts = 1;         // column partials per 256-row panel (the 8 waves' partials are folded in LDS)
 constexpr int kTieCap = 1023;        // listed tie losers per image; beyond it the gathers scan the match list
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
-constexpr int kUnitsPerSplit = 64; // 32-column units one workgroup of the sparse sum kernel covers at most (64-bit live mask)
+constexpr int kUnitsPerSplit = 64; // 32-column units one workgroup of the dense-path kernels covers at most (64-bit live mask)
+constexpr int kScreenUnits = 16;   // ... one workgroup of the screening kernel (their int8 B fragments share its LDS: 8 KiB each at C = 256)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kSkipLog2 = 32.f;    // terms more than 2^32 below every stabiliser are negligible (see coarse_sum_sparse.hip)
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
@@ -53,16 +54,18 @@ struct CoarseWs {
   size_t q0, q1;                              // int8 screening planes
   size_t sigimg;                              // [N][2] the int8 step of image 0 / image 1 of every sample
   size_t amax_u;                              // [N][2] FM_MODE_EXACT_STEP: ord_encode'd largest |x| of image 0 / image 1
+  size_t imgstat;                             // [N][8] per sample {largest L1 norm, largest clipped mass, largest |x|} of
+                                              // image 0, then of image 1 (max pass: the block statistics folded once)
   size_t l1_0, l1_1;                          // L1 norm per descriptor
   size_t bstat0, bstat1;                      // float4 per 32-row block: {largest L1 norm (+inf: a bad value), largest
                                               // clipped L1 mass sum_k max(|x_k| - 127 sigma, 0), largest |x|, 0}
   size_t emarg;                               // [N] log2-domain bound of k * |screening product - exact product|
-  size_t rowS, colS;                          // partial sum-exp of the sparse sum kernel: rows [N][splits_s][Lp],
-                                              // columns [N][panels][Sp]
+  size_t rowS, colS;                          // (round 3: partial sum-exp of the sparse sum kernel; empty since the
+                                              // screening kernel hands over lists of significant entries)
   size_t nmr, nmc;                            // -stabiliser*log2e per row / column
   size_t umax;                                // unit maxima [N][Lp/32][Sp/32] of the integer screening product (as float)
-  size_t cand_j, cand_x;                      // candidate columns and exact dot products per row (sparse kernel's set)
-  size_t ccand_i, ccand_x;                    // the same candidates listed per column: rows, dot products
+  size_t cand_j, cand_x;                      // k_screen: every significant entry of a row (column, exact dot product)
+  size_t ccand_i, ccand_x;                    // ... of a column (row, exact dot product)
   size_t common_total;
   // ---- dense / exact-screening / conf_matrix only ----
   size_t hi0, lo0, hi1, lo1;                  // float16 planes

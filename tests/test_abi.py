@@ -128,7 +128,7 @@ def test_layout_query_is_consistent():
     assert all(o % 256 == 0 for o in offs)
     # sparse sum kernel: splits x units per split cover Sp/32, at most 64 units per split, at most half a round of
     # the chip's workgroup slots at one pair
-    assert v[37] * v[38] >= 150 and v[38] <= 64 and v[6] * v[37] <= 128
+    assert v[37] * v[38] >= 150 and v[38] <= 16 and v[6] * v[37] <= 512      # screening kernel: <= 16 units per workgroup, two per CU
     n = C.c_size_t(0)
     lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n))
     assert offs[-1] == n.value

@@ -56,6 +56,11 @@ def main():
         print(f"   {nme:11s} median {np.median(col):8.0f}  mean {col.mean():8.0f}  min {col.min():8.0f}  max {col.max():8.0f}")
     tot = d[:, :6].sum(1)
     print(f"   total       median {np.median(tot):8.0f}  mean {tot.mean():8.0f}  max {tot.max():8.0f}")
+    wg = tot.reshape(nwg, 8).max(1)
+    print("   per-wave total percentiles 50/90/99/100:", [int(np.percentile(tot, q)) for q in (50, 90, 99, 100)])
+    print("   per-workgroup (slowest wave) percentiles 50/90/99/100:", [int(np.percentile(wg, q)) for q in (50, 90, 99, 100)])
+    worst = int(np.argmax(tot))
+    print("   slowest wave:", [int(x) for x in d[worst]])
     live = d[:, 6] > 0
     print(f"   sweep per live unit {d[live, 3].sum() / d[live, 6].sum():.0f} cyc; exact per entry {d[live, 4].sum() / max(d[live, 7].sum(), 1):.0f} cyc")
 

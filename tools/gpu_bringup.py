@@ -109,11 +109,24 @@ def run(f0, f1, hw_c0, hw_c1, thr=0.2, border=2, temp=0.1, label=""):
     colA = q_decode(view(ws, base, lay["colmax_u"], n * Sp, torch.int32)).reshape(n, Sp) * (sig[:, 0] * sig[:, 1])[:, None]
     nmr = view(ws, base, lay["nmr"], n * Lp, torch.float32).reshape(n, Lp)
     nmc = view(ws, base, lay["nmc"], n * Sp, torch.float32).reshape(n, Sp)
-    # softmax denominators = the sum pass's partials folded (k_cand_conf does the same for its candidates;
-    # the rsum / csum arrays are only written on the exact-screening / conf_matrix paths)
+    # softmax denominators: the screening kernel hands over, per row and per column, the list of its significant entries
+    # (index, exact dot product; x = -inf marks a reserved but empty place) and k_select sums the list's terms; the
+    # dense sum kernel (samples with flagged units) hands over partial sums instead
     splits_s = lay["splits_s"]
-    rsum = view(ws, base, lay["rowS"], n * splits_s * Lp, torch.float32).reshape(n, splits_s, Lp).sum(1)
-    csum = view(ws, base, lay["colS"], n * panels * Sp, torch.float32).reshape(n, panels, Sp).sum(1)
+    log2e_ = 1.4426950408889634
+    k_ = inv_ct * log2e_
+
+    def list_sums(cnt_key, x_key, rows_pad, nm):
+        cntv = view(ws, base, lay[cnt_key], n * rows_pad, torch.int32).reshape(n, rows_pad)
+        xv = view(ws, base, lay[x_key], n * rows_pad * slots, torch.float32).reshape(n, rows_pad, slots).astype(np.float64)
+        live = np.arange(slots)[None, None, :] < np.minimum(cntv, slots)[:, :, None]
+        with np.errstate(over="ignore", invalid="ignore"):
+            term = np.where(live, np.exp2(xv * k_ + nm[:, :, None].astype(np.float64)), 0.0)
+        return np.nan_to_num(term).sum(2)
+    # (ccand_x sits right behind ccand_i in the workspace: one [cols, slots] int32 array further)
+    lay = dict(lay, ccand_x=lay["ccand_i"] + ((n * Sp * slots * 4 + 255) // 256) * 256)
+    rsum = list_sums("cand_count", "cand_x", Lp, nmr)
+    csum = list_sums("ccand_count", "ccand_x", Sp, nmc)
     scal = view(ws, base, lay["scalars"], 3, torch.int32)
     dcnt = view(ws, base, lay["dense_cnt"], n, torch.int32)
     print(f"   scalars: flags={scal[0]} dense_units={scal[1]} per sample {dcnt.tolist()}; sparse splits {splits_s} x {lay['units_s']} units")
