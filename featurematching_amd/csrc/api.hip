@@ -142,7 +142,7 @@ extern "C" int fm_default_cand_slots(float thr) {
 static bool valid_slots(int s) { return s >= 4 && s <= 64 && (s & (s - 1)) == 0; }
 
 static bool needs_dense_region(int mode, bool want_conf) {
-  return want_conf || (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) != 0;
+  return want_conf || (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_STATS)) != 0;
 }
 
 extern "C" int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int cand_slots, int mode, int want_conf_matrix,
@@ -150,7 +150,7 @@ extern "C" int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int ca
   if (!bytes) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP)) return FM_E_UNSUPPORTED;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP | FM_MODE_STATS)) return FM_E_UNSUPPORTED;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   *bytes = needs_dense_region(mode, want_conf_matrix != 0) ? w.total : w.common_total;
   return FM_OK;
@@ -213,7 +213,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP)) return FM_E_UNSUPPORTED;
+  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP | FM_MODE_STATS)) return FM_E_UNSUPPORTED;
   const bool exact = (mode & FM_MODE_EXACT_SCREENING) != 0;
   const bool dense = needs_dense_region(mode, conf_matrix != nullptr);      // exact screening and conf_matrix read the planes too
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
@@ -233,7 +233,8 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   // sparse sum kernel: stabilisers, live units, exact terms of the few significant entries, candidates (listed per row
   // and per column); flags the samples with too many significant entries per unit (flat similarity)
   // (dead-row certificates only when nobody reads every row's denominator: the dense conf_matrix does)
-  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, conf_matrix ? 0 : 1, st);
+  const bool stats = (mode & FM_MODE_STATS) != 0;      // the softmax statistics of EVERY row and column are wanted
+  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, (conf_matrix || stats) ? 0 : 1, st);
   if (e != hipSuccess) return (int)e;
   if (dense) {
     // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or
@@ -248,7 +249,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   // The assignment folds the softmax denominators of its candidates from the partial sums itself.  The
   // denominators / log-softmax offsets of EVERY row and column are only needed by the exact screening and by the
   // dense conf_matrix:
-  if (exact || conf_matrix) {
+  if (exact || conf_matrix || stats) {
     e = launch_reduce(1, w, base, inv_ct, st);
     if (e != hipSuccess) return (int)e;
   }
@@ -258,6 +259,10 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   }
   if (conf_matrix) {           // dense data['conf_matrix'] on request (one more sweep)
     e = launch_corr(3, w, base, inv_ct, thr, st, conf_matrix);
+    if (e != hipSuccess) return (int)e;
+    // ... whose hi/lo-split products carry 22 bits: the entries that matter are rewritten from their exact float32 dot
+    // products (the rows' lists of significant entries)
+    e = launch_conf_patch(w, base, inv_ct, conf_matrix, st);
     if (e != hipSuccess) return (int)e;
   }
   e = launch_select(w, base, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
@@ -275,6 +280,20 @@ extern "C" int fm_coarse_cell_maps(void* workspace, int N, int L, int S, int C, 
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   *cell0 = (int32_t*)((char*)workspace + w.cell0); *pitch0 = w.Lp; *ties0 = (int32_t*)((char*)workspace + w.ties0);
   *cell1 = (int32_t*)((char*)workspace + w.cell1); *pitch1 = w.Sp; *ties1 = (int32_t*)((char*)workspace + w.ties1);
+  return FM_OK;
+}
+
+// Device pointers of the log-softmax offsets the coarse stage leaves in its workspace when it ran with FM_MODE_STATS or a
+// conf_matrix request: log2 softmax(sim, dim 2)[b,i,j] = k2 x + ofs_r[b * pitch_r + i] and log2 softmax(sim, dim 1)[b,i,j]
+// = k2 x + ofs_c[b * pitch_c + j] with x = feat0[b,i] . feat1[b,j] and k2 = log2(e) / (C temperature).
+extern "C" int fm_coarse_softmax_offsets(void* workspace, int N, int L, int S, int C, int cand_slots, const float** ofs_r,
+                                         int* pitch_r, const float** ofs_c, int* pitch_c) {
+  if (!workspace || !ofs_r || !pitch_r || !ofs_c || !pitch_c) return FM_E_NULL;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  *ofs_r = (const float*)((char*)workspace + w.nmr2); *pitch_r = w.Lp;
+  *ofs_c = (const float*)((char*)workspace + w.nmc2); *pitch_c = w.Sp;
   return FM_OK;
 }
 

@@ -62,7 +62,7 @@ class CoarseMatching(nn.Module):
         if self.conf_matrix:
             conf = out['conf_matrix']
             if torch.is_grad_enabled() and (feat_c0.requires_grad or feat_c1.requires_grad):
-                conf = ops.attach_conf_matrix_grad(feat_c0, feat_c1, conf, self.temperature)
+                conf = ops.attach_conf_matrix_grad(feat_c0, feat_c1, conf, self.temperature, out['_coarse_buffers'])
             data.update({'conf_matrix': conf})
         mconf = out['mconf']
         b_ids, i_ids, j_ids = out['b_ids'], out['i_ids'], out['j_ids']

@@ -84,6 +84,20 @@ class CoarseBuffers:
                                            C.byref(p1), C.byref(q1), C.byref(t1)), "fm_coarse_cell_maps")
         return (p0.value, q0.value, t0.value), (p1.value, q1.value, t1.value)
 
+    def softmax_offsets(self):
+        """(ofs_r address, pitch_r, ofs_c address, pitch_c): the log-softmax offsets of every row / column inside the
+        workspace (fm_coarse_softmax_offsets; valid while this object is alive).  Needs stats=True or conf_matrix=True."""
+        if not getattr(self, '_has_stats', False):
+            raise RuntimeError("this coarse call ran without stats=True / conf_matrix=True: no softmax statistics")
+        lib = _lib.load()
+        n, l, s, c, slots = self._shape
+        pr, pc = C.c_void_p(), C.c_void_p()
+        qr, qc = C.c_int(), C.c_int()
+        base = self.workspace.data_ptr() + ((-self.workspace.data_ptr()) % 256)
+        _lib.check(lib.fm_coarse_softmax_offsets(C.c_void_p(base), n, l, s, c, slots, C.byref(pr), C.byref(qr), C.byref(pc),
+                                                 C.byref(qc)), "fm_coarse_softmax_offsets")
+        return pr.value, qr.value, pc.value, qc.value
+
     def sliced(self, m: int) -> dict:
         return dict(b_ids=self.b_ids[:m], i_ids=self.i_ids[:m], j_ids=self.j_ids[:m],
                     mkpts0_c=self.mkpts0_c[:m], mkpts1_c=self.mkpts1_c[:m], mconf=self.mconf[:m])
@@ -94,7 +108,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
                        conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False,
-                       cell_maps: bool = True, exact_step: bool = False) -> CoarseBuffers:
+                       cell_maps: bool = True, exact_step: bool = False, stats: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
@@ -105,7 +119,9 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     candidate slots report FM_E_CANDIDATES).  cell_maps=False (FM_MODE_NO_CELL_MAPS) skips the cell -> match maps the
     cell-ordered window crops read (CoarseBuffers.cell_maps() is then meaningless).  `exact_step`
     (FM_MODE_EXACT_STEP) derives the int8 screening step from the images' true maxima (one more small kernel) instead
-    of from a sample of rows: the answer to FM_E_STEP (an outlier descriptor outside the sample)."""
+    of from a sample of rows: the answer to FM_E_STEP (an outlier descriptor outside the sample).  `stats`
+    (FM_MODE_STATS) leaves the log-softmax offsets of every row and column in the workspace
+    (CoarseBuffers.softmax_offsets(): what dual_softmax_at and its backward read)."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -121,7 +137,8 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     if cand_slots is None:
         cand_slots = lib.fm_default_cand_slots(float(thr))
     mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
-           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_EXACT_STEP if exact_step else 0)
+           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_EXACT_STEP if exact_step else 0) | \
+           (_lib.FM_MODE_STATS if stats else 0)
     nbytes = C.c_size_t(0)
     _lib.check(lib.fm_coarse_workspace_bytes_mode(n, l, s, c, cand_slots, mode, int(bool(conf_matrix)), C.byref(nbytes)),
                "fm_coarse_workspace_bytes_mode")
@@ -147,6 +164,8 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     out._keep = (f0, f1, sc0, sc1)   # inputs must outlive the enqueued kernels
     out._shape = (n, l, s, c, cand_slots)
     out._has_cell_maps = bool(cell_maps)
+    out._has_stats = bool(stats or conf_matrix)
+    out._temperature = float(temperature)
     return out
 
 
@@ -218,7 +237,7 @@ MODE_MEMORY = ModeMemory()
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
                  scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None,
-                 dense: Optional[bool] = None, exact_step: Optional[bool] = None) -> dict:
+                 dense: Optional[bool] = None, exact_step: Optional[bool] = None, stats: bool = False) -> dict:
     """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
     N*min(L,S)), with the dense sum kernel (FM_E_DENSE), with the exact screening pass, then with more candidate
     slots when the device reports the corresponding condition, with the exact int8 step when the sampled one clipped an
@@ -234,7 +253,7 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
     if exact_step is None:
         exact_step = MODE_MEMORY.step(key, probing)
     if exact_screening is None:
-        exact_screening = bool(conf_matrix) or mem_exact
+        exact_screening = bool(conf_matrix) or bool(stats) or mem_exact
     if dense is None:
         dense = mem_dense
     kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening),
@@ -242,7 +261,7 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
     retried_internal = False
     for _ in range(8):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
-                                 scale0, scale1, conf_matrix=conf_matrix, **kw)
+                                 scale0, scale1, conf_matrix=conf_matrix, stats=stats, **kw)
         try:
             m = buf.read_count()
         except _lib.FMatchError as e:
@@ -281,6 +300,63 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
     raise RuntimeError("coarse_match: overflow persisted after retries")
 
 
+def _dsm_backward(f0, f1, temperature, buffers, b_ids, i_ids, j_ids, gc):
+    """(dL/df0, dL/df1) of sum_e g_e conf_e from gc = g * conf at the entries (fm_dual_softmax_backward): two launches of
+    one tiled kernel that recomputes the similarities tile by tile - no [N, L, S] array."""
+    lib = _lib.load()
+    x0, x1 = _f32c(f0, "feat_c0"), _f32c(f1, "feat_c1")
+    n, l, c = x0.shape
+    s = x1.shape[1]
+    pr, qr, pc, qc = buffers.softmax_offsets()
+    need = int(lib.fm_dual_softmax_backward_workspace_bytes(n, l, s, c))
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=x0.device)
+    off = (-ws.data_ptr()) % 256
+    d0, d1 = torch.empty_like(x0), torch.empty_like(x1)
+    k = int(b_ids.shape[0])
+    b64 = lambda t: t.to(torch.int64).contiguous()
+    bb, ii, jj, g = b64(b_ids), b64(i_ids), b64(j_ids), _f32c(gc, "gc")
+    _lib.check(lib.fm_dual_softmax_backward(_ptr(x0), _ptr(x1), n, l, s, c, float(temperature), C.c_void_p(pr), qr,
+                                            C.c_void_p(pc), qc, _ptr(bb), _ptr(ii), _ptr(jj), _ptr(g), k,
+                                            C.c_void_p(ws.data_ptr() + off), need, _ptr(d0), _ptr(d1), _stream(x0.device)),
+               "fm_dual_softmax_backward")
+    d0._keep = (ws, bb, ii, jj, g, buffers)
+    return d0.to(f0.dtype), d1.to(f1.dtype)
+
+
+class _DualSoftmaxAt(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat_c0, feat_c1, b_ids, i_ids, j_ids, temperature, buffers):
+        lib = _lib.load()
+        x0, x1 = _f32c(feat_c0, "feat_c0"), _f32c(feat_c1, "feat_c1")
+        n, l, c = x0.shape
+        s = x1.shape[1]
+        pr, qr, pc, qc = buffers.softmax_offsets()
+        k = int(b_ids.shape[0])
+        b64 = lambda t: t.to(torch.int64).contiguous()
+        bb, ii, jj = b64(b_ids), b64(i_ids), b64(j_ids)
+        conf = torch.empty(k, dtype=torch.float32, device=x0.device)
+        _lib.check(lib.fm_dual_softmax_conf_at(_ptr(x0), _ptr(x1), n, l, s, c, float(temperature), C.c_void_p(pr), qr,
+                                               C.c_void_p(pc), qc, _ptr(bb), _ptr(ii), _ptr(jj), k, _ptr(conf),
+                                               _stream(x0.device)), "fm_dual_softmax_conf_at")
+        ctx.save_for_backward(feat_c0, feat_c1, bb, ii, jj, conf)
+        ctx.temperature, ctx.buffers = float(temperature), buffers
+        return conf
+
+    @staticmethod
+    def backward(ctx, grad):
+        f0, f1, bb, ii, jj, conf = ctx.saved_tensors
+        d0, d1 = _dsm_backward(f0, f1, ctx.temperature, ctx.buffers, bb, ii, jj, grad.float() * conf)
+        return d0, d1, None, None, None, None, None
+
+
+def dual_softmax_at(feat_c0: torch.Tensor, feat_c1: torch.Tensor, b_ids, i_ids, j_ids, buffers: CoarseBuffers) -> torch.Tensor:
+    """conf_matrix[b_ids, i_ids, j_ids] (coarse_matching_new.py:64-68) as a differentiable function of the descriptors,
+    without the matrix: `buffers` = the CoarseBuffers of a coarse call on the same descriptors that ran with stats=True
+    (out['_coarse_buffers'] of ops.coarse_match(..., stats=True)).  What the reference's coarse loss with sparse
+    supervision reads (losses/loss.py:57-61: conf[pos_mask]); forward and backward allocate O(N (L + S) C)."""
+    return _DualSoftmaxAt.apply(feat_c0, feat_c1, b_ids, i_ids, j_ids, buffers._temperature, buffers)
+
+
 class _ConfMatrixGrad(torch.autograd.Function):
     """Attaches the gradient of the dual softmax to the conf_matrix the HIP forward produced, so that the
     reference's coarse loss (losses/loss.py:27-67 reads data['conf_matrix']) trains the descriptors.
@@ -289,18 +365,30 @@ class _ConfMatrixGrad(torch.autograd.Function):
     (coarse_matching_new.py:64-68).  With G = dL/dconf and c = conf:
         dL/dsim = 2 G c - A u - B v,   u_j = sum_i (G c)_ij,   v_i = sum_j (G c)_ij
         dL/df0  = dL/dsim . f1 / (C T),   dL/df1 = dL/dsim^T . f0 / (C T)
-    The forward values come from the HIP kernels; the backward recomputes A and B with torch ops and uses plain
-    library GEMMs (three dense [N,L,S] temporaries - training only)."""
+    The reference's loss reads conf at the supervised entries only (sparse_spvs, its default: loss.py:57-61), so the G
+    autograd hands over is zero almost everywhere: its non-zero entries go to fm_dual_softmax_backward, which recomputes
+    A and B tile by tile from the softmax statistics of the forward call - no [N, L, S] temporary.  A G that is dense
+    (the non-default loss over all negatives: more than 16 entries per row on average) takes the plain torch
+    formula below (three dense temporaries), with a warning."""
 
     @staticmethod
-    def forward(ctx, feat_c0, feat_c1, conf, temperature):
+    def forward(ctx, feat_c0, feat_c1, conf, temperature, buffers):
         ctx.save_for_backward(feat_c0, feat_c1, conf)
-        ctx.temperature = float(temperature)
+        ctx.temperature, ctx.buffers = float(temperature), buffers
         return conf.view_as(conf)
 
     @staticmethod
     def backward(ctx, grad):
         f0, f1, conf = ctx.saved_tensors
+        n, l, s = conf.shape
+        if ctx.buffers is not None:
+            nz = torch.nonzero(grad, as_tuple=True)
+            if nz[0].shape[0] <= 16 * n * max(l, s):
+                gc = grad[nz] * conf[nz]
+                d0, d1 = _dsm_backward(f0, f1, ctx.temperature, ctx.buffers, nz[0], nz[1], nz[2], gc)
+                return d0, d1, None, None, None
+            import warnings
+            warnings.warn("conf_matrix gradient is dense: falling back to the torch formula (three [N,L,S] temporaries)")
         k = 1.0 / (f0.shape[-1] * ctx.temperature)
         sim = torch.bmm(f0.float(), f1.float().transpose(1, 2)) * k
         gc = grad * conf
@@ -311,13 +399,14 @@ class _ConfMatrixGrad(torch.autograd.Function):
         del sim, gc
         g0 = torch.bmm(dsim, f1.float()) * k
         g1 = torch.bmm(dsim.transpose(1, 2), f0.float()) * k
-        return g0.to(f0.dtype), g1.to(f1.dtype), None, None
+        return g0.to(f0.dtype), g1.to(f1.dtype), None, None, None
 
 
 def attach_conf_matrix_grad(feat_c0: torch.Tensor, feat_c1: torch.Tensor, conf_matrix: torch.Tensor,
-                            temperature: float) -> torch.Tensor:
-    """conf_matrix (from coarse_match(..., conf_matrix=True)) as a differentiable function of the descriptors."""
-    return _ConfMatrixGrad.apply(feat_c0, feat_c1, conf_matrix, temperature)
+                            temperature: float, buffers: Optional[CoarseBuffers] = None) -> torch.Tensor:
+    """conf_matrix (from coarse_match(..., conf_matrix=True)) as a differentiable function of the descriptors;
+    `buffers` = out['_coarse_buffers'] of that call (its softmax statistics serve the HIP backward)."""
+    return _ConfMatrixGrad.apply(feat_c0, feat_c1, conf_matrix, temperature, buffers)
 
 
 def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor, w: int, stride: int,

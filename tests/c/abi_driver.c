@@ -40,6 +40,10 @@ static __typeof__(fm_debug_launch_prep_f16)* p_fm_debug_launch_prep_f16;
 static __typeof__(fm_debug_launch_prep)* p_fm_debug_launch_prep;
 static __typeof__(fm_fine_match_maps)* p_fm_fine_match_maps;
 static __typeof__(fm_fine_match_maps_dtype)* p_fm_fine_match_maps_dtype;
+static __typeof__(fm_coarse_softmax_offsets)* p_fm_coarse_softmax_offsets;
+static __typeof__(fm_dual_softmax_conf_at)* p_fm_dual_softmax_conf_at;
+static __typeof__(fm_dual_softmax_backward)* p_fm_dual_softmax_backward;
+static __typeof__(fm_dual_softmax_backward_workspace_bytes)* p_fm_dual_softmax_backward_workspace_bytes;
 static __typeof__(fm_fine_maps_scratch_bytes_dtype)* p_fm_fine_maps_scratch_bytes_dtype;
 static __typeof__(fm_fine_maps_scratch_bytes)* p_fm_fine_maps_scratch_bytes;
 static __typeof__(fm_debug_reset_counters)* p_fm_debug_reset_counters;
@@ -63,7 +67,7 @@ int main(int argc, char** argv) {
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes); RESOLVE(fm_coarse_workspace_bytes_mode);
   RESOLVE(fm_coarse_match); RESOLVE(fm_coarse_match_dtype); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
-  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_fine_match_maps); RESOLVE(fm_fine_match_maps_dtype); RESOLVE(fm_fine_maps_scratch_bytes_dtype); RESOLVE(fm_fine_maps_scratch_bytes); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
+  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_fine_match_maps); RESOLVE(fm_fine_match_maps_dtype); RESOLVE(fm_coarse_softmax_offsets); RESOLVE(fm_dual_softmax_conf_at); RESOLVE(fm_dual_softmax_backward); RESOLVE(fm_dual_softmax_backward_workspace_bytes); RESOLVE(fm_fine_maps_scratch_bytes_dtype); RESOLVE(fm_fine_maps_scratch_bytes); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
@@ -88,7 +92,7 @@ int main(int argc, char** argv) {
   EXPECT(bytes == full, 1);
   EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 1, &bytes), FM_OK);
   EXPECT(bytes == full, 1);
-  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 16, 0, &bytes), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 64, 0, &bytes), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, FM_MODE_EXACT_STEP, 0, &bytes), FM_OK);
   EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, NULL), FM_E_NULL);
   EXPECT(p_fm_coarse_workspace_bytes(0, 4800, 4800, 256, 8, &bytes), FM_E_SHAPE);
@@ -128,7 +132,7 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.0f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 5, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 16, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
-  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 16, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);   /* unknown mode bit */
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 64, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);   /* unknown mode bit */
   {   /* a workspace sized for the common path is refused when the call needs the dense regions */
     size_t small = 0;
     EXPECT(p_fm_coarse_workspace_bytes_mode(1, 64, 64, 64, 8, 0, 0, &small), FM_OK);
@@ -198,6 +202,21 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 32, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 64, 32, 32, 32, 32, 9, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_fine_match_maps(f, f, 2, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
+  /* training surface: argument checks of the dual-softmax entries */
+  {
+    const float* pr = NULL; const float* pc = NULL; int qr = 0, qc = 0;
+    EXPECT(p_fm_coarse_softmax_offsets(NULL, 1, 64, 64, 64, 8, &pr, &qr, &pc, &qc), FM_E_NULL);
+    EXPECT(p_fm_coarse_softmax_offsets((void*)f, 1, 64, 64, 64, 8, &pr, &qr, &pc, &qc), FM_OK);
+    EXPECT(qr, 256); EXPECT(qc, 64);
+    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 64, 0.1f, f, 256, f, 64, ids, ids, ids, 0, NULL, NULL), FM_OK);      /* K == 0 */
+    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 64, 0.1f, f, 32, f, 64, ids, ids, ids, 4, f, NULL), FM_E_SHAPE);     /* pitch < L */
+    EXPECT(p_fm_dual_softmax_conf_at(f, NULL, 1, 64, 64, 64, 0.1f, f, 256, f, 64, ids, ids, ids, 4, f, NULL), FM_E_NULL);
+    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 66, 0.1f, f, 256, f, 64, ids, ids, ids, 4, f, NULL), FM_E_UNSUPPORTED);
+    EXPECT((int)p_fm_dual_softmax_backward_workspace_bytes(1, 64, 64, 64), 512 + 4 * 64 * 64 * 4);
+    EXPECT((int)p_fm_dual_softmax_backward_workspace_bytes(0, 64, 64, 64), 0);
+    EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, 256, f, 64, ids, ids, ids, f, 4, (void*)f, 16, f, f, NULL), FM_E_WORKSPACE);
+    EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, 256, f, 64, NULL, ids, ids, f, 4, (void*)f, 1u << 30, f, f, NULL), FM_E_NULL);
+  }
   /* element type of the maps: an unknown one is refused, half-precision NCHW maps need scratch for both copies */
   EXPECT(p_fm_fine_match_maps_dtype(f, f, 7, 1, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_fine_match_maps_dtype(f, f, FM_BF16, 0, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_NULL);

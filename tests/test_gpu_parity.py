@@ -779,6 +779,73 @@ def test_conf_matrix_carries_the_dual_softmax_gradient():
         assert scale > 0 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
 
 
+@pytest.mark.parametrize("dist", ["borderline", "peaky"])
+def test_dual_softmax_at_supervised_entries_and_its_backward_without_an_LxS_array(dist):
+    """SURVEY 8(f) row 3 at the metric's size (640x480: L = S = 4800, C = 256): the reference's coarse loss with sparse
+    supervision reads conf_matrix at the ground-truth entries only (losses/loss.py:57-61).  ops.dual_softmax_at gives
+    those entries - and, through fm_dual_softmax_backward, their gradient w.r.t. the descriptors - from the softmax
+    statistics of a coarse call (stats=True) and tile-wise recomputed similarities: no [N, L, S] array is ever
+    allocated (asserted on torch's allocator), against float64 autograd through coarse_matching_new.py:64-68."""
+    cfg = synth.CONFIGS["cfg2"]
+    sh = synth.config_shapes(cfg)
+    l, c = sh['l'], cfg['c']
+    f0, f1 = synth.coarse_descriptors(cfg['seed'] + 40, 1, l, c, dist)
+    hw_c = (sh['hc'], sh['wc'])
+    # supervised entries: 2500 true partners (row i of image 0 sits at column perm^-1(i) of image 1) + 500 wrong pairs
+    perm = synth.permutation(cfg['seed'] + 40, 3, l)             # f1[q] = f0[perm[q]] + noise
+    inv = np.empty(l, np.int64); inv[perm] = np.arange(l)
+    rows = synth.permutation(9, 1, l)[:3000]
+    cols = inv[rows].copy()
+    cols[2500:] = synth.permutation(9, 2, l)[:500]
+    gi, gj = torch.as_tensor(rows, device=DEV), torch.as_tensor(cols, device=DEV)
+    gb = torch.zeros_like(gi)
+
+    def focal(p):          # compute_coarse_loss 'focal' with sparse supervision (loss.py:53-60), alpha 0.25 gamma 2
+        p = torch.clamp(p, 1e-6, 1 - 1e-6)
+        return (-0.25 * torch.pow(1 - p, 2.0) * p.log()).mean()
+
+    # the reference's expression under float64 autograd (this one DOES build the L x S matrices)
+    b0 = torch.as_tensor(f0, device=DEV, dtype=torch.float64).requires_grad_(True)
+    b1 = torch.as_tensor(f1, device=DEV, dtype=torch.float64).requires_grad_(True)
+    sim = torch.einsum("nlc,nsc->nls", b0 / c ** .5, b1 / c ** .5) / 0.1
+    conf64 = (torch.softmax(sim, 1) * torch.softmax(sim, 2))[gb, gi, gj]
+    focal(conf64).backward()
+    ref0, ref1, conf64 = b0.grad.clone(), b1.grad.clone(), conf64.detach().clone()
+    del sim, b0, b1
+    torch.cuda.empty_cache()
+
+    a0 = torch.as_tensor(f0, device=DEV).requires_grad_(True)
+    a1 = torch.as_tensor(f1, device=DEV).requires_grad_(True)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = ops.coarse_match(a0.detach(), a1.detach(), hw_c, hw_c, 8.0, stats=True, dense=(dist != "peaky"))
+    conf = ops.dual_softmax_at(a0, a1, gb, gi, gj, out['_coarse_buffers'])
+    focal(conf).backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 0.75 * l * l * 4, f"peak {peak / 1e6:.1f} MB: an L x S float32 array is {l * l * 4 / 1e6:.1f} MB"
+    assert (conf.detach().double() - conf64).abs().max().item() <= 1e-5
+    for got, ref in ((a0.grad, ref0), (a1.grad, ref1)):
+        scale = ref.abs().max().item()
+        assert scale > 0 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
+
+
+def test_dense_conf_matrix_entries_that_matter_take_the_exact_route():
+    """data['conf_matrix'] on peaked data (|sim| ~ 160): the dense sweep's hi/lo-split products carry 22 bits (2e-4 in a
+    conf near 1 there); every entry with a non-negligible row term is rewritten from its exact float32 dot product
+    (k_conf_patch), so the matrix is within 1e-5 of the reference everywhere."""
+    f0, f1 = synth.coarse_descriptors(58, 2, 30 * 40, 256, "peaky")
+    hw_c = (30, 40)
+    ref = orc.coarse_match(f0, f1, (240, 320), hw_c, hw_c, 0.2, 2, 0.1, return_conf=True)
+    out = ops.coarse_match(torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV), hw_c, hw_c, 8.0, conf_matrix=True)
+    _assert_coarse(out, ref)
+    err = (out['conf_matrix'].cpu() - ref['conf_matrix']).abs().max().item()
+    assert err <= 1e-5, err
+    smax = float(np.abs(f0[0].astype(np.float64) @ f1[0].astype(np.float64).T).max()) / (256 * 0.1)
+    assert smax > 100            # (where the 22-bit route alone would be ~2^-22 * 160 = 4e-5 off)
+
+
 def test_gt_padding_sampler():
     """The older training sampler (network/utils/coarse_matching.py:114-141): predicted matches (sub-sampled when
     there are too many) followed by randomly drawn ground-truth matches with mconf = 0; gt_mask marks them and
