@@ -47,10 +47,12 @@ SIGNATURES = {
     "fm_debug_launch_prep_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "fm_read_count": (_i, [_p, _i, C.POINTER(C.c_int32), _p]),
-    "fm_coarse_softmax_offsets": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_p), C.POINTER(_i)]),
-    "fm_dual_softmax_conf_at": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p]),
+    "fm_coarse_softmax_stats": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_p),
+                                     C.POINTER(_p), C.POINTER(_i)]),
+    "fm_dual_softmax_conf_at": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p]),
     "fm_dual_softmax_backward_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
-    "fm_dual_softmax_backward": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, C.c_size_t, _p, _p, _p]),
+    "fm_dual_softmax_backward": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, C.c_size_t, _p,
+                                      _p, _p]),
     "fm_gather_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "fm_coarse_cell_maps": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_p),
                                  C.POINTER(_p), C.POINTER(_i), C.POINTER(_p)]),

@@ -283,17 +283,19 @@ extern "C" int fm_coarse_cell_maps(void* workspace, int N, int L, int S, int C, 
   return FM_OK;
 }
 
-// Device pointers of the log-softmax offsets the coarse stage leaves in its workspace when it ran with FM_MODE_STATS or a
-// conf_matrix request: log2 softmax(sim, dim 2)[b,i,j] = k2 x + ofs_r[b * pitch_r + i] and log2 softmax(sim, dim 1)[b,i,j]
-// = k2 x + ofs_c[b * pitch_c + j] with x = feat0[b,i] . feat1[b,j] and k2 = log2(e) / (C temperature).
-extern "C" int fm_coarse_softmax_offsets(void* workspace, int N, int L, int S, int C, int cand_slots, const float** ofs_r,
-                                         int* pitch_r, const float** ofs_c, int* pitch_c) {
-  if (!workspace || !ofs_r || !pitch_r || !ofs_c || !pitch_c) return FM_E_NULL;
+// Device pointers of the softmax statistics the coarse stage leaves in its workspace when it ran with FM_MODE_STATS or a
+// conf_matrix request: softmax(sim, dim 2)[b,i,j] = exp2(k2 x + nm_r[b * pitch_r + i]) / sum_r[b * pitch_r + i] and
+// softmax(sim, dim 1)[b,i,j] = exp2(k2 x + nm_c[b * pitch_c + j]) / sum_c[b * pitch_c + j] with x = feat0[b,i] . feat1[b,j]
+// and k2 = log2(e) / (C temperature).
+extern "C" int fm_coarse_softmax_stats(void* workspace, int N, int L, int S, int C, int cand_slots, const float** nm_r,
+                                       const float** sum_r, int* pitch_r, const float** nm_c, const float** sum_c,
+                                       int* pitch_c) {
+  if (!workspace || !nm_r || !sum_r || !pitch_r || !nm_c || !sum_c || !pitch_c) return FM_E_NULL;
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  *ofs_r = (const float*)((char*)workspace + w.nmr2); *pitch_r = w.Lp;
-  *ofs_c = (const float*)((char*)workspace + w.nmc2); *pitch_c = w.Sp;
+  *nm_r = (const float*)((char*)workspace + w.nmr); *sum_r = (const float*)((char*)workspace + w.rsum); *pitch_r = w.Lp;
+  *nm_c = (const float*)((char*)workspace + w.nmc); *sum_c = (const float*)((char*)workspace + w.csum); *pitch_c = w.Sp;
   return FM_OK;
 }
 

@@ -7,8 +7,10 @@
 // g_e = dL/dconf_e at the supervised entries e = (b, i, j) and c_e = conf_e:
 //     dL/dsim_kl = 2 g c [kl supervised] - A_kl u_l - B_kl v_k,      u_l = sum_e[j_e = l] g_e c_e,   v_k = sum_e[i_e = k] g_e c_e
 //     dL/df0 = dL/dsim . f1 / (C T),     dL/df1 = dL/dsim^T . f0 / (C T)
-// A and B follow from the log-softmax offsets the coarse stage leaves in its workspace (k_reduce_sums: log2 A_kl =
-// k2 x_kl + ofs_c[l], log2 B_kl = k2 x_kl + ofs_r[k], x = raw dot product, k2 = log2(e) / (C T)), so the backward is two
+// A and B follow from the softmax statistics the coarse stage leaves in its workspace (stabilisers and denominators:
+// A_kl = exp2(k2 x_kl + nm_c[l]) / sum_c[l], B_kl = exp2(k2 x_kl + nm_r[k]) / sum_r[k], x = raw dot product, k2 = log2(e) /
+// (C T); kept apart - folded into one offset nm - log2(sum) the float32 rounding of ~230 - 230 would cost 1e-5 of a conf
+// near 1), so the backward is two
 // launches of ONE kernel with the roles of the images swapped: a workgroup owns 32 rows of the "owner" image, sweeps the
 // other image in tiles of 32 descriptors, recomputes the 32 x 32 similarities of the tile in float32 (exact products,
 // fused multiply-adds in channel order), turns them into D = -(A u + B v) and accumulates D . other into its rows'
@@ -35,8 +37,9 @@ __device__ __forceinline__ float row_sum16_g(float v) {      // sum over the 16 
 // conf at K entries: 16 lanes per entry (16 channels per lane, four 16-byte loads per row), the exact float32 dot
 // product in a fixed order - the arithmetic of k_screen's exact phase.
 __global__ __launch_bounds__(256) void k_conf_at(const float* __restrict__ f0, const float* __restrict__ f1, int L, int S, int c_in,
-                                                 float k2, const float* __restrict__ ofs_r, int pitch_r,
-                                                 const float* __restrict__ ofs_c, int pitch_c,
+                                                 float k2, const float* __restrict__ nm_r, const float* __restrict__ sum_r,
+                                                 int pitch_r, const float* __restrict__ nm_c,
+                                                 const float* __restrict__ sum_c, int pitch_c,
                                                  const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
                                                  const int64_t* __restrict__ j_ids, int K, float* __restrict__ conf,
                                                  float* __restrict__ xdot) {
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256) void k_conf_at(const float* __restrict__ f0, c
   }
   const float x = row_sum16_g(s);
   if (l16 == 0 && e < K) {
-    conf[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, ofs_r[b * pitch_r + i])) *
-              __builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, ofs_c[b * pitch_c + j]));
+    conf[e] = (__builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm_r[b * pitch_r + i])) / sum_r[b * pitch_r + i]) *
+              (__builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm_c[b * pitch_c + j])) / sum_c[b * pitch_c + j]);
     if (xdot) xdot[e] = x;
   }
 }
@@ -77,13 +80,15 @@ __global__ __launch_bounds__(256) void k_dsm_uv(const int64_t* __restrict__ b_id
   atomicAdd(&u[b_ids[e] * S + j_ids[e]], gc[e]);
 }
 
-// dX[k, :] = sum_l D_kl Y[l, :],  D_kl = -(exp2(k2 x_kl + ofs_y[l]) w_y[l] + exp2(k2 x_kl + ofs_x[k]) w_x[k]),  x = X_k . Y_l
+// dX[k, :] = sum_l D_kl Y[l, :],  D_kl = -(exp2(k2 x_kl + nm_y[l]) w_y[l] / sum_y[l] + exp2(k2 x_kl + nm_x[k]) w_x[k] / sum_x[k]),
+// x = X_k . Y_l
 // grid (ceil(R / 32), N, Z): workgroup = 32 owner rows x the z-th share of the other image's 32-descriptor tiles.
 // C = padded channel count (64 / 128 / 256), c_in <= C the rows' real length.  Partial gradients (one per z) go to
 // part[z][b][row][c_in]; k_dsm_combine adds them up and scales.
 template <int C>
 __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, const float* __restrict__ Y, int R, int T, int c_in,
-                                                 const float* __restrict__ ofs_x, int pitch_x, const float* __restrict__ ofs_y,
+                                                 const float* __restrict__ ofs_x, const float* __restrict__ sum_x, int pitch_x,
+                                                 const float* __restrict__ ofs_y, const float* __restrict__ sum_y,
                                                  int pitch_y, const float* __restrict__ w_x, const float* __restrict__ w_y,
                                                  float k2, float* __restrict__ part) {
   constexpr int P = C + 4;                   // row pitch (floats): 16-byte reads of 16 consecutive rows hit all banks
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, co
   for (int q = 0; q < 4; ++q) {
     const int k = k0 + ty + 8 * q;
     ox[q] = k < R ? ofs_x[(long)b * pitch_x + k] : 0.f;
-    wx[q] = k < R ? w_x[(long)b * R + k] : 0.f;
+    wx[q] = k < R ? w_x[(long)b * R + k] / sum_x[(long)b * pitch_x + k] : 0.f;
   }
   const int c4 = tid & 63, rg = tid >> 6;                 // gradient phase: channels 4 c4 .. + 3, rows 8 rg .. + 7
   float acc[8][4];
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, co
     load_tile(Ys, Yb, l0, T);
     const int l = l0 + tx;
     const float oy = l < T ? ofs_y[(long)b * pitch_y + l] : 0.f;
-    const float wy = l < T ? w_y[(long)b * T + l] : 0.f;
+    const float wy = l < T ? w_y[(long)b * T + l] / sum_y[(long)b * pitch_y + l] : 0.f;
     __syncthreads();
     float sv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -213,8 +218,9 @@ __global__ __launch_bounds__(256) void k_dsm_entries(const float* __restrict__ f
 // with its exact dot product; their conf is rewritten from that number and the same log-softmax offsets.
 // One thread per (row, slot).
 __global__ __launch_bounds__(256) void k_conf_patch(const int* __restrict__ rcount, const int* __restrict__ rlist_j,
-                                                    const float* __restrict__ rlist_x, const float* __restrict__ ofs_r,
-                                                    const float* __restrict__ ofs_c, const int* __restrict__ dense_cnt, int N,
+                                                    const float* __restrict__ rlist_x, const float* __restrict__ nm_r,
+                                                    const float* __restrict__ sum_r, const float* __restrict__ nm_c,
+                                                    const float* __restrict__ sum_c, const int* __restrict__ dense_cnt, int N,
                                                     int L, int S, int Lp, int Sp, int slots, float k2, float* __restrict__ conf) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long grow = gid / slots;
@@ -225,15 +231,17 @@ __global__ __launch_bounds__(256) void k_conf_patch(const int* __restrict__ rcou
   const float x = rlist_x[grow * slots + slot];
   if (!(x > -INFINITY)) return;                    // a reserved but empty place
   const int j = rlist_j[grow * slots + slot];
-  conf[((long)b * L + i) * S + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, ofs_r[grow])) *
-                                    __builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, ofs_c[(long)b * Sp + j]));
+  const long gcol = (long)b * Sp + j;
+  conf[((long)b * L + i) * S + j] = (__builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm_r[grow])) / sum_r[grow]) *
+                                    (__builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm_c[gcol])) / sum_c[gcol]);
 }
 
 hipError_t launch_conf_patch(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st) {
   const long total = (long)w.N * w.Lp * w.slots;
   hipLaunchKernelGGL(k_conf_patch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const int*)(base + w.cand_count),
-                     (const int*)(base + w.cand_j), (const float*)(base + w.cand_x), (const float*)(base + w.nmr2),
-                     (const float*)(base + w.nmc2), (const int*)(base + w.dense_cnt), w.N, w.L, w.S, w.Lp, w.Sp, w.slots,
+                     (const int*)(base + w.cand_j), (const float*)(base + w.cand_x), (const float*)(base + w.nmr),
+                     (const float*)(base + w.rsum), (const float*)(base + w.nmc), (const float*)(base + w.csum),
+                     (const int*)(base + w.dense_cnt), w.N, w.L, w.S, w.Lp, w.Sp, w.slots,
                      inv_ct * kLog2e, conf);
   return hipGetLastError();
 }
@@ -251,16 +259,17 @@ using namespace fm;
 static bool dsm_shape_ok(int N, int L, int S, int C) { return N > 0 && L > 0 && S > 0 && valid_channels(C); }
 
 extern "C" int fm_dual_softmax_conf_at(const float* feat0, const float* feat1, int N, int L, int S, int C, float temperature,
-                                       const float* ofs_r, int pitch_r, const float* ofs_c, int pitch_c,
+                                       const float* ofs_r, const float* sum_r, int pitch_r, const float* ofs_c,
+                                       const float* sum_c, int pitch_c,
                                        const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, int K, float* conf,
                                        void* stream) {
   if (K == 0) return FM_OK;
-  if (!feat0 || !feat1 || !ofs_r || !ofs_c || !b_ids || !i_ids || !j_ids || !conf) return FM_E_NULL;
+  if (!feat0 || !feat1 || !ofs_r || !ofs_c || !sum_r || !sum_c || !b_ids || !i_ids || !j_ids || !conf) return FM_E_NULL;
   if (!(N > 0 && L > 0 && S > 0) || K < 0 || pitch_r < L || pitch_c < S) return FM_E_SHAPE;
   if (!valid_channels(C) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
   const float k2 = kLog2e / ((float)C * temperature);
   hipLaunchKernelGGL(k_conf_at, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, feat0, feat1, L, S, C, k2, ofs_r,
-                     pitch_r, ofs_c, pitch_c, b_ids, i_ids, j_ids, K, conf, (float*)nullptr);
+                     sum_r, pitch_r, ofs_c, sum_c, pitch_c, b_ids, i_ids, j_ids, K, conf, (float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -271,11 +280,12 @@ extern "C" size_t fm_dual_softmax_backward_workspace_bytes(int N, int L, int S, 
 }
 
 extern "C" int fm_dual_softmax_backward(const float* feat0, const float* feat1, int N, int L, int S, int C, float temperature,
-                                        const float* ofs_r, int pitch_r, const float* ofs_c, int pitch_c,
+                                        const float* ofs_r, const float* sum_r, int pitch_r, const float* ofs_c,
+                                        const float* sum_c, int pitch_c,
                                         const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, const float* gc,
                                         int K, void* workspace, size_t workspace_bytes, float* d_feat0, float* d_feat1,
                                         void* stream) {
-  if (!feat0 || !feat1 || !ofs_r || !ofs_c || !workspace || !d_feat0 || !d_feat1) return FM_E_NULL;
+  if (!feat0 || !feat1 || !ofs_r || !ofs_c || !sum_r || !sum_c || !workspace || !d_feat0 || !d_feat1) return FM_E_NULL;
   if (K > 0 && (!b_ids || !i_ids || !j_ids || !gc)) return FM_E_NULL;
   if (!(N > 0 && L > 0 && S > 0) || K < 0 || pitch_r < L || pitch_c < S) return FM_E_SHAPE;
   if (!valid_channels(C) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
@@ -301,8 +311,9 @@ extern "C" int fm_dual_softmax_backward(const float* feat0, const float* feat1, 
     static unsigned long long lds_set = 0;                                                                                 \
     e = ensure_dynamic_lds(&k_dsm_bwd<CC>, (64 * (CC + 4) + 32 * 36) * 4, &lds_set);                                       \
     if (e != hipSuccess) return (int)e;                                                                                    \
-    hipLaunchKernelGGL(k_dsm_bwd<CC>, grid, dim3(256), smem, st, X, Y, R, T, C, side ? ofs_c : ofs_r, side ? pitch_c : pitch_r, \
-                       side ? ofs_r : ofs_c, side ? pitch_r : pitch_c, side ? u : v, side ? v : u, k2, part);             \
+    hipLaunchKernelGGL(k_dsm_bwd<CC>, grid, dim3(256), smem, st, X, Y, R, T, C, side ? ofs_c : ofs_r, side ? sum_c : sum_r, \
+                       side ? pitch_c : pitch_r, side ? ofs_r : ofs_c, side ? sum_r : sum_c, side ? pitch_r : pitch_c,     \
+                       side ? u : v, side ? v : u, k2, part);                                                            \
     break;                                                                                                                 \
   }
     switch (Cp) {

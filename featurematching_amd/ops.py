@@ -84,19 +84,20 @@ class CoarseBuffers:
                                            C.byref(p1), C.byref(q1), C.byref(t1)), "fm_coarse_cell_maps")
         return (p0.value, q0.value, t0.value), (p1.value, q1.value, t1.value)
 
-    def softmax_offsets(self):
-        """(ofs_r address, pitch_r, ofs_c address, pitch_c): the log-softmax offsets of every row / column inside the
-        workspace (fm_coarse_softmax_offsets; valid while this object is alive).  Needs stats=True or conf_matrix=True."""
+    def softmax_stats(self):
+        """(nm_r, sum_r, pitch_r, nm_c, sum_c, pitch_c): device addresses of the stabilisers and denominators of every
+        row / column inside the workspace (fm_coarse_softmax_stats; valid while this object is alive).  Needs
+        stats=True or conf_matrix=True."""
         if not getattr(self, '_has_stats', False):
             raise RuntimeError("this coarse call ran without stats=True / conf_matrix=True: no softmax statistics")
         lib = _lib.load()
         n, l, s, c, slots = self._shape
-        pr, pc = C.c_void_p(), C.c_void_p()
+        nr, sr, nc, sc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         qr, qc = C.c_int(), C.c_int()
         base = self.workspace.data_ptr() + ((-self.workspace.data_ptr()) % 256)
-        _lib.check(lib.fm_coarse_softmax_offsets(C.c_void_p(base), n, l, s, c, slots, C.byref(pr), C.byref(qr), C.byref(pc),
-                                                 C.byref(qc)), "fm_coarse_softmax_offsets")
-        return pr.value, qr.value, pc.value, qc.value
+        _lib.check(lib.fm_coarse_softmax_stats(C.c_void_p(base), n, l, s, c, slots, C.byref(nr), C.byref(sr), C.byref(qr),
+                                               C.byref(nc), C.byref(sc), C.byref(qc)), "fm_coarse_softmax_stats")
+        return C.c_void_p(nr.value), C.c_void_p(sr.value), qr.value, C.c_void_p(nc.value), C.c_void_p(sc.value), qc.value
 
     def sliced(self, m: int) -> dict:
         return dict(b_ids=self.b_ids[:m], i_ids=self.i_ids[:m], j_ids=self.j_ids[:m],
@@ -121,7 +122,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     (FM_MODE_EXACT_STEP) derives the int8 screening step from the images' true maxima (one more small kernel) instead
     of from a sample of rows: the answer to FM_E_STEP (an outlier descriptor outside the sample).  `stats`
     (FM_MODE_STATS) leaves the log-softmax offsets of every row and column in the workspace
-    (CoarseBuffers.softmax_offsets(): what dual_softmax_at and its backward read)."""
+    (CoarseBuffers.softmax_stats(): what dual_softmax_at and its backward read)."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -307,7 +308,7 @@ def _dsm_backward(f0, f1, temperature, buffers, b_ids, i_ids, j_ids, gc):
     x0, x1 = _f32c(f0, "feat_c0"), _f32c(f1, "feat_c1")
     n, l, c = x0.shape
     s = x1.shape[1]
-    pr, qr, pc, qc = buffers.softmax_offsets()
+    stats = buffers.softmax_stats()
     need = int(lib.fm_dual_softmax_backward_workspace_bytes(n, l, s, c))
     ws = torch.empty(need + 256, dtype=torch.uint8, device=x0.device)
     off = (-ws.data_ptr()) % 256
@@ -315,8 +316,8 @@ def _dsm_backward(f0, f1, temperature, buffers, b_ids, i_ids, j_ids, gc):
     k = int(b_ids.shape[0])
     b64 = lambda t: t.to(torch.int64).contiguous()
     bb, ii, jj, g = b64(b_ids), b64(i_ids), b64(j_ids), _f32c(gc, "gc")
-    _lib.check(lib.fm_dual_softmax_backward(_ptr(x0), _ptr(x1), n, l, s, c, float(temperature), C.c_void_p(pr), qr,
-                                            C.c_void_p(pc), qc, _ptr(bb), _ptr(ii), _ptr(jj), _ptr(g), k,
+    _lib.check(lib.fm_dual_softmax_backward(_ptr(x0), _ptr(x1), n, l, s, c, float(temperature), *stats,
+                                            _ptr(bb), _ptr(ii), _ptr(jj), _ptr(g), k,
                                             C.c_void_p(ws.data_ptr() + off), need, _ptr(d0), _ptr(d1), _stream(x0.device)),
                "fm_dual_softmax_backward")
     d0._keep = (ws, bb, ii, jj, g, buffers)
@@ -330,13 +331,13 @@ class _DualSoftmaxAt(torch.autograd.Function):
         x0, x1 = _f32c(feat_c0, "feat_c0"), _f32c(feat_c1, "feat_c1")
         n, l, c = x0.shape
         s = x1.shape[1]
-        pr, qr, pc, qc = buffers.softmax_offsets()
+        stats = buffers.softmax_stats()
         k = int(b_ids.shape[0])
         b64 = lambda t: t.to(torch.int64).contiguous()
         bb, ii, jj = b64(b_ids), b64(i_ids), b64(j_ids)
         conf = torch.empty(k, dtype=torch.float32, device=x0.device)
-        _lib.check(lib.fm_dual_softmax_conf_at(_ptr(x0), _ptr(x1), n, l, s, c, float(temperature), C.c_void_p(pr), qr,
-                                               C.c_void_p(pc), qc, _ptr(bb), _ptr(ii), _ptr(jj), k, _ptr(conf),
+        _lib.check(lib.fm_dual_softmax_conf_at(_ptr(x0), _ptr(x1), n, l, s, c, float(temperature), *stats,
+                                               _ptr(bb), _ptr(ii), _ptr(jj), k, _ptr(conf),
                                                _stream(x0.device)), "fm_dual_softmax_conf_at")
         ctx.save_for_backward(feat_c0, feat_c1, bb, ii, jj, conf)
         ctx.temperature, ctx.buffers = float(temperature), buffers

@@ -68,7 +68,7 @@ enum fm_status {
 #define FM_MODE_NO_CELL_MAPS 4    /* skip the cell -> match maps of fm_coarse_cell_maps (two returning atomics per match):
                                      for callers that do not use the cell-ordered window crops */
 #define FM_MODE_STATS 16          /* also leave the log-softmax offsets of EVERY row and column in the workspace
-                                     (fm_coarse_softmax_offsets): what fm_dual_softmax_conf_at / _backward read.  No
+                                     (fm_coarse_softmax_stats): what fm_dual_softmax_conf_at / _backward read.  No
                                      row or column is skipped as "cannot hold a match"; needs the full-size workspace */
 #define FM_MODE_EXACT_STEP 8      /* one more (small) kernel finds the largest |x| of every image first, and the int8
                                      screening step is derived from it instead of from a sample of rows: nothing is
@@ -354,30 +354,33 @@ int fm_epipolar_errors(const float* mkpts0, const float* mkpts1, int kpt_stride,
 /*
  * Training surface of the coarse stage without any [N, L, S] array.  The reference's coarse loss
  * (losses/loss.py:27-67 with sparse_spvs, its default) reads data['conf_matrix'] at the supervised entries only.
- *   fm_coarse_softmax_offsets : [dev] pointers into the workspace of a fm_coarse_match call that ran with FM_MODE_STATS
- *                               (or a conf_matrix request): log2 softmax(sim, dim 2)[b,i,j] = k2 x + ofs_r[b*pitch_r + i],
- *                               log2 softmax(sim, dim 1)[b,i,j] = k2 x + ofs_c[b*pitch_c + j], x = feat0[b,i] . feat1[b,j],
- *                               k2 = log2(e) / (C temperature).  Valid while the workspace is.
+ *   fm_coarse_softmax_stats   : [dev] pointers into the workspace of a fm_coarse_match call that ran with FM_MODE_STATS
+ *                               (or a conf_matrix request): softmax(sim, dim 2)[b,i,j] = exp2(k2 x + nm_r[b*pitch_r + i]) /
+ *                               sum_r[b*pitch_r + i], softmax(sim, dim 1)[b,i,j] = exp2(k2 x + nm_c[b*pitch_c + j]) /
+ *                               sum_c[b*pitch_c + j], x = feat0[b,i] . feat1[b,j], k2 = log2(e) / (C temperature)
+ *                               (stabiliser and denominator kept apart: folded into one offset the float32 rounding
+ *                               would cost 1e-5 of a conf near 1).  Valid while the workspace is.
  *   fm_dual_softmax_conf_at   : conf[e] = softmax(sim,1) * softmax(sim,2) at K entries (b_ids, i_ids, j_ids [dev] int64),
  *                               from exact float32 dot products (coarse_matching_new.py:64-68 restricted to the entries).
  *   fm_dual_softmax_backward  : d_feat0 [N,L,C], d_feat1 [N,S,C] = the gradient of sum_e g_e conf_e w.r.t. the
  *                               descriptors, given gc[e] = g_e * conf_e [dev] float32 [K]:
  *                                 dL/dsim_kl = 2 g c [kl supervised] - A_kl u_l - B_kl v_k,  u / v = column / row sums of g c
- *                               (A, B recomputed tile by tile from the offsets; float32 arithmetic).  workspace:
+ *                               (A, B recomputed tile by tile from the statistics; float32 arithmetic).  workspace:
  *                               fm_dual_softmax_backward_workspace_bytes bytes [dev], 256-byte aligned.  feat0 / feat1
  *                               float32.  Entries sharing a row or a column are added with float atomics (the order of
  *                               their additions is the only non-deterministic part).
  */
-int fm_coarse_softmax_offsets(void* workspace, int N, int L, int S, int C, int cand_slots, const float** ofs_r,
-                              int* pitch_r, const float** ofs_c, int* pitch_c);
+int fm_coarse_softmax_stats(void* workspace, int N, int L, int S, int C, int cand_slots, const float** nm_r,
+                            const float** sum_r, int* pitch_r, const float** nm_c, const float** sum_c, int* pitch_c);
 int fm_dual_softmax_conf_at(const float* feat0, const float* feat1, int N, int L, int S, int C, float temperature,
-                            const float* ofs_r, int pitch_r, const float* ofs_c, int pitch_c, const int64_t* b_ids,
-                            const int64_t* i_ids, const int64_t* j_ids, int K, float* conf, void* stream);
+                            const float* nm_r, const float* sum_r, int pitch_r, const float* nm_c, const float* sum_c,
+                            int pitch_c, const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, int K,
+                            float* conf, void* stream);
 size_t fm_dual_softmax_backward_workspace_bytes(int N, int L, int S, int C);
 int fm_dual_softmax_backward(const float* feat0, const float* feat1, int N, int L, int S, int C, float temperature,
-                             const float* ofs_r, int pitch_r, const float* ofs_c, int pitch_c, const int64_t* b_ids,
-                             const int64_t* i_ids, const int64_t* j_ids, const float* gc, int K, void* workspace,
-                             size_t workspace_bytes, float* d_feat0, float* d_feat1, void* stream);
+                             const float* nm_r, const float* sum_r, int pitch_r, const float* nm_c, const float* sum_c,
+                             int pitch_c, const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, const float* gc,
+                             int K, void* workspace, size_t workspace_bytes, float* d_feat0, float* d_feat1, void* stream);
 
 #ifdef __cplusplus
 }

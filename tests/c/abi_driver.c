@@ -40,7 +40,7 @@ static __typeof__(fm_debug_launch_prep_f16)* p_fm_debug_launch_prep_f16;
 static __typeof__(fm_debug_launch_prep)* p_fm_debug_launch_prep;
 static __typeof__(fm_fine_match_maps)* p_fm_fine_match_maps;
 static __typeof__(fm_fine_match_maps_dtype)* p_fm_fine_match_maps_dtype;
-static __typeof__(fm_coarse_softmax_offsets)* p_fm_coarse_softmax_offsets;
+static __typeof__(fm_coarse_softmax_stats)* p_fm_coarse_softmax_stats;
 static __typeof__(fm_dual_softmax_conf_at)* p_fm_dual_softmax_conf_at;
 static __typeof__(fm_dual_softmax_backward)* p_fm_dual_softmax_backward;
 static __typeof__(fm_dual_softmax_backward_workspace_bytes)* p_fm_dual_softmax_backward_workspace_bytes;
@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes); RESOLVE(fm_coarse_workspace_bytes_mode);
   RESOLVE(fm_coarse_match); RESOLVE(fm_coarse_match_dtype); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
-  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_fine_match_maps); RESOLVE(fm_fine_match_maps_dtype); RESOLVE(fm_coarse_softmax_offsets); RESOLVE(fm_dual_softmax_conf_at); RESOLVE(fm_dual_softmax_backward); RESOLVE(fm_dual_softmax_backward_workspace_bytes); RESOLVE(fm_fine_maps_scratch_bytes_dtype); RESOLVE(fm_fine_maps_scratch_bytes); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
+  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_fine_match_maps); RESOLVE(fm_fine_match_maps_dtype); RESOLVE(fm_coarse_softmax_stats); RESOLVE(fm_dual_softmax_conf_at); RESOLVE(fm_dual_softmax_backward); RESOLVE(fm_dual_softmax_backward_workspace_bytes); RESOLVE(fm_fine_maps_scratch_bytes_dtype); RESOLVE(fm_fine_maps_scratch_bytes); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
@@ -204,18 +204,18 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_fine_match_maps(f, f, 2, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
   /* training surface: argument checks of the dual-softmax entries */
   {
-    const float* pr = NULL; const float* pc = NULL; int qr = 0, qc = 0;
-    EXPECT(p_fm_coarse_softmax_offsets(NULL, 1, 64, 64, 64, 8, &pr, &qr, &pc, &qc), FM_E_NULL);
-    EXPECT(p_fm_coarse_softmax_offsets((void*)f, 1, 64, 64, 64, 8, &pr, &qr, &pc, &qc), FM_OK);
+    const float* pr = NULL; const float* pc = NULL; const float* sr = NULL; const float* sc = NULL; int qr = 0, qc = 0;
+    EXPECT(p_fm_coarse_softmax_stats(NULL, 1, 64, 64, 64, 8, &pr, &sr, &qr, &pc, &sc, &qc), FM_E_NULL);
+    EXPECT(p_fm_coarse_softmax_stats((void*)f, 1, 64, 64, 64, 8, &pr, &sr, &qr, &pc, &sc, &qc), FM_OK);
     EXPECT(qr, 256); EXPECT(qc, 64);
-    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 64, 0.1f, f, 256, f, 64, ids, ids, ids, 0, NULL, NULL), FM_OK);      /* K == 0 */
-    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 64, 0.1f, f, 32, f, 64, ids, ids, ids, 4, f, NULL), FM_E_SHAPE);     /* pitch < L */
-    EXPECT(p_fm_dual_softmax_conf_at(f, NULL, 1, 64, 64, 64, 0.1f, f, 256, f, 64, ids, ids, ids, 4, f, NULL), FM_E_NULL);
-    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 66, 0.1f, f, 256, f, 64, ids, ids, ids, 4, f, NULL), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, ids, ids, ids, 0, NULL, NULL), FM_OK);      /* K == 0 */
+    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 64, 0.1f, f, f, 32, f, f, 64, ids, ids, ids, 4, f, NULL), FM_E_SHAPE);     /* pitch < L */
+    EXPECT(p_fm_dual_softmax_conf_at(f, NULL, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, ids, ids, ids, 4, f, NULL), FM_E_NULL);
+    EXPECT(p_fm_dual_softmax_conf_at(f, f, 1, 64, 64, 66, 0.1f, f, f, 256, f, f, 64, ids, ids, ids, 4, f, NULL), FM_E_UNSUPPORTED);
     EXPECT((int)p_fm_dual_softmax_backward_workspace_bytes(1, 64, 64, 64), 512 + 4 * 64 * 64 * 4);
     EXPECT((int)p_fm_dual_softmax_backward_workspace_bytes(0, 64, 64, 64), 0);
-    EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, 256, f, 64, ids, ids, ids, f, 4, (void*)f, 16, f, f, NULL), FM_E_WORKSPACE);
-    EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, 256, f, 64, NULL, ids, ids, f, 4, (void*)f, 1u << 30, f, f, NULL), FM_E_NULL);
+    EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, ids, ids, ids, f, 4, (void*)f, 16, f, f, NULL), FM_E_WORKSPACE);
+    EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, NULL, ids, ids, f, 4, (void*)f, 1u << 30, f, f, NULL), FM_E_NULL);
   }
   /* element type of the maps: an unknown one is refused, half-precision NCHW maps need scratch for both copies */
   EXPECT(p_fm_fine_match_maps_dtype(f, f, 7, 1, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);

@@ -825,10 +825,13 @@ def test_dual_softmax_at_supervised_entries_and_its_backward_without_an_LxS_arra
     torch.cuda.synchronize()
     peak = torch.cuda.max_memory_allocated() - base
     assert peak < 0.75 * l * l * 4, f"peak {peak / 1e6:.1f} MB: an L x S float32 array is {l * l * 4 / 1e6:.1f} MB"
-    assert (conf.detach().double() - conf64).abs().max().item() <= 1e-5
+    # (against float64: the float32 reference's own sums are up to ~5e-6 away at S = 4800, tools/diag_conf_f64.py)
+    assert (conf.detach().double() - conf64).abs().max().item() <= 1.5e-5
     for got, ref in ((a0.grad, ref0), (a1.grad, ref1)):
         scale = ref.abs().max().item()
-        assert scale > 0 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
+        # ('peaky': every supervised conf is beyond the loss's clamp at 1e-6 / 1 - 1e-6 - the gradient is exactly zero)
+        assert (scale > 0) == (dist == "borderline")
+        assert (got.double() - ref).abs().max().item() <= 2e-4 * scale
 
 
 def test_dense_conf_matrix_entries_that_matter_take_the_exact_route():
