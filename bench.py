@@ -875,12 +875,15 @@ def main():
         "roofline_aux": ({
             "fine_from_maps": {"bound": "hbm",
                                "kernel": ("k_nchw_to_nhwc64 (image 1) + " if a.layout == "nchw" else "") + f"k_fine_maps<{a.window}> (window crop + fine stage, no window tensors)",
-                               # SURVEY 8(d) fine-kernel bytes (the window bytes, read once) + for NCHW maps the read + write of
-                               # image 1's channels-last copy (= the bytes of both maps)
-                               "algorithmic_bytes": fine_bytes + (map_bytes if a.layout == "nchw" else 0.0),
-                               "achieved": round((fine_bytes + (map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9, 1),
+                               # SURVEY 8(d) fine-kernel bytes ONLY: the window bytes of both images read once + 12 bytes
+                               # written per keypoint.  What the NCHW route moves beyond that (the channels-last copy of
+                               # image 1: read + write of one map) is overhead, reported beside it, not work.
+                               "algorithmic_bytes": fine_bytes,
+                               "achieved": round(fine_bytes / (tk["fine"] * 1e-3) / 1e9, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round((fine_bytes + (map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "frac": round(fine_bytes / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "bytes_moved_by_design": fine_bytes + (map_bytes if a.layout == "nchw" else 0.0),
+                               "frac_of_bytes_moved": round((fine_bytes + (map_bytes if a.layout == "nchw" else 0.0)) / (tk["fine"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "avg_ms": round(tk["fine"], 5)}} if maps_path else {
             "window_crop": {"bound": "hbm", "kernel": "k_gather_cellorder64 (both images, one launch)" if a.layout == "nchw"
                                                       else f"2 x k_gather_nhwc64<{a.window}> (channels-last maps: 16-byte-chunk copy)",

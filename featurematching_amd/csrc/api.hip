@@ -33,7 +33,10 @@ static int choose_splits_sparse(int N, int panels, int nunits, int* units_per_sp
   if (const char* e = getenv("FM_TARGET_WGS_S")) target = atoi(e) > 0 ? atoi(e) : 512;
 #endif
   int s = target / (N * panels > 0 ? N * panels : 1);
-  const int smin = (nunits + kScreenUnits - 1) / kScreenUnits;
+  // (a batch that fills the chip by itself: ranges of <= 8 units keep a workgroup's LDS under 80 KB - two per CU, the
+  // only latency hiding this kernel has; 64 x 640x480: 593 -> 527 us)
+  const int ucap = N * panels >= 256 ? 8 : kScreenUnits;
+  const int smin = (nunits + ucap - 1) / ucap;
   if (s < smin) s = smin;
   if (s > nunits) s = nunits;
   if (s < 1) s = 1;
@@ -243,7 +246,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
     if (e != hipSuccess) return (int)e;
     // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
     // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
-    e = launch_corr(1, w, base, inv_ct, thr, st);
+    e = launch_dense(w, base, inv_ct, thr, st);
     if (e != hipSuccess) return (int)e;
   }
   // The assignment folds the softmax denominators of its candidates from the partial sums itself.  The
@@ -312,6 +315,7 @@ extern "C" int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C,
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0) return (int)launch_max_i8(w, (char*)workspace, st);
+  if (mode == 1) return (int)launch_dense(w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st);
   return (int)launch_corr(mode, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st);
 }
 

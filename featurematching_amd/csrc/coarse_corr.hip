@@ -707,7 +707,7 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
 #define FM_CORR_CASE(CC)                                                     \
   case CC: return mode == 3 ? launch_corr_t<CC, 3>(a, blocks, st)            \
                  : mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)          \
-                 : (mode ? launch_corr_t<CC, 1>(a, blocks, st) : hipErrorInvalidValue);
+                 : hipErrorInvalidValue;       /* mode 1 (the dense sum sweep) is k_dense, coarse_dense.hip */
   switch (w.C) {
     FM_CORR_CASE(64)
     FM_CORR_CASE(128)

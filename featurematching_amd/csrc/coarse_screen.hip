@@ -301,10 +301,12 @@ __global__ __launch_bounds__(512) void k_screen(ScreenArgs a) {
       tot += __builtin_popcount(masks[k]);
     }
   }
-  // more than half of a block of >= 64 units is alive: flat similarity, a matrix-core job (a small block - a tiny
-  // image, a one-unit split - is cheap to sweep whatever is alive, and truly flat units still overflow kMaxExact below)
-  const bool flat = (tot * 2 > 8 * U && 8 * U >= 64) || !screen_ok;
-  int nd_units = flat ? __builtin_popcount(masks[wv]) : 0;       // units this wave leaves to the dense kernel
+  // more than half of the block's units are alive (and more than a handful): flat similarity, a matrix-core job (a
+  // tiny block - a tiny image - is cheap to sweep whatever is alive, and truly flat units still overflow kMaxExact below)
+  const bool flat = (tot * 2 > 8 * U && tot >= 12) || !screen_ok;
+  // units left to the dense kernel: a flat block is reported ONCE, by wave 0 (every wave reporting its own share was
+  // 3800 atomics on two addresses per 640x480 pair: 40 us of a 57 us launch on flat data); otherwise per wave, rarely
+  int nd_units = (flat && wv == 0) ? tot : 0;
 
   int nlist = 0;                 // parked significant entries (wave-uniform)
   DIAG_STAMP(2)

@@ -96,6 +96,7 @@ hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, i
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st);
 hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st,
                        float* conf = nullptr);
+hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st);
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);
 hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,
                          float scale_px, const float* scale0, const float* scale1,

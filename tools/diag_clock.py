@@ -41,13 +41,16 @@ def main():
     off = (-ws.data_ptr()) % 256
     ptr = C.c_void_p(ws.data_ptr() + off)
     lay = layout(p.n, p.l, p.l, p.c, slots)
-    names = ["cycles", "ticks100MHz", "units", "mfma_cyc", "epilogue_cyc", "barrier_cyc", "prologue_cyc", "tail_cyc"]
-    for mode in (1, 0):
+    names = ["cycles", "ticks100MHz", "units", "chain_cyc", "-", "barrier_cyc", "prologue_cyc", "tail_cyc"]
+    for mode in (1,):
         for rep in range(20):          # warm: the clock ramps with load
             lib.fm_debug_reset_counters(ptr, p.n, p.l, p.l, p.c, slots, st)
+            # (the screening kernel flags the samples the dense kernel redoes)
+            lib.fm_debug_launch_sum_sparse(ptr, C.c_void_p(p.f0.data_ptr()), C.c_void_p(p.f1.data_ptr()), p.n, p.l, p.l, p.c,
+                                           slots, 0.1, 0.2, st)
             v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, mode, st)
         torch.cuda.synchronize()
-        o = off + lay["cand_conf"] + p.l * slots * 4          # candidate slots of the first padded row
+        o = off + lay["cand_x"] + p.l * slots * 4             # candidate slots of the first padded row
         d = ws[o: o + 512 * 4].view(torch.float32).cpu().numpy().reshape(64, 8)     # [panel*8 + wave, stamp]
         print(f"mode {mode}: {d.shape[0]} waves of split 0 ({lay['splits']} splits, "
               f"{-(-lay['tiles'] // lay['splits'])} tiles each); clock {np.median(d[:, 0]) / np.median(d[:, 1]) * 0.1:.2f} GHz")
