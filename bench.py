@@ -273,24 +273,28 @@ def kernel_source_sha():
 
 
 def committed_traffic(workload):
-    """Fabric/HBM bytes per launch of the correlation kernels from the committed rocprofv3 PMC passes of this round
-    (profiles/r03_pmc_fetch_write_cfg2.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py --streams 1
+    """Fabric/HBM bytes per launch of the correlation kernels from the committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_fetch_write_cfg2.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py --streams 1
     --pairs 1 --no-graph`), with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of the bytes of
     wide reads; both counters in KiB).  Counters collected by an earlier run, not by this one - hence the file name
-    next to them; None when the file is missing, belongs to another workload or was collected with other kernel
-    sources than the ones in this tree (its `kernel_src_sha16` differs)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_fetch_write_cfg2.json")
-    if workload != "cfg2" or not os.path.exists(path):
+    next to them.  The newest round's file whose `kernel_src_sha16` equals the sources in this tree is used (the
+    counters then belong to these kernels); None when there is none or the workload is another one."""
+    import glob
+    if workload != "cfg2":
         return None, None
-    with open(path) as f:
-        d = json.load(f)
-    if d.get("kernel_src_sha16") != kernel_source_sha():
-        return None, None
-    tot = 0.0
-    for name, c in d.get("kernels", {}).items():
-        if ("k_max_i8" in name or "k_screen" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
-    return (int(tot) if tot else None), "profiles/r03_pmc_fetch_write_cfg2.json"
+    sha = kernel_source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_cfg2.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel_src_sha16") != sha:
+            continue
+        tot = 0.0
+        for name, c in d.get("kernels", {}).items():
+            if ("k_max_i8" in name or "k_screen" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        if tot:
+            return int(tot), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def verify(pair, nverify=2):
