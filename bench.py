@@ -105,6 +105,10 @@ class Pair:
         # ... and in 'mixed' data those peakless rows sit next to peaked ones: more candidates than slots until the exact
         # screening pass (FM_MODE_EXACT_SCREENING) has the denominators
         self.exact = dist == "mixed"
+        # ... and the caller that knows ALL its samples are like that (what FM_DEV_ALL_DENSE tells ops.coarse_match's mode
+        # memory after the first call) passes the FM_MODE_FLAT hint: no screening sweep, planes from the prep kernel
+        self.flat = dist != "peaky"
+        self.slots = None                # candidate slots per row / column (None: fm_default_cand_slots(thr))
         self.conf_matrix = False         # materialise data['conf_matrix'] (cfg#3's HBM-bound mode)
         self.stages = "all"      # diagnostic only (--stages): "coarse" or "fine" time a part of the step
 
@@ -116,8 +120,8 @@ class Pair:
             buf = self.last[0]
         else:
             buf = ops.coarse_match_async(self.f0, self.f1, self.hw_c, self.hw_c, self.hw_i[0] / self.hw_c[0],
-                                         cap=self.cap, dense=self.dense, exact_screening=self.exact,
-                                         conf_matrix=self.conf_matrix,
+                                         cap=self.cap, cand_slots=self.slots, dense=self.dense, exact_screening=self.exact,
+                                         conf_matrix=self.conf_matrix, flat=(self.flat and self.dense and not self.conf_matrix),
                                          cell_maps=(self.fine_path == "windows" and self.layout == "nchw"))
         if self.stages == "coarse" and self.last is not None:
             self.last = (buf,) + self.last[1:]
@@ -192,7 +196,7 @@ def time_kernels(pair):
     buf = pair.last[0]
     ws = buf.workspace
     ptr = C.c_void_p(ws.data_ptr() + ((-ws.data_ptr()) % 256))
-    slots = lib.fm_default_cand_slots(0.2)
+    slots = pair.slots or lib.fm_default_cand_slots(0.2)
     f0, f1 = C.c_void_p(pair.f0.data_ptr()), C.c_void_p(pair.f1.data_ptr())
     shape = (pair.n, pair.l, pair.l, pair.c, slots)
 
@@ -208,9 +212,23 @@ def time_kernels(pair):
     t = {}
     t["max"] = _events(lambda: _lib.check(lib.fm_debug_launch_corr(ptr, *shape, 0.1, 0.2, 0, st()), "max"))
     # (4 launches per reset: a row's 8 candidate slots take the one candidate each launch adds on 'peaky' data)
-    t["sparse"] = _events(sparse, before=reset, group=4 if pair.dist == "peaky" else 1, iters=10 if pair.dist == "peaky" else 20)
+    flat = pair.dense and pair.flat and not pair.conf_matrix
     t["planes"] = t["dense"] = 0.0
-    if pair.dense:
+    if flat:
+        # FM_MODE_FLAT: no screening sweep and no plane kernel - the stabiliser kernel k_stab takes the sweep's place, the
+        # planes come out of k_prep_split (timed as "prep" below); the dense sum kernel redoes every sample
+        def stab():
+            _lib.check(lib.fm_debug_launch_flat(ptr, f0, f1, *shape, 0.1, 0.2, 1, st()), "stab")
+
+        def reflag():          # (the counters the dense kernel appends to are cleared, k_stab flags the samples again)
+            reset()
+            stab()
+        t["sparse"] = _events(stab)
+        t["dense"] = _events(lambda: _lib.check(lib.fm_debug_launch_corr(ptr, *shape, 0.1, 0.2, 1, st()), "dense"),
+                             before=reflag, group=1, iters=20)
+    else:
+        t["sparse"] = _events(sparse, before=reset, group=4 if pair.dist == "peaky" else 1, iters=10 if pair.dist == "peaky" else 20)
+    if pair.dense and not flat:
         # the dense sum kernel redoes the samples the sparse one flagged; the untimed part of every iteration clears
         # the counters and lets the sparse kernel flag again
         def reflag():
@@ -221,7 +239,10 @@ def time_kernels(pair):
         # every launch redoes the flagged samples and adds their candidates: one launch per reflag
         t["dense"] = _events(lambda: _lib.check(lib.fm_debug_launch_corr(ptr, *shape, 0.1, 0.2, 1, st()), "dense"),
                              before=reflag, group=1, iters=20)
-    t["prep"] = _events(lambda: _lib.check(lib.fm_debug_launch_prep(ptr, f0, f1, *shape, st()), "prep"))
+    if flat:
+        t["prep"] = _events(lambda: _lib.check(lib.fm_debug_launch_flat(ptr, f0, f1, *shape, 0.1, 0.2, 0, st()), "prep+planes"))
+    else:
+        t["prep"] = _events(lambda: _lib.check(lib.fm_debug_launch_prep(ptr, f0, f1, *shape, st()), "prep"))
     # the whole coarse stage, as the step enqueues it
     keep = pair.stages
     pair.stages = "coarse"
@@ -395,7 +416,8 @@ def cpu_baseline(wl, window, seed, budget_s=18.0):
                       f"the same pair"}
 
 
-def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, check=True, layout="nchw", fine_path="maps"):
+def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, check=True, layout="nchw", fine_path="maps",
+                flat_hint=True, slots=None, exact=None):
     """Pairs/s of the same step for another workload / distribution / pairs per launch: `nsets` resident input sets
     (generated on the device) cycled through on `nstreams` streams by hipGraph replay, `steps` timed steps.  Returns
     (pairs/s, verification of the first input set's last step against the oracle, matches per pair)."""
@@ -404,6 +426,10 @@ def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, chec
     for p in range(nsets):
         pairs.append(Pair(wb, 5000 + 31 * p, window, dev, dist, share=pairs[p % nstreams] if p >= nstreams else None,
                           device_data=True, layout=layout, fine_path=fine_path))
+        pairs[-1].flat = pairs[-1].flat and flat_hint
+        pairs[-1].slots = slots
+        if exact is not None:
+            pairs[-1].exact = exact
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     for i, p in enumerate(pairs):
         with torch.cuda.stream(streams[i % nstreams]):
@@ -425,7 +451,7 @@ def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, chec
     # the headline's own timed region), then the median of three timed regions of `steps` steps
     tw = time.perf_counter()
     i = 0
-    while i < 2 * nsets or time.perf_counter() - tw < 0.15:
+    while i < 2 * nsets or time.perf_counter() - tw < 0.4:
         run(i)
         i += 1
         if i % 64 == 0:
@@ -835,7 +861,7 @@ def main():
     traffic, traffic_src = committed_traffic(a.workload)
     copy_gbs = copy_rate(crop_bytes, dev)
     maps_path = pairs[0].fine_path == "maps"
-    launches = 4 + (2 if pairs[0].dense else 0) + ((2 if a.layout == "nchw" else 1) if maps_path else (3 if a.layout == "nhwc" else 2))
+    launches = 4 + (2 if pairs[0].dense and not pairs[0].flat else 0) + ((2 if a.layout == "nchw" else 1) if maps_path else (3 if a.layout == "nhwc" else 2))
     map_bytes = 2.0 * wl["n"] * cf * 4 * sh0["hf"] * sh0["wf"]           # both fine maps
     out = {
         "metric": ("image-pairs/sec at 640x480 (coarse corr + dual-softmax mutual-NN + fine window refinement)"
@@ -867,7 +893,7 @@ def main():
         # matrix-core type the dominant kernel runs on.
         "roofline": {"bound": "mfma",
                      "kernel": "coarse correlation: k_max_i8<256> + k_screen<256>"
-                               + (" + k_prep_f16 + k_corr<256,1>" if pairs[0].dense else "")
+                               + (" + k_prep_f16 + k_dense<256>" if pairs[0].dense else "")
                                + " (every launch on the L x S product; v_mfma_i32_32x32x32_i8)",
                      "achieved": round(ach, 2), "peak": PEAK_I8_DENSE_TOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_I8_DENSE_TOPS, 4),
@@ -957,8 +983,12 @@ def extras(a, wl, dev, streams, flops):
         tcb = tb["max"] + tb["sparse"] + tb["planes"] + tb["dense"]
         del p
         rate, ver, m_pp = stream_rate(wl, a.window, dev, dist, 1, 4, steps=400, nsets=8)
-        return {"value": round(rate, 2), "unit": "image-pairs/s", "verified": ver["ok"] if ver else None,
+        rate_nohint, ver2, _ = stream_rate(wl, a.window, dev, dist, 1, 4, steps=400, nsets=8, flat_hint=False)
+        return {"value": round(rate, 2), "unit": "image-pairs/s", "verified": (ver["ok"] and ver2["ok"]) if ver and ver2 else None,
                 "verification": ver, "matches_per_pair": round(m_pp, 1),
+                "mode": "FM_MODE_DENSE | FM_MODE_FLAT (the hint a caller - or ops.coarse_match's mode memory after its first "
+                        "call, from FM_DEV_ALL_DENSE - passes for data like this: no screening sweep, planes from the prep kernel)",
+                "value_without_flat_hint": round(rate_nohint, 2),
                 "corr_avg_ms": round(tcb, 5), "frac": round(flops / (tcb * 1e-3) / 1e12 / PEAK_I8_DENSE_TOPS, 4),
                 "frac_of_f16_peak": round(flops / (tcb * 1e-3) / 1e12 / PEAK_F16_DENSE_TFLOPS, 4),
                 "max_pass_avg_ms": round(tb["max"], 5), "sparse_sum_avg_ms": round(tb["sparse"], 5),

@@ -21,7 +21,9 @@ FM_E_DENSE = -8
 FM_E_INTERNAL = -9
 FM_E_STEP = -10
 FM_DEV_RANGE = 4                                    # device status bit
+FM_DEV_ALL_DENSE = 256                              # informational device status bit (fm_read_count_info)
 FM_MODE_EXACT_SCREENING, FM_MODE_DENSE, FM_MODE_NO_CELL_MAPS, FM_MODE_EXACT_STEP, FM_MODE_STATS = 1, 2, 4, 8, 16   # `mode` bits
+FM_MODE_FLAT = 32
 
 _lib = None
 
@@ -47,6 +49,8 @@ SIGNATURES = {
     "fm_debug_launch_prep_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "fm_read_count": (_i, [_p, _i, C.POINTER(C.c_int32), _p]),
+    "fm_read_count_info": (_i, [_p, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p]),
+    "fm_debug_launch_flat": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "fm_coarse_softmax_stats": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_p),
                                      C.POINTER(_p), C.POINTER(_i)]),
     "fm_dual_softmax_conf_at": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p]),

@@ -144,8 +144,11 @@ extern "C" int fm_default_cand_slots(float thr) {
 // a power of two in [4, 64]: a row's slots are adjacent lanes of one wave and k_keep_emit keeps 256/slots <= 64 rows
 static bool valid_slots(int s) { return s >= 4 && s <= 64 && (s & (s - 1)) == 0; }
 
+constexpr int kKnownModes = FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP | FM_MODE_STATS |
+                            FM_MODE_FLAT;
+
 static bool needs_dense_region(int mode, bool want_conf) {
-  return want_conf || (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_STATS)) != 0;
+  return want_conf || (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_STATS | FM_MODE_FLAT)) != 0;
 }
 
 extern "C" int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int cand_slots, int mode, int want_conf_matrix,
@@ -153,7 +156,7 @@ extern "C" int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int ca
   if (!bytes) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP | FM_MODE_STATS)) return FM_E_UNSUPPORTED;
+  if (mode & ~kKnownModes) return FM_E_UNSUPPORTED;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   *bytes = needs_dense_region(mode, want_conf_matrix != 0) ? w.total : w.common_total;
   return FM_OK;
@@ -216,7 +219,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   if (N <= 0 || L <= 0 || S <= 0 || cap < 0 || L != h0c * w0c || S != h1c * w1c) return FM_E_SHAPE;
   if (!valid_channels(C) || !valid_slots(cand_slots)) return FM_E_UNSUPPORTED;
   if (!(thr > 0.f) || !(thr < 1.f) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
-  if (mode & ~(FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP | FM_MODE_STATS)) return FM_E_UNSUPPORTED;
+  if (mode & ~kKnownModes) return FM_E_UNSUPPORTED;
   const bool exact = (mode & FM_MODE_EXACT_SCREENING) != 0;
   const bool dense = needs_dense_region(mode, conf_matrix != nullptr);      // exact screening and conf_matrix read the planes too
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
@@ -228,7 +231,11 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   // The common path is four launches: prep -> max pass -> sparse sum kernel -> assignment.
   // one dispatch: clear the per-call counters, quantise both images (one int8 step per image), L1 norms
   // (FM_MODE_EXACT_STEP: the images' largest |x| first - a memset node and one small kernel - and the int8 step from them)
-  hipError_t e = launch_prep(feat0, feat1, in_dtype, C, w, base, (mode & FM_MODE_EXACT_STEP) ? 1 : 0, st);
+  // (FM_MODE_FLAT: the float16 planes of every sample too - the dense sum kernel will want them all)
+  // (a hint: not taken when the dense conf_matrix / the softmax statistics are wanted - their exact rewrite reads the
+  // screening kernel's lists)
+  const bool flat = (mode & FM_MODE_FLAT) != 0 && !conf_matrix && !(mode & FM_MODE_STATS);
+  hipError_t e = launch_prep(feat0, feat1, in_dtype, C, w, base, (mode & FM_MODE_EXACT_STEP) ? 1 : 0, flat ? 1 : 0, st);
   if (e != hipSuccess) return (int)e;
   // max pass: row / column / unit maxima of the integer screening product (atomicMax: no partials, no reduction kernel)
   e = launch_max_i8(w, base, st);
@@ -237,13 +244,18 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
   // and per column); flags the samples with too many significant entries per unit (flat similarity)
   // (dead-row certificates only when nobody reads every row's denominator: the dense conf_matrix does)
   const bool stats = (mode & FM_MODE_STATS) != 0;      // the softmax statistics of EVERY row and column are wanted
-  e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, (conf_matrix || stats) ? 0 : 1, st);
+  // (FM_MODE_FLAT: the caller expects flat similarity everywhere - the sweep would only find that out again; a small
+  // kernel forms the stabilisers and flags every sample for the dense sum kernel)
+  if (flat) e = launch_stab(w, base, inv_ct, thr, (conf_matrix || stats) ? 0 : 1, st);
+  else e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, (conf_matrix || stats) ? 0 : 1, st);
   if (e != hipSuccess) return (int)e;
-  if (dense) {
+  if (dense && !flat) {
     // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or
     // the conf_matrix sweep will run); exits at once otherwise
     e = launch_prep_f16(feat0, feat1, in_dtype, C, w, base, (exact || conf_matrix) ? 1 : 0, st);
     if (e != hipSuccess) return (int)e;
+  }
+  if (dense) {
     // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
     // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
     e = launch_dense(w, base, inv_ct, thr, st);
@@ -338,7 +350,7 @@ extern "C" int fm_debug_launch_prep(void* workspace, const float* feat0, const f
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  return (int)launch_prep(feat0, feat1, FM_F32, C, w, (char*)workspace, 0, (hipStream_t)stream);
+  return (int)launch_prep(feat0, feat1, FM_F32, C, w, (char*)workspace, 0, 0, (hipStream_t)stream);
 }
 
 // Diagnostic: launch the float16 plane kernel alone (force = 1: every sample; 0: the samples flagged for the dense
@@ -350,6 +362,19 @@ extern "C" int fm_debug_launch_prep_f16(void* workspace, const float* feat0, con
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
   return (int)launch_prep_f16(feat0, feat1, FM_F32, C, w, (char*)workspace, force, (hipStream_t)stream);
+}
+
+// Diagnostic: the two launches FM_MODE_FLAT has of its own (which = 0: k_prep_split writing the float16 planes too,
+// 1: k_stab) on a workspace a previous FM_MODE_FLAT call filled.
+extern "C" int fm_debug_launch_flat(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
+                                    int cand_slots, float temperature, float thr, int which, void* stream) {
+  if (!workspace || !feat0 || !feat1) return FM_E_NULL;
+  const int bad = check_coarse_shape(N, L, S, C, cand_slots);
+  if (bad) return bad;
+  if (which < 0 || which > 1) return FM_E_UNSUPPORTED;
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  if (which == 0) return (int)launch_prep(feat0, feat1, FM_F32, C, w, (char*)workspace, 0, 1, (hipStream_t)stream);
+  return (int)launch_stab(w, (char*)workspace, 1.0f / ((float)C * temperature), thr, 1, (hipStream_t)stream);
 }
 
 // Diagnostic: zero the candidate counters and the scalars, so that the sum kernels can be launched again on a
@@ -365,6 +390,10 @@ extern "C" int fm_debug_reset_counters(void* workspace, int N, int L, int S, int
 }
 
 extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, void* stream) {
+  return fm_read_count_info(d_count, cap, m_out, nullptr, stream);
+}
+
+extern "C" int fm_read_count_info(const int32_t* d_count, int cap, int32_t* m_out, int32_t* info_out, void* stream) {
   if (!d_count || !m_out) return FM_E_NULL;
   int32_t h[2] = {0, 0};
   hipStream_t st = (hipStream_t)stream;
@@ -373,6 +402,7 @@ extern "C" int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, vo
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return (int)e;
   *m_out = h[0];
+  if (info_out) *info_out = h[1];
   if (h[1] & FM_DEV_INTERNAL) return FM_E_INTERNAL;
   if (h[1] & FM_DEV_RANGE) return FM_E_RANGE;
   if (h[1] & FM_DEV_STEP) return FM_E_STEP;

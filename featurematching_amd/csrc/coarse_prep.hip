@@ -58,7 +58,14 @@ __device__ __forceinline__ bool bad_value(float4 v) {   // NaN fails the compari
 //     (((row/32 * KSTEPS + ks) * 2 + h) * 32 + row%32) * 8 + k%8   with chunk q = k/8 = h*KSTEPS + ks.
 // A workgroup that sees a non-finite / out-of-range value reports +inf as its block L1 maximum; k_sum_sparse
 // turns that into FM_DEV_RANGE (the flag word itself is cleared by this kernel, so it cannot be set here).
-template <int C>
+// PLANES (FM_MODE_FLAT: the caller expects flat similarity, every sample goes to the dense sum kernel): the float16
+// hi / lo planes are written here as well, from the values this kernel holds anyway - k_prep_f16's launch and its
+// second pass over the descriptors are gone.  Their power-of-two scale must not wait for the image's true maximum (a
+// grid-wide reduction): it is derived from the image's int8 step, 127 sigma = kPrepHeadroom * (largest |x| of the
+// sampled rows) -> [2^13, 2^14), which every workgroup - and every later kernel, from sigimg - arrives at alike.  An
+// element more than ~4x beyond the sample's maximum would leave float16's range: k_stab compares the image's true
+// maximum (block statistics) with the scale and reports FM_DEV_STEP, the call is repeated with the exact step.
+template <int C, bool PLANES>
 __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   constexpr int KS8 = C / 32;
   const int tid = threadIdx.x;
@@ -164,6 +171,9 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   const float inv_sigma = sigma > 0.f ? 1.0f / sigma : 0.f;
   const float clip_at = 127.f * sigma;
   if (tid == 0 && rb * 32 == (long)b * rows_pad) a.sigimg[b * 2 + (img1 ? 1 : 0)] = sigma;
+  const float sc16 = PLANES ? f16_plane_scale(clip_at) : 1.0f;
+  _Float16* const hi = img1 ? a.hi1 : a.hi0;
+  _Float16* const lo = img1 ? a.lo1 : a.lo0;
 
   float s1 = 0.f, amax = 0.f, clip = 0.f;
   bool bad = false;
@@ -216,6 +226,27 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
     const int h = q16 / KS8, ks = q16 - h * KS8;
     const long off = (((rb * KS8 + ks) * 2 + h) * 32 + r) * 16;
     *reinterpret_cast<int4*>(qp + off) = make_int4(wq[0], wq[1], wq[2], wq[3]);
+    if (PLANES) {      // the two 8-channel chunks of this 16-channel chunk, in k_prep_f16's layout and arithmetic
+      constexpr int KSTEPS = C / 16;
+      typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int c8 = 0; c8 < 2; ++c8) {
+        const float x[8] = {v[2 * c8].x, v[2 * c8].y, v[2 * c8].z, v[2 * c8].w,
+                            v[2 * c8 + 1].x, v[2 * c8 + 1].y, v[2 * c8 + 1].z, v[2 * c8 + 1].w};
+        half8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xs = x[e] * sc16;
+          hh[e] = (_Float16)xs;
+          ll[e] = (_Float16)(xs - (float)hh[e]);
+        }
+        const int q8 = 2 * q16 + c8;
+        const int h2 = q8 / KSTEPS, ks2 = q8 - h2 * KSTEPS;
+        const long off2 = (((rb * KSTEPS + ks2) * 2 + h2) * 32 + r) * 8;
+        *reinterpret_cast<half8*>(hi + off2) = hh;
+        *reinterpret_cast<half8*>(lo + off2) = ll;
+      }
+    }
   }
   PREP_STAMP(3)
   // per-row L1 norm and clipped mass (a row's channels sit in 8 threads); block maxima
@@ -305,13 +336,7 @@ __global__ __launch_bounds__(256) void k_prep_f16(PrepArgs a) {
   __syncthreads();
   m0 = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3]));
   m1 = fmaxf(fmaxf(wred[1][0], wred[1][1]), fmaxf(wred[1][2], wred[1][3]));
-  auto pow2_scale = [](float amax) {        // 2^k with amax * 2^k in [2^13, 2^14); 1 for an all-zero (or bad) image
-    if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
-    int e;
-    frexpf(amax, &e);                       // amax = f * 2^e, f in [0.5, 1)
-    return ldexpf(1.0f, 14 - e);
-  };
-  const float sc0 = pow2_scale(m0), sc1 = pow2_scale(m1);
+  const float sc0 = f16_plane_scale(m0), sc1 = f16_plane_scale(m1);
   const float sc = img1 ? sc1 : sc0;
   if (!img1 && rb * 32 == (long)b * rows_pad && tid == 0) a.f16inv[b] = (1.0f / sc0) * (1.0f / sc1);
   _Float16* const hi = img1 ? a.hi1 : a.hi0;
@@ -388,7 +413,7 @@ hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, i
 }
 
 hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                       int exact_step, hipStream_t st) {
+                       int exact_step, int planes, hipStream_t st) {
   PrepArgs a;
   fill_prep_args(a, feat0, feat1, in_dtype, c_in, w, base);
   const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / 32);
@@ -398,12 +423,18 @@ hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_prep_amax, dim3(blocks), dim3(256), 0, st, a);
   }
+#define FM_PREP_CASE(CC)                                                                                  \
+  case CC:                                                                                                \
+    if (planes) hipLaunchKernelGGL((k_prep_split<CC, true>), dim3(blocks), dim3(256), 0, st, a);          \
+    else hipLaunchKernelGGL((k_prep_split<CC, false>), dim3(blocks), dim3(256), 0, st, a);                \
+    break;
   switch (w.C) {
-    case 64: hipLaunchKernelGGL(k_prep_split<64>, dim3(blocks), dim3(256), 0, st, a); break;
-    case 128: hipLaunchKernelGGL(k_prep_split<128>, dim3(blocks), dim3(256), 0, st, a); break;
-    case 256: hipLaunchKernelGGL(k_prep_split<256>, dim3(blocks), dim3(256), 0, st, a); break;
+    FM_PREP_CASE(64)
+    FM_PREP_CASE(128)
+    FM_PREP_CASE(256)
     default: return hipErrorInvalidValue;
   }
+#undef FM_PREP_CASE
   return hipGetLastError();
 }
 

@@ -269,6 +269,13 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
       if (lane >= d) incl += o;
     }
     if (threadIdx.x < rows_per_block) rowoff[threadIdx.x] = pre + incl - cntq;
+    // informational: did every sample go to the dense sum kernel?  (the caller's cue for FM_MODE_FLAT; last block only)
+    bool all_dense = false;
+    if (blk == a.nblk - 1 && a.dense_enabled) {
+      bool mine = true;
+      for (int bb = threadIdx.x; bb < a.N; bb += 64) mine = mine && a.dense_cnt[bb] > 0;
+      all_dense = __all(mine);
+    }
     if (blk == a.nblk - 1 && threadIdx.x == 63) {
       const int run = pre + incl;
       a.d_count[0] = run;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
       if (!a.exact && (fl & (unsigned)FM_INT_SCREEN_OVERFLOW)) fl |= (unsigned)FM_DEV_CANDIDATES;
       if (fl & (unsigned)FM_INT_LOOKBACK_TIMEOUT) fl |= (unsigned)FM_DEV_INTERNAL;
       a.d_count[1] = (int)((fl & (15u | (unsigned)FM_DEV_INTERNAL | (unsigned)FM_DEV_STEP) & ~(unsigned)FM_DEV_CAPACITY) |
-                           (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u));
+                           (run > a.cap ? (unsigned)FM_DEV_CAPACITY : 0u) | (all_dense ? (unsigned)FM_DEV_ALL_DENSE : 0u));
     }
   }
   __syncthreads();

@@ -26,6 +26,16 @@ __device__ __forceinline__ float4 half4_to_float4(uint2 p, int dtype) {
                      half_bits_to_float(p.y & 0xffffu, dtype), half_bits_to_float(p.y >> 16, dtype));
 }
 
+// Exact power-of-two scale of an image's float16 hi / lo planes: 2^k with amax * 2^k in [2^13, 2^14) (1 for an all-zero
+// or bad image).  The matrix cores flush float16 SUBNORMAL inputs, so without it the lo half of every value below
+// 2^-3 - |lo| ~ 2^-12 |x| < 2^-14 - would be lost (such elements would carry 11 instead of 22 bits).
+__device__ __forceinline__ float f16_plane_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
+  int e;
+  frexpf(amax, &e);                       // amax = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.0f, 14 - e);
+}
+
 // Error of the int8 screening product against the exact one (raw dot-product units).  k_prep_split quantises each
 // IMAGE with ONE step: q = clamp(rint(a / sigma), -127, 127).  With a = sigma q + da, |da_k| <= sigma / 2 + e_k where
 // e_k = max(|a_k| - 127 sigma, 0) is what the clamp cut off (zero unless the step, estimated from a sample of the

@@ -90,7 +90,10 @@ struct Scalars {          // lives at ws.scalars (zeroed per call)
 
 // ---- launchers (each enqueues on `st`, returns hipGetLastError()) ----
 hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
-                       int exact_step, hipStream_t st);
+                       int exact_step, int planes, hipStream_t st);
+// FM_MODE_FLAT: stabilisers of every row / column, the pair margin, the float16 planes' scale; flags every sample for
+// the dense sum kernel (what the screening kernel does besides screening)
+hipError_t launch_stab(const CoarseWs& w, char* base, float inv_ct, float thr, int allow_dead, hipStream_t st);
 hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                            int force, hipStream_t st);
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st);

@@ -61,8 +61,9 @@ class CoarseBuffers:
     def read_count(self) -> int:
         """The single host sync of the path: returns M (raises on a device-side status)."""
         lib = _lib.load()
-        m = C.c_int32(0)
-        st = lib.fm_read_count(_ptr(self.count), self.cap, C.byref(m), _stream(self.count.device))
+        m, info = C.c_int32(0), C.c_int32(0)
+        st = lib.fm_read_count_info(_ptr(self.count), self.cap, C.byref(m), C.byref(info), _stream(self.count.device))
+        self.info = int(info.value)          # raw FM_DEV_* bits, the informational ones included (FM_DEV_ALL_DENSE)
         if st != _lib.FM_OK:
             err = _lib.FMatchError(st, "fm_coarse_match")
             err.required = int(m.value)
@@ -109,7 +110,8 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        scale0: Optional[torch.Tensor] = None, scale1: Optional[torch.Tensor] = None,
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
                        conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False,
-                       cell_maps: bool = True, exact_step: bool = False, stats: bool = False) -> CoarseBuffers:
+                       cell_maps: bool = True, exact_step: bool = False, stats: bool = False,
+                       flat: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
@@ -122,7 +124,9 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     (FM_MODE_EXACT_STEP) derives the int8 screening step from the images' true maxima (one more small kernel) instead
     of from a sample of rows: the answer to FM_E_STEP (an outlier descriptor outside the sample).  `stats`
     (FM_MODE_STATS) leaves the log-softmax offsets of every row and column in the workspace
-    (CoarseBuffers.softmax_stats(): what dual_softmax_at and its backward read)."""
+    (CoarseBuffers.softmax_stats(): what dual_softmax_at and its backward read).  `flat` (FM_MODE_FLAT, implies
+    dense) is the hint that every sample has flat similarity: the screening sweep is skipped, the planes come out of the
+    prep kernel and all samples go to the dense sum kernel (two launches fewer); the result does not depend on it."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -139,7 +143,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
         cand_slots = lib.fm_default_cand_slots(float(thr))
     mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
            (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_EXACT_STEP if exact_step else 0) | \
-           (_lib.FM_MODE_STATS if stats else 0)
+           (_lib.FM_MODE_STATS if stats else 0) | (_lib.FM_MODE_FLAT if flat else 0)
     nbytes = C.c_size_t(0)
     _lib.check(lib.fm_coarse_workspace_bytes_mode(n, l, s, c, cand_slots, mode, int(bool(conf_matrix)), C.byref(nbytes)),
                "fm_coarse_workspace_bytes_mode")
@@ -188,7 +192,7 @@ class ModeMemory:
         import threading
         from collections import OrderedDict
         self._lock = threading.Lock()
-        self._d = OrderedDict()          # key -> {'dense': bool, 'exact': bool, 'step': bool, 'calls': int, 'learnt': int}
+        self._d = OrderedDict()          # key -> {'dense', 'exact', 'step', 'flat': bool, 'calls': int, 'learnt': int}
         self.capacity, self.reprobe = capacity, reprobe
 
     def start(self, key):
@@ -209,12 +213,22 @@ class ModeMemory:
             e = self._d.get(key)
             return bool(e and e['step'] and not probing)
 
-    def learn(self, key, dense=False, exact=False, step=False):
+    def flat(self, key, probing=False):
+        """start the call with the flat-similarity hint (FM_MODE_FLAT)?  Learnt when a dense call of this shape reported
+        that EVERY sample went to the dense sum kernel (FM_DEV_ALL_DENSE); forgotten with the other flags."""
         with self._lock:
-            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'step': False, 'calls': 0, 'learnt': 0})
+            e = self._d.get(key)
+            return bool(e and e.get('flat') and not probing)
+
+    def learn(self, key, dense=False, exact=False, step=False, flat=None):
+        with self._lock:
+            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'step': False, 'flat': False, 'calls': 0,
+                                         'learnt': 0})
             e['dense'] |= bool(dense)
             e['exact'] |= bool(exact)
             e['step'] |= bool(step)
+            if flat is not None:
+                e['flat'] = bool(flat)
             e['learnt'] += 1
             self._d.move_to_end(key)
             while len(self._d) > self.capacity:
@@ -238,14 +252,17 @@ MODE_MEMORY = ModeMemory()
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
                  scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None,
-                 dense: Optional[bool] = None, exact_step: Optional[bool] = None, stats: bool = False) -> dict:
+                 dense: Optional[bool] = None, exact_step: Optional[bool] = None, stats: bool = False,
+                 flat: Optional[bool] = None) -> dict:
     """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
     N*min(L,S)), with the dense sum kernel (FM_E_DENSE), with the exact screening pass, then with more candidate
     slots when the device reports the corresponding condition, with the exact int8 step when the sampled one clipped an
     outlier (FM_E_STEP), and once more when the assignment kernel's bounded wait ran out (FM_E_INTERNAL: "call again",
     fmatch.h).  exact_screening=None: on when conf_matrix is
     requested (that path already runs the denominator reduction the exact screening needs, and it is the training /
-    untrained-network mode in which flat rows occur) or when MODE_MEMORY holds it for this shape; dense=None likewise."""
+    untrained-network mode in which flat rows occur) or when MODE_MEMORY holds it for this shape; dense=None likewise.
+    flat=None: the FM_MODE_FLAT hint is taken from MODE_MEMORY - learnt when a dense call of this shape reports that
+    every sample went to the dense sum kernel (FM_DEV_ALL_DENSE), dropped with the other flags at the next re-probe."""
     lib = _lib.load()
     key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
     mem_dense, mem_exact, probing = (False, False, False)
@@ -255,10 +272,13 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
         exact_step = MODE_MEMORY.step(key, probing)
     if exact_screening is None:
         exact_screening = bool(conf_matrix) or bool(stats) or mem_exact
+    managed_flat = flat is None
     if dense is None:
         dense = mem_dense
+    if flat is None:
+        flat = bool(dense) and MODE_MEMORY.flat(key, probing)
     kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening),
-              dense=bool(dense), exact_step=bool(exact_step))
+              dense=bool(dense) or bool(flat), exact_step=bool(exact_step), flat=bool(flat))
     retried_internal = False
     for _ in range(8):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
@@ -293,6 +313,10 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
             raise
         if probing:                      # the common path served a shape that once needed more: forget the flags
             MODE_MEMORY.forget(key)
+        elif managed_flat and kw['dense'] and not conf_matrix and not stats:
+            all_dense = bool(getattr(buf, 'info', 0) & _lib.FM_DEV_ALL_DENSE)
+            if all_dense != kw['flat']:  # every sample went to the dense kernel: skip the screening sweep next time
+                MODE_MEMORY.learn(key, dense=True, flat=all_dense)
         out = buf.sliced(m)
         if conf_matrix:
             out['conf_matrix'] = buf.conf_matrix

@@ -73,6 +73,14 @@ enum fm_status {
 #define FM_MODE_EXACT_STEP 8      /* one more (small) kernel finds the largest |x| of every image first, and the int8
                                      screening step is derived from it instead of from a sample of rows: nothing is
                                      clipped, whatever the data (answers FM_E_STEP) */
+#define FM_MODE_FLAT 32           /* a HINT (implies FM_MODE_DENSE): the caller expects flat similarity in every sample
+                                     (an untrained network, textureless or occluded scenes - what FM_DEV_ALL_DENSE
+                                     reported for the previous call of this kind).  The screening sweep, whose only
+                                     finding would be "flat", is skipped: k_prep_split writes the float16 planes
+                                     itself, a small kernel forms the stabilisers, and EVERY sample goes to the dense
+                                     sum kernel - two launches and one pass over the descriptors fewer.  The hint never
+                                     changes what is computed beyond which of the two float32-grade arithmetics serves
+                                     a sample (they agree to ~1e-7): peaked data under the hint is correct, only slower */
 
 /* element type of the coarse descriptors handed to fm_coarse_match_dtype */
 enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
@@ -84,6 +92,9 @@ enum fm_dtype { FM_F32 = 0, FM_F16 = 1, FM_BF16 = 2 };
 #define FM_DEV_DENSE 8
 #define FM_DEV_INTERNAL 32
 #define FM_DEV_STEP 128
+#define FM_DEV_ALL_DENSE 256      /* informational, never an error: every sample of the call was served by the dense sum
+                                     kernel (fm_read_count_info reports it; FM_MODE_FLAT is the faster way to run the
+                                     next call on such data) */
 
 int fm_version(void);
 const char* fm_strerror(int status);
@@ -167,12 +178,18 @@ int fm_debug_launch_prep(void* workspace, const float* feat0, const float* feat1
 int fm_debug_launch_prep_f16(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
                              int cand_slots, int force, void* stream);
 int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream);
+/* FM_MODE_FLAT's two own launches alone: which = 0 k_prep_split with the float16 planes (clears the per-call counters
+ * like fm_debug_launch_prep), which = 1 the stabiliser kernel k_stab.  Full-size workspace. */
+int fm_debug_launch_flat(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
+                         int cand_slots, float temperature, float thr, int which, void* stream);
 
 /* Copy {M, status} to the host and wait for the stream (the one host sync of the
  * path, where the reference's torch.where syncs: coarse_matching_new.py:109).
  * Returns FM_OK or the error the status bits encode; *m_out is min(M, cap) on
  * success and the required capacity on FM_E_CAPACITY. */
 int fm_read_count(const int32_t* d_count, int cap, int32_t* m_out, void* stream);
+/* The same, and the raw device status bits (FM_DEV_*, the informational ones included) in *info_out. */
+int fm_read_count_info(const int32_t* d_count, int cap, int32_t* m_out, int32_t* info_out, void* stream);
 
 /*
  * Window crop (fine_preprocess.py:43-50): out[m, wy*W+wx, c] =

@@ -154,6 +154,70 @@ def test_headline_step_w5_at_cfg2_against_oracle(layout):
     assert np.abs(k1.cpu().numpy()[gi] - ref['mkpts1_f'][ri]).max() <= FINE_TOL_PX
 
 
+@pytest.mark.parametrize("name,dist", [("cfg1_borderline", "borderline"), ("cfg2_borderline", "borderline"),
+                                       ("cfg2_mixed", "mixed"), ("cfg2_peaky", "peaky"), ("cfg3_first2_borderline", "borderline"),
+                                       ("l9600_borderline", "borderline")])
+def test_flat_hint_against_reference_fixture(name, dist):
+    """FM_MODE_FLAT (the caller's hint that every sample has flat similarity: no screening sweep, the float16 planes out
+    of k_prep_split, k_stab, every sample to the dense sum kernel) against the REFERENCE's outputs - on flat data
+    ('borderline': every conf in (0.2, 1)), on 'mixed' data (dead rows + rows without a peak; with the exact screening
+    pass, as the bench runs it) and on PEAKED data, where the hint is wrong and must only cost time.  The call reports
+    FM_DEV_ALL_DENSE (informational), which is how ops.coarse_match's mode memory learns the hint."""
+    g = load_golden(name)
+    inp = case_inputs(g['meta'], dist, with_fine=False)
+    t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    hw_c = inp['hw_c']
+    buf = ops.coarse_match_async(t0, t1, hw_c, hw_c, inp['hw_i'][0] / hw_c[0], dense=True, flat=True,
+                                 exact_screening=(dist == "mixed"))
+    m = buf.read_count()
+    assert buf.info & _lib.FM_DEV_ALL_DENSE
+    ndiff = _assert_coarse(buf.sliced(m), g)
+    assert ndiff <= 6, f"{ndiff} guard-band flips"
+    # ... and the same call without the hint: the same matches (two float32-grade arithmetics may differ in the last bits
+    # of conf for a sample that changes kernels - 'peaky' here - never in the set outside the guard band)
+    buf2 = ops.coarse_match_async(t0, t1, hw_c, hw_c, inp['hw_i'][0] / hw_c[0], dense=True, exact_screening=(dist == "mixed"))
+    m2 = buf2.read_count()
+    assert bool(buf2.info & _lib.FM_DEV_ALL_DENSE) == (dist != "peaky")
+    _assert_coarse(buf.sliced(m), {k: v for k, v in _np(buf2.sliced(m2)).items()}, conf_tol=2e-6)
+
+
+def test_mode_memory_learns_the_flat_hint():
+    """ops.coarse_match on flat data: FM_E_DENSE -> repeated with FM_MODE_DENSE -> that call reports FM_DEV_ALL_DENSE ->
+    the shape's next call carries FM_MODE_FLAT; same matches every time."""
+    g = load_golden("cfg1_borderline")
+    inp = case_inputs(g['meta'], "borderline", with_fine=False)
+    t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    ops.MODE_MEMORY.clear()
+    key = (tuple(t0.shape), tuple(t1.shape), 0.2, 0.1)
+    outs = [ops.coarse_match(t0, t1, inp['hw_c'], inp['hw_c'], 8.0) for _ in range(3)]
+    snap = ops.MODE_MEMORY.snapshot()[key]
+    assert snap['dense'] and snap['flat']
+    for o in outs:
+        _assert_coarse(o, g)
+    assert np.array_equal(_np(outs[1])['mconf'], _np(outs[2])['mconf'])
+    ops.MODE_MEMORY.clear()
+
+
+def test_flat_hint_with_an_outlier_outside_the_sampled_rows():
+    """The float16 planes k_prep_split writes under FM_MODE_FLAT are scaled from the SAMPLED rows' maximum: a descriptor
+    ~6x beyond it would leave float16's range - k_stab compares the image's true maximum with the scale and reports
+    FM_E_STEP; with FM_MODE_EXACT_STEP (scale from the true maximum) the call is served."""
+    l, c, hw = 1200, 128, (30, 40)
+    f0, f1 = synth.coarse_descriptors(92, 1, l, c, "borderline")
+    sampled = sorted({(t * l) // 32 for t in range(32)})
+    free = [r for r in range(l) if r not in sampled]
+    f0[0, free[9]] *= 12.0
+    ref = orc.coarse_match(f0, f1, (240, 320), hw, hw, 0.2, 2, 0.1)
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    with pytest.raises(_lib.FMatchError) as e:
+        ops.coarse_match_async(t0, t1, hw, hw, 8.0, dense=True, flat=True, exact_screening=True).read_count()
+    assert e.value.status == _lib.FM_E_STEP
+    buf = ops.coarse_match_async(t0, t1, hw, hw, 8.0, dense=True, flat=True, exact_screening=True, exact_step=True)
+    m = buf.read_count()
+    _assert_coarse(buf.sliced(m), ref)
+    assert m == ref['i_ids'].shape[0] > 100
+
+
 def test_cfg5_coarse_against_reference_fixture():
     g = load_golden("cfg5_peaky")                       # 1024x1024 -> L = S = 16384
     inp = case_inputs(g['meta'], "peaky", with_fine=False)

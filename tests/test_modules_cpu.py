@@ -99,5 +99,13 @@ def test_mode_memory_is_bounded_decays_and_forgets():
     assert m.start('b') == (False, False, True)                 # third remembered call: probe the common path
     m.forget('b')
     assert m.start('b') == (False, False, False)
+    # the flat-similarity hint (FM_MODE_FLAT): learnt with an explicit True / False, never on the probing call
+    assert not m.flat('c')
+    m.learn('c', dense=True, flat=True)
+    assert m.flat('c') and not m.flat('c', probing=True) and m.snapshot()['c']['flat']
+    m.learn('c', dense=True)                                     # (flat=None leaves it alone)
+    assert m.flat('c')
+    m.learn('c', dense=True, flat=False)
+    assert not m.flat('c')
     m.clear()
     assert not m.snapshot()

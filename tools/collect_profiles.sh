@@ -33,6 +33,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python bench.
 echo "cfg3 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -- python bench.py --workload cfg5 --steps 50 --warmup 5 --skip-cpu --quick > $O/cfg5.json 2> $O/cfg5.err
 echo "cfg5 done"
+# (5b) flat-similarity data (FM_MODE_DENSE | FM_MODE_FLAT): kernel time of the dense path, one stream, eager
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/borderline -- python bench.py --dist borderline --steps 100 --warmup 10 --skip-cpu --quick --streams 1 --pairs 1 --no-graph > $O/borderline.json 2> $O/borderline.err
+echo "borderline done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/mixed -- python bench.py --dist mixed --steps 100 --warmup 10 --skip-cpu --quick --streams 1 --pairs 1 --no-graph > $O/mixed.json 2> $O/mixed.err
+echo "mixed done"
 # (6) the context layers either side of the path: kernel time, then matrix-core counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ctx -- python tools/time_matcher.py > $O/ctx.log 2> $O/ctx.err
 echo "ctx done"

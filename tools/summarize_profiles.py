@@ -7,6 +7,7 @@ committed under profiles/:
   profiles/<round>_bench_cfg2_default_kernel_stats.csv   rocprofv3 --stats of the default bench command
   profiles/<round>_bench_cfg2_serial_kernel_stats.csv    same step, one stream, eager (no overlap)
   profiles/<round>_bench_cfg3_kernel_stats.csv, ..._cfg5_...
+  profiles/<round>_bench_cfg2_borderline_serial_kernel_stats.csv, ..._mixed_...   flat-similarity data (dense path)
   profiles/<round>_pmc_fetch_write_cfg2.json             FETCH_SIZE / WRITE_SIZE per launch and kernel (KiB)
   profiles/<round>_pmc_sq_cfg2.csv, ..._cfg3.csv         matrix-core busy / wait fractions per kernel
   profiles/<round>_forward_features_kernel_stats.csv     rocprofv3 --stats of tools/time_matcher.py (net.forward tail)
@@ -66,6 +67,8 @@ def main():
     stats("serial", f"{rnd}_bench_cfg2_serial_kernel_stats.csv")
     stats("cfg3", f"{rnd}_bench_cfg3_kernel_stats.csv")
     stats("cfg5", f"{rnd}_bench_cfg5_kernel_stats.csv")
+    stats("borderline", f"{rnd}_bench_cfg2_borderline_serial_kernel_stats.csv")
+    stats("mixed", f"{rnd}_bench_cfg2_mixed_serial_kernel_stats.csv")
 
     fw = {}
     for tag in ("fetch", "write"):
