@@ -24,6 +24,7 @@ FM_DEV_RANGE = 4                                    # device status bit
 FM_DEV_ALL_DENSE = 256                              # informational device status bit (fm_read_count_info)
 FM_MODE_EXACT_SCREENING, FM_MODE_DENSE, FM_MODE_NO_CELL_MAPS, FM_MODE_EXACT_STEP, FM_MODE_STATS = 1, 2, 4, 8, 16   # `mode` bits
 FM_MODE_FLAT = 32
+FM_LAYOUT_NCHW_PREPARED = 2                         # fm_fine_match_maps*: image 1's channels-last copy is already in `scratch`
 
 _lib = None
 
@@ -42,6 +43,8 @@ SIGNATURES = {
                              _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "fm_coarse_match_dtype": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
                                    _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "fm_coarse_match_maps": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
+                                  _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
     "fm_debug_launch_corr": (_i, [_p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "fm_debug_launch_sum_sparse": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),

@@ -207,12 +207,48 @@ extern "C" int fm_coarse_match(const float* feat0, const float* feat1, int N, in
                                j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, conf_matrix, stream);
 }
 
+static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                             int h0c, int w0c, int h1c, int w1c, float temperature, float thr, int border_rm,
+                             float scale_px, const float* scale0, const float* scale1, void* workspace,
+                             size_t workspace_bytes, int cand_slots, int mode, int64_t* b_ids,
+                             int64_t* i_ids, int64_t* j_ids, float* mkpts0_c, float* mkpts1_c, float* mconf,
+                             int cap, int32_t* d_count, float* conf_matrix, const MapCopyJob* job, void* stream);
+
 extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
                                      int h0c, int w0c, int h1c, int w1c, float temperature, float thr, int border_rm,
                                      float scale_px, const float* scale0, const float* scale1, void* workspace,
                                      size_t workspace_bytes, int cand_slots, int mode, int64_t* b_ids,
                                      int64_t* i_ids, int64_t* j_ids, float* mkpts0_c, float* mkpts1_c, float* mconf,
                                      int cap, int32_t* d_count, float* conf_matrix, void* stream) {
+  return coarse_match_impl(feat0, feat1, in_dtype, N, L, S, C, h0c, w0c, h1c, w1c, temperature, thr, border_rm, scale_px,
+                           scale0, scale1, workspace, workspace_bytes, cand_slots, mode, b_ids, i_ids, j_ids, mkpts0_c,
+                           mkpts1_c, mconf, cap, d_count, conf_matrix, nullptr, stream);
+}
+
+// fm_coarse_match_dtype + the channels-last copy of image 1's fine map as a side job of the assignment launch
+extern "C" int fm_coarse_match_maps(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                                    int h0c, int w0c, int h1c, int w1c, float temperature, float thr, int border_rm,
+                                    float scale_px, const float* scale0, const float* scale1, void* workspace,
+                                    size_t workspace_bytes, int cand_slots, int mode, int64_t* b_ids,
+                                    int64_t* i_ids, int64_t* j_ids, float* mkpts0_c, float* mkpts1_c, float* mconf,
+                                    int cap, int32_t* d_count, float* conf_matrix, const float* feat_f1, int Nf, int Cf,
+                                    int Hf1, int Wf1, void* scratch1, void* stream) {
+  if (!feat_f1 || !scratch1) return FM_E_NULL;
+  if (Nf <= 0 || Hf1 <= 0 || Wf1 <= 0) return FM_E_SHAPE;
+  if (Cf != 64) return FM_E_UNSUPPORTED;
+  if (((uintptr_t)scratch1 & 15) || ((uintptr_t)feat_f1 & 15)) return FM_E_WORKSPACE;
+  const MapCopyJob job{feat_f1, (float*)scratch1, Nf, Hf1, Wf1};
+  return coarse_match_impl(feat0, feat1, in_dtype, N, L, S, C, h0c, w0c, h1c, w1c, temperature, thr, border_rm, scale_px,
+                           scale0, scale1, workspace, workspace_bytes, cand_slots, mode, b_ids, i_ids, j_ids, mkpts0_c,
+                           mkpts1_c, mconf, cap, d_count, conf_matrix, &job, stream);
+}
+
+static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                             int h0c, int w0c, int h1c, int w1c, float temperature, float thr, int border_rm,
+                             float scale_px, const float* scale0, const float* scale1, void* workspace,
+                             size_t workspace_bytes, int cand_slots, int mode, int64_t* b_ids,
+                             int64_t* i_ids, int64_t* j_ids, float* mkpts0_c, float* mkpts1_c, float* mconf,
+                             int cap, int32_t* d_count, float* conf_matrix, const MapCopyJob* job, void* stream) {
   if (!feat0 || !feat1 || !workspace || !d_count) return FM_E_NULL;
   if (in_dtype != FM_F32 && in_dtype != FM_F16 && in_dtype != FM_BF16) return FM_E_UNSUPPORTED;
   if (cap > 0 && (!b_ids || !i_ids || !j_ids || !mkpts0_c || !mkpts1_c || !mconf)) return FM_E_NULL;
@@ -281,7 +317,7 @@ extern "C" int fm_coarse_match_dtype(const void* feat0, const void* feat1, int i
     if (e != hipSuccess) return (int)e;
   }
   e = launch_select(w, base, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
-                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, dense ? (mode | FM_MODE_DENSE) : mode, st);
+                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, dense ? (mode | FM_MODE_DENSE) : mode, st, job);
   return (int)e;
 }
 

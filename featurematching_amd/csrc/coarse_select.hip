@@ -10,6 +10,7 @@
 // candidate in the row / column maxima of :105-106 - the maxima over candidates decide.
 // The border mask (:100-102) is applied last: border cells still compete in the maxima.
 #include "fm_internal.h"
+#include "fm_maps_device.h"
 
 namespace fm {
 
@@ -34,6 +35,7 @@ struct SelArgs {
   int* cell0; int* cell1;     // cell -> match index + 1 (for the cell-ordered window gathers)
   int* ties0; int* ties1;     // [0] = count, then the matches that lost their cell to an exactly tied match
   int nblk;                   // logical blocks of 256 (row, slot) pairs
+  MapCopyJob job;             // side job (fm_coarse_match_maps): workgroups nblk .. gridDim.x - 1 transpose a fine map
   float* diag;                // diagnostic build: stamp buffer
 };
 
@@ -109,6 +111,15 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
 #else
 #define SEL_STAMP(i)
 #endif
+  // ---- side-job role (fm_coarse_match_maps): the workgroups BEHIND the assignment's own - those are dispatched first,
+  // their look-back chain is not delayed - copy image 1's NCHW fine map to channels-last storage: an HBM-bound stream
+  // next to 152 latency-bound workgroups that leave the memory system idle ----
+  if ((int)blockIdx.x >= a.nblk) {
+    __shared__ float tr_tile[64 * 65];
+    nchw_to_nhwc64_units<float>(a.job.src, a.job.dst, a.job.Hf, a.job.Wf, a.job.N, tr_tile, (long)blockIdx.x - a.nblk,
+                                (long)gridDim.x - a.nblk);
+    return;
+  }
   const int blk = blockIdx.x;
   SEL_STAMP(1)
   const int lane = threadIdx.x & 63;
@@ -332,7 +343,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
                          int h1c, int w1c, float inv_ct, float thr, int border, float scale_px,
                          const float* scale0, const float* scale1, int64_t* b_ids, int64_t* i_ids,
                          int64_t* j_ids, float* k0, float* k1, float* mconf, int cap, int32_t* d_count,
-                         int mode, hipStream_t st) {
+                         int mode, hipStream_t st, const MapCopyJob* job) {
   SelArgs a;
   a.exact = (mode & FM_MODE_EXACT_SCREENING) ? 1 : 0;
   a.dense_enabled = (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING)) ? 1 : 0;
@@ -360,7 +371,15 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   const int blocks = (int)(((long)w.N * w.Lp * w.slots + 255) / 256);
   a.nblk = blocks;
   a.diag = (float*)(base + w.rowB);       // (diagnostic builds run on a full-size workspace)
-  hipLaunchKernelGGL(k_select, dim3(blocks), dim3(256), 0, st, a);
+  a.job = MapCopyJob{nullptr, nullptr, 0, 0, 0};
+  int extra = 0;
+  if (job && job->src) {
+    // one workgroup per (sample, row, 64-pixel piece) up to four per compute unit, the rest in grid strides
+    a.job = *job;
+    const long units = (long)((job->Wf + 63) / 64) * job->Hf * job->N;
+    extra = (int)(units < 1024 ? units : 1024);
+  }
+  hipLaunchKernelGGL(k_select, dim3(blocks + extra), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

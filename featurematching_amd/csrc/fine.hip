@@ -1,6 +1,7 @@
 // Fine stage: window crop (network/module/fine_preprocess.py:43-50) and the dual-direction
 // local-window correlation + soft-argmax (network/utils/fine_matching_new.py:50-79).
 #include "fm_device.h"
+#include "fm_maps_device.h"
 
 namespace fm {
 
@@ -687,42 +688,8 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
 template <typename T>
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc64(const T* __restrict__ src, T* __restrict__ dst, int Hf, int Wf,
                                                         int N) {
-  struct alignas(4 * sizeof(T)) V4 { T x, y, z, w; };
   __shared__ T tile[64 * 65];                  // [x][c], pitch 65
-  const int tid = threadIdx.x;
-  const int tx = (Wf + 63) / 64;
-  const long total = (long)tx * Hf * N;        // (sample, row, 64-pixel piece) in a flat order walked in grid strides
-  for (long t = blockIdx.x; t < total; t += gridDim.x) {
-  const int x0 = (int)(t % tx) * 64, y = (int)((t / tx) % Hf), b = (int)(t / ((long)tx * Hf));
-  const T* in = src + ((long)b * 64 * Hf + y) * Wf + x0;      // + c * Hf * Wf
-  const long plane = (long)Hf * Wf;
-  const int nx = min(64, Wf - x0);
-  const bool vec = (Wf & 3) == 0;              // rows aligned to 4 elements
-  V4 v[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {                // channel c = 16 p + tid / 16, pixels 4 (tid % 16) .. + 3
-    const int c = 16 * p + (tid >> 4), xq = (tid & 15) * 4;
-    const T* row = in + c * plane;
-    if (vec && xq + 3 < nx) v[p] = *reinterpret_cast<const V4*>(row + xq);
-    else v[p] = V4{xq < nx ? row[xq] : T(0), xq + 1 < nx ? row[xq + 1] : T(0), xq + 2 < nx ? row[xq + 2] : T(0),
-                   xq + 3 < nx ? row[xq + 3] : T(0)};
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int c = 16 * p + (tid >> 4), xq = (tid & 15) * 4;
-    tile[(xq + 0) * 65 + c] = v[p].x; tile[(xq + 1) * 65 + c] = v[p].y;
-    tile[(xq + 2) * 65 + c] = v[p].z; tile[(xq + 3) * 65 + c] = v[p].w;
-  }
-  __syncthreads();
-  V4* out = reinterpret_cast<V4*>(dst + (((long)b * Hf + y) * Wf + x0) * 64);
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {                // pixel x = 16 p + tid / 16, channels 4 (tid % 16) .. + 3
-    const int x = 16 * p + (tid >> 4), c4 = (tid & 15) * 4;
-    if (x < nx)
-      out[x * 16 + (tid & 15)] = V4{tile[x * 65 + c4], tile[x * 65 + c4 + 1], tile[x * 65 + c4 + 2], tile[x * 65 + c4 + 3]};
-  }
-  __syncthreads();                             // the tile is rewritten by the next piece
-  }
+  nchw_to_nhwc64_units<T>(src, dst, Hf, Wf, N, tile, blockIdx.x, gridDim.x);     // (fm_maps_device.h)
 }
 
 }  // namespace fm
@@ -934,7 +901,13 @@ extern "C" int fm_fine_match_maps_dtype(const void* feat_f0, const void* feat_f1
   if (N <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0 || stride <= 0 || w0c <= 0 || w1c <= 0 || m_max < 0)
     return FM_E_SHAPE;
   if (map_dtype != FM_F32 && map_dtype != FM_F16 && map_dtype != FM_BF16) return FM_E_UNSUPPORTED;
-  if ((layout != 0 && layout != 1) || !maps64_ok(Cf, Hf0, Wf0, W) || !maps64_ok(Cf, Hf1, Wf1, W)) return FM_E_UNSUPPORTED;
+  if ((layout != 0 && layout != 1 && layout != FM_LAYOUT_NCHW_PREPARED) || !maps64_ok(Cf, Hf0, Wf0, W) ||
+      !maps64_ok(Cf, Hf1, Wf1, W))
+    return FM_E_UNSUPPORTED;
+  // (image 1's channels-last copy was made by the coarse call - fm_coarse_match_maps - into `scratch`: float32 maps only)
+  const bool prepared = layout == FM_LAYOUT_NCHW_PREPARED;
+  if (prepared && map_dtype != FM_F32) return FM_E_UNSUPPORTED;
+  if (prepared) layout = 0;
   if (layout == 0 && !scratch) return FM_E_NULL;
   hipStream_t st = (hipStream_t)stream;
   const float* m0 = (const float*)feat_f0;
@@ -947,8 +920,9 @@ extern "C" int fm_fine_match_maps_dtype(const void* feat_f0, const void* feat_f1
   if (layout == 0 && !half) {   // NCHW: a channels-last copy of image 1 (coalesced on both sides); image 0 is read as it is
     float* s1 = (float*)scratch;
     const long pieces = (long)((Wf1 + 63) / 64) * Hf1 * N;
-    hipLaunchKernelGGL(k_nchw_to_nhwc64<float>, dim3((unsigned)(pieces < grid_cap ? pieces : grid_cap)), dim3(256), 0, st,
-                       (const float*)feat_f1, s1, Hf1, Wf1, N);
+    if (!prepared)
+      hipLaunchKernelGGL(k_nchw_to_nhwc64<float>, dim3((unsigned)(pieces < grid_cap ? pieces : grid_cap)), dim3(256), 0, st,
+                         (const float*)feat_f1, s1, Hf1, Wf1, N);
     m1 = s1;
   } else if (layout == 0) {     // NCHW float16 / bfloat16: channels-last copies of both maps, element type kept
     unsigned short* s0 = (unsigned short*)scratch;

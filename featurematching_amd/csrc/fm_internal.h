@@ -101,10 +101,15 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
                        float* conf = nullptr);
 hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st);
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);
+// side job of the assignment launch (fm_coarse_match_maps): channels-last copy of a float32 NCHW map, or src == NULL
+struct MapCopyJob {
+  const float* src; float* dst; int N, Hf, Wf;
+};
 hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border,
                          float scale_px, const float* scale0, const float* scale1,
                          int64_t* b_ids, int64_t* i_ids, int64_t* j_ids, float* k0, float* k1,
-                         float* mconf, int cap, int32_t* d_count, int mode, hipStream_t st);
+                         float* mconf, int cap, int32_t* d_count, int mode, hipStream_t st,
+                         const MapCopyJob* job = nullptr);
 hipError_t launch_conf_patch(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
 hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                              float inv_ct, float thr, int dense_enabled, int allow_dead, hipStream_t st);

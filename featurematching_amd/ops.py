@@ -111,7 +111,8 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        cap: Optional[int] = None, cand_slots: Optional[int] = None,
                        conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False,
                        cell_maps: bool = True, exact_step: bool = False, stats: bool = False,
-                       flat: bool = False) -> CoarseBuffers:
+                       flat: bool = False, side_map: Optional[torch.Tensor] = None,
+                       side_scratch: Optional[torch.Tensor] = None) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
@@ -126,7 +127,10 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     (FM_MODE_STATS) leaves the log-softmax offsets of every row and column in the workspace
     (CoarseBuffers.softmax_stats(): what dual_softmax_at and its backward read).  `flat` (FM_MODE_FLAT, implies
     dense) is the hint that every sample has flat similarity: the screening sweep is skipped, the planes come out of the
-    prep kernel and all samples go to the dense sum kernel (two launches fewer); the result does not depend on it."""
+    prep kernel and all samples go to the dense sum kernel (two launches fewer); the result does not depend on it.
+    `side_map` (fm_coarse_match_maps): image 1's NCHW float32 fine map [N, 64, Hf, Wf] - its channels-last copy, which
+    fine_match_maps would make as its first launch, rides in the assignment kernel's launch instead and lands in
+    `side_scratch` (allocated when not given; CoarseBuffers.side_scratch) - pass that to fine_match_maps(prepared=...)."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -159,12 +163,24 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
         out.conf_matrix = torch.empty(n, l, s, dtype=torch.float32, device=dev)
     sc0 = None if scale0 is None else _f32c(scale0.to(dev), "scale0")
     sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
-    st = lib.fm_coarse_match_dtype(_ptr(f0), _ptr(f1), _DTYPES[f0.dtype], n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
-                             int(hw1_c[1]), float(temperature), float(thr), int(border_rm), float(scale_px),
-                             _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots, mode,
-                             _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids), _ptr(out.mkpts0_c),
-                             _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), _ptr(out.conf_matrix),
-                             _stream(dev))
+    args = (_ptr(f0), _ptr(f1), _DTYPES[f0.dtype], n, l, s, c, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]),
+            int(hw1_c[1]), float(temperature), float(thr), int(border_rm), float(scale_px),
+            _ptr(sc0), _ptr(sc1), ws_ptr, nbytes.value, cand_slots, mode,
+            _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids), _ptr(out.mkpts0_c),
+            _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count), _ptr(out.conf_matrix))
+    if side_map is not None:
+        if not (side_map.is_cuda and side_map.dtype == torch.float32 and side_map.dim() == 4 and side_map.shape[1] == 64
+                and side_map.is_contiguous()):
+            raise ValueError("side_map: a contiguous NCHW float32 GPU map with 64 channels")
+        need = side_map.numel() * 4
+        if side_scratch is None or side_scratch.numel() * side_scratch.element_size() < need:
+            side_scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+        st = lib.fm_coarse_match_maps(*args, _ptr(side_map), int(side_map.shape[0]), 64, int(side_map.shape[2]),
+                                      int(side_map.shape[3]), _ptr(side_scratch), _stream(dev))
+        out.side_scratch = side_scratch
+        out._side_map = side_map
+    else:
+        st = lib.fm_coarse_match_dtype(*args, _stream(dev))
     _lib.check(st, "fm_coarse_match_dtype")
     out._keep = (f0, f1, sc0, sc1)   # inputs must outlive the enqueued kernels
     out._shape = (n, l, s, c, cand_slots)
@@ -577,11 +593,13 @@ def _map_layout(t: torch.Tensor):
 def fine_match_maps(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, j_ids, w: int, stride: int, w0c: int,
                     w1c: int, mix0: torch.Tensor, mix1: torch.Tensor, mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor,
                     scale_f: float, pad: int = 2, count: Optional[torch.Tensor] = None,
-                    scratch: Optional[torch.Tensor] = None):
+                    scratch: Optional[torch.Tensor] = None, prepared: Optional[torch.Tensor] = None):
     """Window crop + fine stage from the maps in one call (fm_fine_match_maps_dtype; fine_preprocess.py:43-50 with plain
     windows + fine_matching_new.py:50-79): no window tensors.  Channels-last maps are read in place; of NCHW float32
     maps image 1 is first copied to channels-last storage in `scratch` (allocated when not given), of NCHW float16 /
     bfloat16 maps (an autocast backbone, network/net.py:56-57) both images are, in their own element type.
+    `prepared`: the scratch buffer a coarse_match_async(side_map=feat_f1) call filled (FM_LAYOUT_NCHW_PREPARED: NCHW
+    float32 maps, image 1's copy exists already - no transpose launch here).
     Returns (mkpts0_f, mkpts1_f), float32."""
     lib = _lib.load()
     if not feat_f0.is_cuda:
@@ -602,6 +620,10 @@ def fine_match_maps(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, 
     if m_max == 0:
         return out0, out1
     need = int(lib.fm_fine_maps_scratch_bytes_dtype(n, cf, hf0, wf0, hf1, wf1, lay0, dt))
+    if prepared is not None:
+        if lay0 != 0 or dt != _lib.FM_F32 or prepared.numel() * prepared.element_size() < need:
+            raise ValueError("prepared: NCHW float32 maps and the scratch a coarse_match_async(side_map=...) call filled")
+        scratch, lay0 = prepared, _lib.FM_LAYOUT_NCHW_PREPARED
     if need and (scratch is None or scratch.numel() * scratch.element_size() < need):
         scratch = torch.empty(need, dtype=torch.uint8, device=dev)
     st = lib.fm_fine_match_maps_dtype(_ptr(f0), _ptr(f1), dt, lay0, n, cf, hf0, wf0, hf1, wf1, w, stride, pad, int(w0c),

@@ -158,6 +158,26 @@ int fm_coarse_match_dtype(const void* feat0, const void* feat1, int in_dtype, in
                           float* mkpts0_c, float* mkpts1_c, float* mconf,
                           int cap, int32_t* d_count, float* conf_matrix, void* stream);
 
+/*
+ * fm_coarse_match_dtype + a SIDE JOB for callers that go on to fm_fine_match_maps with NCHW float32 fine maps (the
+ * reference's layout, network/net.py:56-57): the channels-last copy of image 1's fine map that fm_fine_match_maps makes
+ * as its first launch does not depend on the coarse stage at all, and the assignment kernel - 152 small, latency-bound
+ * workgroups at 640x480 - leaves the memory system idle.  Here the transpose rides in the assignment kernel's launch as
+ * a second workgroup role: one launch fewer per pair and the copy costs no time of its own.
+ *   feat_f1 [dev] float32 [Nf, 64, Hf1, Wf1] (NCHW), scratch1 [dev] fm_fine_maps_scratch_bytes(..., layout 0) bytes,
+ *   16-byte aligned; afterwards call fm_fine_match_maps with layout = FM_LAYOUT_NCHW_PREPARED and the same scratch.
+ * Everything else as fm_coarse_match_dtype (same outputs, same status codes).
+ */
+int fm_coarse_match_maps(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                         int h0c, int w0c, int h1c, int w1c,
+                         float temperature, float thr, int border_rm, float scale_px,
+                         const float* scale0, const float* scale1,
+                         void* workspace, size_t workspace_bytes, int cand_slots, int mode,
+                         int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                         float* mkpts0_c, float* mkpts1_c, float* mconf,
+                         int cap, int32_t* d_count, float* conf_matrix,
+                         const float* feat_f1, int Nf, int Cf, int Hf1, int Wf1, void* scratch1, void* stream);
+
 /* Diagnostic only: workspace layout of fm_coarse_match (40 values: 10 ints, byte offsets, the sparse
  * sum kernel's split geometry, total; order documented in csrc/api.hip) so tests can inspect
  * intermediate statistics. */
@@ -280,6 +300,9 @@ int fm_fine_match(const float* win0, const float* win1, int m_max, const int32_t
  * (fm_fine_maps_scratch_bytes bytes [dev], 16-byte aligned; 0 bytes / NULL for layout 1) by a tiled transpose.  b_ids / i_ids / j_ids, d_count, mkpts*_c as the coarse stage left them; mix0 / mix1, scale_f,
  * out0 / out1 as in fm_fine_match.  Cf = 64, W in {5,7}.  Results equal fm_gather_windows + fm_fine_match bit for bit.
  */
+#define FM_LAYOUT_NCHW_PREPARED 2  /* layout of fm_fine_match_maps*: NCHW maps whose image-1 channels-last copy already sits in
+                                     `scratch` - made by fm_coarse_match_maps, whose assignment launch carries the
+                                     transpose as a side job (float32 maps) */
 size_t fm_fine_maps_scratch_bytes(int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1, int layout);
 int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, int layout, int N, int Cf, int Hf0, int Wf0,
                        int Hf1, int Wf1, int W, int stride, int pad, int w0c, int w1c,

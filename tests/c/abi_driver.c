@@ -60,6 +60,9 @@ static __typeof__(fm_gather_merge_windows)* p_fm_gather_merge_windows;
 static __typeof__(fm_gather_windows_pair)* p_fm_gather_windows_pair;
 static __typeof__(fm_fine_match)* p_fm_fine_match;
 static __typeof__(fm_epipolar_errors)* p_fm_epipolar_errors;
+static __typeof__(fm_coarse_match_maps)* p_fm_coarse_match_maps;
+static __typeof__(fm_read_count_info)* p_fm_read_count_info;
+static __typeof__(fm_debug_launch_flat)* p_fm_debug_launch_flat;
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s libfmatch_hip.so\n", argv[0]); return 2; }
@@ -73,6 +76,7 @@ int main(int argc, char** argv) {
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
   RESOLVE(fm_coarse_tf_packed_bytes); RESOLVE(fm_coarse_tf_workspace_bytes); RESOLVE(fm_coarse_tf_pack_weights);
   RESOLVE(fm_coarse_transformer);
+  RESOLVE(fm_coarse_match_maps); RESOLVE(fm_read_count_info); RESOLVE(fm_debug_launch_flat);
 
   EXPECT(p_fm_version(), FM_VERSION);
   for (int s = FM_E_INTERNAL; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
@@ -133,6 +137,25 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 5, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 16, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 64, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);   /* unknown mode bit */
+  /* fm_coarse_match_maps: the side job's arguments are checked before anything is enqueued */
+  EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL, 1, 64, 32, 32, one, NULL), FM_E_NULL);
+  EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, (const float*)one, 1, 64, 32, 32, NULL, NULL), FM_E_NULL);
+  EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, (const float*)one, 1, 32, 32, 32, one, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, (const float*)one, 1, 64, 0, 32, one, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, (const float*)((char*)one + 4), 1, 64, 32, 32, one, NULL), FM_E_WORKSPACE);
+  /* ... and then the coarse call's own (here: thr out of range) */
+  EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 1.0f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, (const float*)one, 1, 64, 32, 32, one, NULL), FM_E_UNSUPPORTED);
+  {   /* FM_MODE_FLAT is a known mode bit and needs the full-size workspace (the float16 planes) */
+    size_t common2 = 0, flatb = 0;
+    EXPECT(p_fm_coarse_workspace_bytes_mode(1, 64, 64, 64, 8, 0, 0, &common2), FM_OK);
+    EXPECT(p_fm_coarse_workspace_bytes_mode(1, 64, 64, 64, 8, FM_MODE_FLAT, 0, &flatb), FM_OK);
+    EXPECT(flatb > common2, 1);
+    EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, common2, 8, FM_MODE_FLAT, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
+    EXPECT(p_fm_debug_launch_flat(NULL, (const float*)one, (const float*)one, 1, 64, 64, 64, 8, 0.1f, 0.2f, 0, NULL), FM_E_NULL);
+    EXPECT(p_fm_debug_launch_flat(one, (const float*)one, (const float*)one, 1, 64, 64, 64, 8, 0.1f, 0.2f, 2, NULL), FM_E_UNSUPPORTED);
+    int32_t mm = 0, info = 0;
+    EXPECT(p_fm_read_count_info(NULL, 4, &mm, &info, NULL), FM_E_NULL);
+  }
   {   /* a workspace sized for the common path is refused when the call needs the dense regions */
     size_t small = 0;
     EXPECT(p_fm_coarse_workspace_bytes_mode(1, 64, 64, 64, 8, 0, 0, &small), FM_OK);
@@ -201,7 +224,10 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 64, 32, 32, 32, 0, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_SHAPE);
   EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 32, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_fine_match_maps(f, f, 1, 1, 64, 32, 32, 32, 32, 9, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
-  EXPECT(p_fm_fine_match_maps(f, f, 2, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_fine_match_maps(f, f, 3, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
+  /* FM_LAYOUT_NCHW_PREPARED: the scratch a fm_coarse_match_maps call filled is mandatory; float32 maps only */
+  EXPECT(p_fm_fine_match_maps(f, f, FM_LAYOUT_NCHW_PREPARED, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_fine_match_maps_dtype(f, f, FM_F16, FM_LAYOUT_NCHW_PREPARED, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, (void*)f, f, f, NULL), FM_E_UNSUPPORTED);
   /* training surface: argument checks of the dual-softmax entries */
   {
     const float* pr = NULL; const float* pc = NULL; const float* sr = NULL; const float* sc = NULL; int qr = 0, qc = 0;

@@ -218,6 +218,40 @@ def test_flat_hint_with_an_outlier_outside_the_sampled_rows():
     assert m == ref['i_ids'].shape[0] > 100
 
 
+@pytest.mark.parametrize("name,w", [("cfg1_peaky", 7), ("cfg2_peaky", 5), ("cfg3_first2_peaky", 7)])
+def test_assignment_launch_carries_the_map_copy(name, w):
+    """fm_coarse_match_maps: the channels-last copy of image 1's NCHW fine map as a side job of the assignment kernel's
+    launch, then fm_fine_match_maps with FM_LAYOUT_NCHW_PREPARED.  The coarse outputs are those of fm_coarse_match_dtype
+    bit for bit, the scratch buffer is the permuted map bit for bit, and the fine keypoints equal the two-launch form's
+    (ragged widths included: cfg1's 64-px rows are one piece, cfg2's 320-px rows five)."""
+    g = load_golden(name)
+    inp = case_inputs(g['meta'], "peaky", ww=w * w)
+    t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    ff0, ff1 = _maps(inp, "nchw")
+    hw_c, scale = inp['hw_c'], inp['hw_i'][0] / inp['hw_c'][0]
+    plain = ops.coarse_match_async(t0, t1, hw_c, hw_c, scale)
+    m = plain.read_count()
+    fused = ops.coarse_match_async(t0, t1, hw_c, hw_c, scale, side_map=ff1)
+    assert fused.read_count() == m
+    for k, v in plain.sliced(m).items():
+        assert torch.equal(v, fused.sliced(m)[k]), k
+    n, cf, hf, wf = ff1.shape
+    got = fused.side_scratch[:ff1.numel() * 4].view(torch.float32).view(n, hf, wf, cf)
+    assert torch.equal(got, ff1.permute(0, 2, 3, 1).contiguous())
+    mix0, mix1 = _mix_tensors(inp['mix'])
+    o = fused.sliced(m)
+    a0, a1 = ops.fine_match_maps(ff0, ff1, o['b_ids'], o['i_ids'], o['j_ids'], w, 4, hw_c[1], hw_c[1], mix0, mix1,
+                                 o['mkpts0_c'], o['mkpts1_c'], inp['hw_i'][0] / inp['hw_f'][0], prepared=fused.side_scratch)
+    b0, b1 = ops.fine_match_maps(ff0, ff1, o['b_ids'], o['i_ids'], o['j_ids'], w, 4, hw_c[1], hw_c[1], mix0, mix1,
+                                 o['mkpts0_c'], o['mkpts1_c'], inp['hw_i'][0] / inp['hw_f'][0])
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    if w == 7:        # the reference's own fine keypoints
+        gi, ri, nref = _common_rows(o, g)
+        assert len(gi) == nref
+        assert np.abs(a0.cpu().numpy()[gi, :2] - g['mkpts0_f'][ri, :2]).max() <= FINE_TOL_PX
+        assert np.abs(a1.cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= FINE_TOL_PX
+
+
 def test_cfg5_coarse_against_reference_fixture():
     g = load_golden("cfg5_peaky")                       # 1024x1024 -> L = S = 16384
     inp = case_inputs(g['meta'], "peaky", with_fine=False)
