@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "fm_internal.h"
@@ -165,6 +166,10 @@ __device__ __forceinline__ void ctf_wait(half8 (&w)[2][2], half8 (&b)[2]) {
                : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(b[0]), "+v"(b[1]) : "n"(VM) : "memory");
 }
 template <int VM>
+__device__ __forceinline__ void ctf_wait(half8 (&w)[1][2], half8 (&b)[2]) {
+  asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(b[0]), "+v"(b[1]) : "n"(VM) : "memory");
+}
+template <int VM>
 __device__ __forceinline__ void ctf_wait(half8 (&w)[4][2], half8 (&b)[2]) {
   asm volatile("s_waitcnt vmcnt(%10) lgkmcnt(0)"
                : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]),
@@ -219,7 +224,7 @@ __device__ __forceinline__ void ctf_group(half8 (&wa)[P][NB][2], half8 (&bq)[2][
 // (RB_HI: accumulators NB/2 .. NB-1 take row blocks rb0 + RB_HI + ..: two matrices of one fragment region in one pass)
 template <int NB, int KS, int LO, int RB_HI = 0>
 __device__ __forceinline__ void gemm_stage(const char* __restrict__ frag, int rb0, const void* hi, f32x16 (&acc)[NB], int lane) {
-  constexpr int P = 16 / NB;     // k-steps in flight
+  constexpr int P = NB == 1 ? 8 : 16 / NB;     // k-steps in flight (NB = 1: 8 x 2 KiB per wave, two waves per SIMD)
   constexpr int G = KS / P;
   static_assert(KS % P == 0 && (P == 4 || P == 8) && G >= 2, "step count");
   const char* wn[NB];
@@ -267,17 +272,19 @@ __device__ __forceinline__ void store_planes(char* hi, int lo_off, int rbg, cons
 
 // tokens [tok0, tok0 + 32) of x [L, 256] -> planes (k-steps 0..15) scaled per token by the power of two that fits
 // max(|x| of the token, floor_max); scale and 1 / scale per token -> xsc[32], xinv[32].  Rows beyond L are zero.  Contains two barriers.
+template <int NG = 8>        // NG = threads / 32: 8-channel groups handled side by side
 __device__ __forceinline__ void load_tile(const float* __restrict__ x, int tok0, int L, char* hi, int lo_off, float* red8,
                                           float* xinv, float* xsc, float floor_max, int tid) {
-  // thread -> (token = tid & 31, 8-channel groups (tid >> 5) + 8 i)
+  // thread -> (token = tid & 31, 8-channel groups (tid >> 5) + NG i)
+  constexpr int NI = 32 / NG;
   const int tok = tid & 31, g = tid >> 5;
   const bool ok = tok0 + tok < L;
   const float* row = x + (size_t)(tok0 + tok) * kD;
-  f32x4 v[4][2];
+  f32x4 v[NI][2];
   float m = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = g + 8 * i;
+  for (int i = 0; i < NI; ++i) {
+    const int j = g + NG * i;
     v[i][0] = v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ok) {
       v[i][0] = *reinterpret_cast<const f32x4*>(row + 8 * j);
@@ -290,13 +297,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ x, int tok0,
   __syncthreads();
   m = floor_max;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) m = fmaxf(m, red8[k * 32 + tok]);
+  for (int k = 0; k < NG; ++k) m = fmaxf(m, red8[k * 32 + tok]);
   float s, inv;
   pow2_scale(m, s, inv);
   if (g == 0) { xinv[tok] = inv; xsc[tok] = s; }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = g + 8 * i;                  // channels 8j .. 8j+7 = k-step j >> 1, half j & 1: one 16-byte slot
+  for (int i = 0; i < NI; ++i) {
+    const int j = g + NG * i;                 // channels 8j .. 8j+7 = k-step j >> 1, half j & 1: one 16-byte slot
     half8 h8, l8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -313,7 +320,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ x, int tok0,
 
 // largest |v| of every token over all 256 / 512 channels of the workgroup (this wave holds NB x 16 x 2 of them);
 // contains one barrier.  Returns the token's power-of-two scale and its inverse.
-template <int NB>
+template <int NB, int NW = 4>
 __device__ __forceinline__ void token_scale(const f32x16 (&v)[NB], float* redm, int wv, int lane, float& s, float& inv) {
   float m = 0.f;
 #pragma unroll
@@ -325,6 +332,7 @@ __device__ __forceinline__ void token_scale(const f32x16 (&v)[NB], float* redm, 
   if (lane < 32) redm[wv * 32 + r] = m;
   __syncthreads();
   m = fmaxf(fmaxf(redm[r], redm[32 + r]), fmaxf(redm[64 + r], redm[96 + r]));
+  if constexpr (NW == 8) m = fmaxf(m, fmaxf(fmaxf(redm[128 + r], redm[160 + r]), fmaxf(redm[192 + r], redm[224 + r])));
   pow2_scale(m, s, inv);
 }
 
@@ -428,24 +436,32 @@ __global__ __launch_bounds__(256) void k_ctx_kv_sum(TfArgs a) {
 // [64K, 128K): first Q as float32 [chunk of 8 channels][token][8] (32K) and the planes of the attention output (2 x 16K),
 // later the planes of the MLP hidden layer (2 x 32K); then the reduction scratch.
 constexpr int kXmLo = 32 * 1024, kRegion2 = 64 * 1024, kAttHi = kRegion2 + 32 * 1024, kHidLo = 32 * 1024;
-constexpr int kLayerLdsBytes = 128 * 1024 + (8 * 32 + 3 * 4 * 32 + 2 * 32) * 4;
+constexpr int kLayerWaves = 8;         // waves per k_ctx_layer workgroup (4 or 8; FM_CTX_LAYER_WAVES of a tuning build)
+constexpr int layer_lds_bytes(int nw) { return 128 * 1024 + (2 * nw * 32 + 3 * nw * 32 + 2 * 32) * 4; }
 
-// LayerNorm over the 256 channels of every token: this wave holds 64 of them (2 row blocks x 16 registers x 2 halves)
-__device__ __forceinline__ void layer_norm(f32x16 (&y)[2], const float* __restrict__ gamma, const float* __restrict__ beta,
+// LayerNorm over the 256 channels of every token: this wave holds 32 NB of them (NB row blocks x 16 registers x 2 halves)
+template <int NB, int NW>
+__device__ __forceinline__ float fold_waves(const float* red, int r) {
+  float t = (red[r] + red[32 + r]) + (red[64 + r] + red[96 + r]);
+  if constexpr (NW == 8) t += (red[128 + r] + red[160 + r]) + (red[192 + r] + red[224 + r]);
+  return t;
+}
+template <int NB, int NW>
+__device__ __forceinline__ void layer_norm(f32x16 (&y)[NB], const float* __restrict__ gamma, const float* __restrict__ beta,
                                            float* red0, float* red1, int wv, int lane) {
   const int r = lane & 31, h = lane >> 5;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int g = 0; g < 16; ++g) s += y[i][g];
   s += other_half(s);
   if (h == 0) red0[wv * 32 + r] = s;
   __syncthreads();
-  const float mean = ((red0[r] + red0[32 + r]) + (red0[64 + r] + red0[96 + r])) * (1.0f / kD);
+  const float mean = fold_waves<NB, NW>(red0, r) * (1.0f / kD);
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       y[i][g] -= mean;
@@ -454,30 +470,36 @@ __device__ __forceinline__ void layer_norm(f32x16 (&y)[2], const float* __restri
   v += other_half(v);
   if (h == 0) red1[wv * 32 + r] = v;
   __syncthreads();
-  const float var = ((red1[r] + red1[32 + r]) + (red1[64 + r] + red1[96 + r])) * (1.0f / kD);
+  const float var = fold_waves<NB, NW>(red1, r) * (1.0f / kD);
   const float rstd = 1.0f / __builtin_sqrtf(var + 1e-5f);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int ch = 32 * (2 * wv + i) + 8 * q + 4 * h;
+      const int ch = 32 * (NB * wv + i) + 8 * q + 4 * h;
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + ch), b4 = *reinterpret_cast<const f32x4*>(beta + ch);
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[i][4 * q + e] = __builtin_fmaf(y[i][4 * q + e] * rstd, g4[e], b4[e]);
     }
 }
 
-__global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
+// NW waves per workgroup (4: one per SIMD, each owning a quarter of every layer's output channels; 8: two per SIMD, an
+// eighth each - half the accumulators and half the weight ring per wave, so that one wave's matrix work runs while the
+// other waits for its weight fragments)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_ctx_layer(TfArgs a) {
+  constexpr int NBQ = 8 / NW;        // 32-channel row blocks per wave of a 256-wide output (= heads per wave)
+  constexpr int NBH = 16 / NW;       // ... of the 512-wide hidden layer
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const xm = lds;                                             // MLP input planes
   float* const qf = reinterpret_cast<float*>(lds + kRegion2);       // Q, float32
   char* const at = lds + kAttHi;                                    // attention output planes (hi, +16K lo)
   char* const hb = lds + kRegion2;                                  // hidden planes (hi, +32K lo)
   float* const red8 = reinterpret_cast<float*>(lds + 128 * 1024);
-  float* const red0 = red8 + 8 * 32;
-  float* const red1 = red0 + 4 * 32;
-  float* const redm = red1 + 4 * 32;
-  float* const xinv = redm + 4 * 32;
+  float* const red0 = red8 + 2 * NW * 32;
+  float* const red1 = red0 + NW * 32;
+  float* const redm = red1 + NW * 32;
+  float* const xinv = redm + NW * 32;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const bool s1 = (int)blockIdx.x >= a.tiles0;
   const Seg& sg = a.seg[s1 ? 1 : 0];
@@ -485,26 +507,26 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
   const int b = wg / sg.tiles, tile = wg - b * sg.tiles, tok0 = tile * kTok;
 #ifdef FM_DIAG_CTF
   const long long c0_ = __builtin_amdgcn_s_memtime();
-  float* const dg = a.diag + ((size_t)blockIdx.x * 4 + wv) * 16;
+  float* const dg = a.diag + ((size_t)blockIdx.x * NW + wv) * 16;
 #endif
   const float* const hdr = reinterpret_cast<const float*>(a.w + kFragEnd);
   const float* const ln = hdr + kHdrLn;
   // x and (later) the LayerNorm-ed message share one scale per token, so that the MLP reads one operand: the scale
   // fits the larger of the token's |x| and the bound of the message (known at pack time)
-  load_tile(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xm, kXmLo, red8, xinv, xinv + 32, hdr[kHdrMsgBound], tid);
+  load_tile<2 * NW>(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xm, kXmLo, red8, xinv, xinv + 32, hdr[kHdrMsgBound], tid);
   CTF_STAMP(0);
   const float* const kvp = sg.kv + (size_t)b * kKvFloats;
   const float xi = xinv[r], xscale = xinv[32 + r];
 
   // ---- Q = elu(Wq x) + 1: this wave's two heads, float32 in LDS for the per-head products ----
   {
-    f32x16 acc[2] = {};
-    gemm_stage<2, 16, kXmLo>(a.w + kFragQ, 2 * wv, xm, acc, lane);
+    f32x16 acc[NBQ] = {};
+    gemm_stage<NBQ, 16, kXmLo>(a.w + kFragQ, NBQ * wv, xm, acc, lane);
     CTF_STAMP(1);
     const float f = hdr[kHdrWinv + 0] * xi;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      f32x4* p = reinterpret_cast<f32x4*>(qf) + (size_t)(4 * (2 * wv + i)) * 64 + r * 2 + h;
+    for (int i = 0; i < NBQ; ++i) {
+      f32x4* p = reinterpret_cast<f32x4*>(qf) + (size_t)(4 * (NBQ * wv + i)) * 64 + r * 2 + h;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
@@ -518,10 +540,10 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
   __builtin_amdgcn_s_waitcnt(0xc07f);
   // ---- per head: (Q KV) / (Q . Ksum + eps) * S  (attentions.py:43-46), float32 MFMA; chunk j of 8 channels, step t:
   // half h contracts d = 8j + 4h + t ----
-  f32x16 att[2];
+  f32x16 att[NBQ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int hd = 2 * wv + i;
+  for (int i = 0; i < NBQ; ++i) {
+    const int hd = NBQ * wv + i;
     const f32x4* qa = reinterpret_cast<const f32x4*>(qf) + (size_t)(4 * hd) * 64 + r * 2 + h;
     const f32x4* ka = reinterpret_cast<const f32x4*>(kvp) + (size_t)(4 * hd) * 64 + lane;
     f32x16 o = {};
@@ -543,31 +565,31 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
   }
   CTF_STAMP(2);
   float as, ainv;
-  token_scale<2>(att, redm, wv, lane, as, ainv);
+  token_scale<NBQ, NW>(att, redm, wv, lane, as, ainv);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NBQ; ++i) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) att[i][g] *= as;
-    store_planes(at, kPlane, 2 * wv + i, att[i], lane);
+    store_planes(at, kPlane, NBQ * wv + i, att[i], lane);
   }
   __syncthreads();
   CTF_STAMP(3);
   // ---- merge + LayerNorm 1 -> k-steps 16..31 of the MLP input, in the token's x scale ----
   {
-    f32x16 acc[2] = {};
-    gemm_stage<2, 16, kPlane>(a.w + kFragM, 2 * wv, at, acc, lane);
+    f32x16 acc[NBQ] = {};
+    gemm_stage<NBQ, 16, kPlane>(a.w + kFragM, NBQ * wv, at, acc, lane);
     CTF_STAMP(4);
     const float f = hdr[kHdrWinv + 3] * ainv;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NBQ; ++i)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][g] *= f;
-    layer_norm(acc, ln, ln + kD, red0, red1, wv, lane);       // (its barriers also fence the reads of `at` above)
+    layer_norm<NBQ, NW>(acc, ln, ln + kD, red0, red1, wv, lane);       // (its barriers also fence the reads of `at` above)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBQ; ++i) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][g] *= xscale;
-      store_planes(xm, kXmLo, 8 + 2 * wv + i, acc[i], lane);
+      store_planes(xm, kXmLo, 8 + NBQ * wv + i, acc[i], lane);
     }
   }
   __syncthreads();
@@ -575,50 +597,50 @@ __global__ __launch_bounds__(256) void k_ctx_layer(TfArgs a) {
   // ---- MLP: hidden = relu(W1 [x, msg]) ----
   float hinv;
   {
-    f32x16 acc[4] = {};
-    gemm_stage<4, 32, kXmLo>(a.w + kFragW1, 4 * wv, xm, acc, lane);
+    f32x16 acc[NBH] = {};
+    gemm_stage<NBH, 32, kXmLo>(a.w + kFragW1, NBH * wv, xm, acc, lane);
     CTF_STAMP(6);
     const float f = hdr[kHdrWinv + 4] * xi;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NBH; ++i)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][g] = fmaxf(acc[i][g] * f, 0.f);
     float hs;
-    token_scale<4>(acc, redm, wv, lane, hs, hinv);
+    token_scale<NBH, NW>(acc, redm, wv, lane, hs, hinv);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NBH; ++i) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][g] *= hs;
-      store_planes(hb, kHidLo, 4 * wv + i, acc[i], lane);
+      store_planes(hb, kHidLo, NBH * wv + i, acc[i], lane);
     }
   }
   __syncthreads();
   CTF_STAMP(7);
   // ---- W2 hidden -> LayerNorm 2 -> residual ----
   {
-    f32x16 acc[2] = {};
-    gemm_stage<2, 32, kHidLo>(a.w + kFragW2, 2 * wv, hb, acc, lane);
+    f32x16 acc[NBQ] = {};
+    gemm_stage<NBQ, 32, kHidLo>(a.w + kFragW2, NBQ * wv, hb, acc, lane);
     CTF_STAMP(8);
     const float f = hdr[kHdrWinv + 5] * hinv;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NBQ; ++i)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][g] *= f;
     // the residual's x rows (L2) are requested before the LayerNorm, whose reductions hide the round trip
     const bool row_ok = tok0 + r < sg.L;
     const size_t row_off = ((size_t)b * sg.L + (row_ok ? tok0 + r : 0)) * kD;
-    f32x4 xv[2][4];
+    f32x4 xv[NBQ][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NBQ; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xv[i][q] = *reinterpret_cast<const f32x4*>(sg.x + row_off + 32 * (2 * wv + i) + 8 * q + 4 * h);
-    layer_norm(acc, ln + 2 * kD, ln + 3 * kD, red0, red1, wv, lane);
+      for (int q = 0; q < 4; ++q) xv[i][q] = *reinterpret_cast<const f32x4*>(sg.x + row_off + 32 * (NBQ * wv + i) + 8 * q + 4 * h);
+    layer_norm<NBQ, NW>(acc, ln + 2 * kD, ln + 3 * kD, red0, red1, wv, lane);
     CTF_STAMP(9);
     if (row_ok) {
       float* const orow = sg.out + row_off;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rbg = 2 * wv + i;
+      for (int i = 0; i < NBQ; ++i) {
+        const int rbg = NBQ * wv + i;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 ov;
@@ -638,7 +660,7 @@ size_t ws_floats(int N, int L, int S) {
   const size_t t0 = (size_t)N * ((L + kTok - 1) / kTok), t1 = (size_t)N * ((S + kTok - 1) / kTok);
   size_t n = (t0 + t1) * kKvFloats + 2 * (size_t)N * kKvFloats;
 #ifdef FM_DIAG_CTF
-  n += (t0 + t1) * 4 * 16;
+  n += (t0 + t1) * 8 * 16;
 #endif
   return n;
 }
@@ -713,7 +735,13 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
   static unsigned long long set_kv = 0, set_layer = 0;
   hipError_t e = ensure_dynamic_lds(&k_ctx_kv, kKvLdsBytes, &set_kv);
   if (e != hipSuccess) return (int)e;
-  e = ensure_dynamic_lds(&k_ctx_layer, kLayerLdsBytes, &set_layer);
+  int layer_waves = kLayerWaves;
+#ifdef FM_TUNE_ENV
+  if (const char* ev = getenv("FM_CTX_LAYER_WAVES")) layer_waves = atoi(ev) == 4 ? 4 : 8;
+#endif
+  static unsigned long long set_layer4 = 0;
+  e = layer_waves == 8 ? ensure_dynamic_lds(&k_ctx_layer<8>, layer_lds_bytes(8), &set_layer)
+                       : ensure_dynamic_lds(&k_ctx_layer<4>, layer_lds_bytes(4), &set_layer4);
   if (e != hipSuccess) return (int)e;
 
   const int tl[2] = {(L + kTok - 1) / kTok, (S + kTok - 1) / kTok}, len[2] = {L, S};
@@ -757,7 +785,8 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
       tiles_x += N * g.tiles;
     }
     a.tiles0 = N * a.seg[0].tiles;
-    hipLaunchKernelGGL(k_ctx_layer, dim3(tiles_x), dim3(256), kLayerLdsBytes, st, a);
+    if (layer_waves == 8) hipLaunchKernelGGL(k_ctx_layer<8>, dim3(tiles_x), dim3(512), layer_lds_bytes(8), st, a);
+    else hipLaunchKernelGGL(k_ctx_layer<4>, dim3(tiles_x), dim3(256), layer_lds_bytes(4), st, a);
     for (int s = 0; s < nseg; ++s) cur[img[s]] = out[img[s]];
     return hipGetLastError();
   };
