@@ -1036,6 +1036,7 @@ def extras(a, wl, dev, streams, flops):
             p.step()
             torch.cuda.synchronize()
             p.conf_matrix, p.dense, p.stages = True, True, "coarse"
+            p.fuse_maps = False          # (the coarse stage alone: no fine-map copy on board)
             p.step()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1063,7 +1064,7 @@ def extras(a, wl, dev, streams, flops):
                 "conf_matrix_max_abs_err_sample0": cerr, "error_bar": cbar, "largest_abs_similarity": round(smax, 1),
                 "verified": bool(cerr <= cbar),
                 "note": "coarse stage with data['conf_matrix'] requested (FM_MODE_DENSE | exact screening off): prep, max "
-                        "pass, screening, float16 planes, denominator reduction, dense conf sweep (k_corr<256,3>: the "
+                        "pass, screening, float16 planes, denominator reduction, dense conf sweep (k_dense<256, CONF>: the "
                         "5.9 GB write) + exact rewrite of the entries that matter (k_conf_patch), assignment; GB/s = conf_matrix bytes over the WHOLE stage's time"}
             return res
         guarded("cfg3", cfg3_line)

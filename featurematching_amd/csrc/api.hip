@@ -309,7 +309,7 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
     if (e != hipSuccess) return (int)e;
   }
   if (conf_matrix) {           // dense data['conf_matrix'] on request (one more sweep)
-    e = launch_corr(3, w, base, inv_ct, thr, st, conf_matrix);
+    e = launch_dense(w, base, inv_ct, thr, st, conf_matrix);
     if (e != hipSuccess) return (int)e;
     // ... whose hi/lo-split products carry 22 bits: the entries that matter are rewritten from their exact float32 dot
     // products (the rows' lists of significant entries)

@@ -1,4 +1,7 @@
-// Coarse stage, the correlation sweeps (the hot kernels).
+// Coarse stage, the tile-based correlation sweep of rounds 1-3.  What still runs from here is pass C (MODE 2), the exact
+// re-screening of FM_MODE_EXACT_SCREENING; passes A, B and D have been replaced by k_max_i8 (coarse_max_i8.hip), k_screen /
+// k_dense (coarse_screen.hip, coarse_dense.hip) and k_dense<C, CONF>; their description is kept because pass C shares
+// their structure.
 //
 // Reproduces network/utils/coarse_matching_new.py:64-68 (all-pairs correlation + dual
 // softmax statistics) without ever writing the L x S matrix:
@@ -705,9 +708,9 @@ hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, fl
   a.lt = log2f(thr) - (mode == 2 ? 2e-4f : 0.f);   // pass C compares rounded log-softmax values: small guard
   const int blocks = w.N * a.splits * w.panels;
 #define FM_CORR_CASE(CC)                                                     \
-  case CC: return mode == 3 ? launch_corr_t<CC, 3>(a, blocks, st)            \
-                 : mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)          \
-                 : hipErrorInvalidValue;       /* mode 1 (the dense sum sweep) is k_dense, coarse_dense.hip */
+  case CC: return mode == 2 ? launch_corr_t<CC, 2>(a, blocks, st)            \
+                 : hipErrorInvalidValue;       /* mode 1 (the dense sum sweep) and mode 3 (the dense conf_matrix) are \
+                                                  k_dense / k_dense<C, CONF>, coarse_dense.hip */
   switch (w.C) {
     FM_CORR_CASE(64)
     FM_CORR_CASE(128)

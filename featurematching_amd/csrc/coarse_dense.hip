@@ -40,6 +40,7 @@ struct DenseArgs {
   int* cand_count; int* cand_j; float* cand_x; int* ccand_count; int* ccand_i; float* ccand_x;   // the dense kernel's lists
   unsigned* flags;
   float* diag;                          // diagnostic build: stamp buffer (the screening kernel's cand_x region)
+  float* conf;                          // CONF variant: the dense [N, L, S] conf_matrix (nmr / nmc then hold the log-softmax offsets)
   int L, S, Lp, Sp, panels, units, splits, units_per_split, slots, pgroup;
   float k, lt;
 };
@@ -70,7 +71,13 @@ __device__ __forceinline__ float halves_sum_d(float v) {      // lane l + lane l
 template <typename T>
 __device__ __forceinline__ unsigned lds_addr_d(T* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) T*)p; }
 
-template <int C>
+// CONF (round 4): the same sweep writes data['conf_matrix'] (coarse_matching_new.py:68,70) for EVERY sample instead of
+// forming sums and candidates - conf = exp2(k x + nmr2_i) * exp2(k x + nmc2_j) with the log-softmax offsets of
+// k_reduce_sums, the arithmetic of k_corr<C,3>, which it replaces (2.50 ms for the 5.9 GB of a 64-pair batch: a two-deep
+// tile ring whose epilogue - and with it every store - ran behind the MFMA chain).  The epilogue slice of a register is
+// two fused multiply-adds, two exp2, one multiply and ONE store (a scalar row base + a per-lane offset: 32 consecutive
+// floats of two rows per instruction), spread over the next unit's k-steps like the sums' slices.
+template <int C, bool CONF = false>
 __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   constexpr int KSTEPS = C / 16;
   constexpr int PLANE = KSTEPS * 1024;              // bytes of one plane (hi or lo) of a unit
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   __shared__ int s_qkey[8 * kDenseQueue];           // wave-private candidate queue: (col << 5) | local row
   __shared__ float s_qx[8 * kDenseQueue];
 
-  if (*a.dense_units == 0) return;                  // uniform: the screening kernel handled every sample
+  if (!CONF && *a.dense_units == 0) return;         // uniform: the screening kernel handled every sample
 #ifdef FM_DIAG_CLOCK       // diagnostic build only: shader-clock stamps per phase of every wave (tools/diag_clock.py)
   const unsigned long long dg0 = __builtin_amdgcn_s_memtime(), dgr0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long dg_chain = 0, dg_bar = 0, dg_pro = 0, dg_loop_end = 0;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   const int split = kk / pcount;
   const int panel = pg * a.pgroup + (kk - split * pcount);
   const int u0 = split * a.units_per_split, u1 = min(u0 + a.units_per_split, a.units);
-  if (a.dense_cnt[b] == 0) return;                  // uniform: this sample was served by the screening kernel
+  if (!CONF && a.dense_cnt[b] == 0) return;         // uniform: this sample was served by the screening kernel
   const float inv_sc = a.f16inv[b];                 // the planes carry exact power-of-two scales (k_prep_f16)
   const float kq = a.k * inv_sc;                    // accumulator -> log2-domain similarity
   const char* plane_hi = reinterpret_cast<const char*>(a.hi1 + (long)b * a.Sp * C);
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   }
   float* colout = a.colpart + ((long)b * a.panels + panel) * a.Sp;
   auto fold_columns = [&](int u) {                  // the 8 waves' sums of unit u's 32 columns, in wave order
-    if (wv != (u & 7) || lane >= 32) return;
+    if (CONF || wv != (u & 7) || lane >= 32) return;
     const unsigned ad = colred_a + (((u - u0) % 3) * 8 * 32 + lane) * 4;
     float pv[8];
 #pragma unroll
@@ -206,6 +213,20 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
     float cstat = 0.f;
     unsigned bm = 0;                                  // this lane's candidate registers of unit uc: bit 15 - g
     const float kqv = kq, ltv = a.lt;
+    // CONF: unit uc's tile of the matrix - a scalar base (row wrow0, column 32 uc), the lane's own offset (row 4 h, column
+    // r), the row pitch in bytes; a (wave, unit) that touches the matrix's edge stores behind the chain, predicated
+    const char* conf_base = nullptr;
+    long conf_pitch = 0;
+    unsigned conf_voff = 0;
+    bool conf_full = false;
+    if constexpr (CONF) {
+      if (DC) {
+        conf_pitch = (long)a.S * 4;
+        conf_base = reinterpret_cast<const char*>(a.conf + ((long)b * a.L + wrow0) * a.S + (long)uc * 32);
+        conf_voff = (unsigned)((4 * h * a.S + r) * 4);
+        conf_full = !row_edge && uc * 32 + 32 <= a.S;
+      }
+    }
     const unsigned base = ring_a + ((un - u0) % kDenseRing) * UNIT_BYTES + lane * 16;
     constexpr int PF = KSTEPS < 3 ? KSTEPS - 1 : 2;      // B-fragment read-ahead (k-steps): LDS latency under 8 waves' reads
     constexpr int RING = PF + 1;                         // is ~300 cycles, a k-step of this wave ~150
@@ -261,6 +282,24 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
           // Candidates (both terms > thr) are marked on the spot: v_cmp + v_addc shift the hit into a per-lane bit mask
           // (bit 15 - g).  A filter + rescan of the 16 registers took ~1k cycles whenever ANY of the workgroup's 8 waves
           // entered it - nearly every unit - and the per-unit barrier made all of them wait: 13k of 82k cycles.
+          if constexpr (CONF) {
+            // conf of register g's entry and its store: rows (g & 3) + 8 (g >> 2) [+ 4 for the upper half], column r
+            float t1, t2;
+            const char* rowbase = conf_base + (long)((g & 3) + 8 * (g >> 2)) * conf_pitch;      // (wave-uniform: scalar)
+            if (conf_full) {
+              asm volatile(
+                  "v_fma_f32 %[t1], %[x], %[kq], %[nm]\n\t"
+                  "v_fma_f32 %[t2], %[x], %[kq], %[nmc]\n\t"
+                  "v_exp_f32 %[t1], %[t1]\n\t"
+                  "v_exp_f32 %[t2], %[t2]\n\t"
+                  "s_nop 0\n\t"
+                  "v_mul_f32 %[t1], %[t1], %[t2]\n\t"
+                  "global_store_dword %[vo], %[t1], %[sb]"
+                  : [t1] "=&v"(t1), [t2] "=&v"(t2)
+                  : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [vo] "v"(conf_voff), [sb] "s"(rowbase)
+                  : "memory");
+            }
+          } else {
           float t1, t2, t3;
           asm volatile(
               "v_fma_f32 %[t1], %[x], %[kq], %[nm]\n\t"
@@ -277,6 +316,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
               : [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [bm] "+v"(bm), [rs] "+v"(rstat[g]), [cs] "+v"(cstat)
               : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [lt] "v"(ltv)
               : "vcc");
+          }
         }
       }
 #endif
@@ -285,7 +325,19 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
     };
     kstep(kstep, std::integral_constant<int, 0>{});
 #undef issue
-    if (DC) {
+    if constexpr (CONF) {
+      if (DC && !conf_full && wrow0 < a.L) {        // the matrix's edge: predicated stores (x = -inf beyond it)
+        const int col = uc * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int row = wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          const float cf = __builtin_amdgcn_exp2f(__builtin_fmaf(accC[g], kqv, nmsel[g])) *
+                           __builtin_amdgcn_exp2f(__builtin_fmaf(accC[g], kqv, nmc_c));
+          if (row < a.L && col < a.S) a.conf[((long)b * a.L + row) * a.S + col] = cf;
+        }
+      }
+    }
+    if (DC && !CONF) {
       cstat = halves_sum_d(cstat);                  // this wave's 32 rows of column r
       if (h == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(colred_a + ((((uc - u0) % 3) * 8 + wv) * 32 + r) * 4), "v"(cstat) : "memory");
       {
@@ -357,6 +409,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
 #ifdef FM_DIAG_CLOCK
   dg_loop_end = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (CONF) return;
   // ---- the parked candidates -> the per-row / per-column slot lists: one entry per lane; the slot reservation (a
   // returning atomic: one memory round trip) is issued here and consumed behind the row reduction below ----
   int q_pos = -1, q_cpos = -1, q_key = 0;
@@ -401,11 +454,12 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
 #endif
 }
 
-hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st) {
+hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st, float* conf) {
   DenseArgs a;
+  a.conf = conf;
   a.hi0 = (const _Float16*)(base + w.hi0); a.lo0 = (const _Float16*)(base + w.lo0);
   a.hi1 = (const _Float16*)(base + w.hi1); a.lo1 = (const _Float16*)(base + w.lo1);
-  a.nmr = (const float*)(base + w.nmr); a.nmc = (const float*)(base + w.nmc);
+  a.nmr = (const float*)(base + (conf ? w.nmr2 : w.nmr)); a.nmc = (const float*)(base + (conf ? w.nmc2 : w.nmc));
   a.rowpart = (float*)(base + w.rowB); a.colpart = (float*)(base + w.colB);
   a.dense_cnt = (const int*)(base + w.dense_cnt);
   a.dense_units = &((const Scalars*)(base + w.scalars))->dense_units;
@@ -432,10 +486,16 @@ hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, 
   hipError_t e = hipSuccess;
 #define FM_DENSE_CASE(CC)                                                                        \
   case CC: {                                                                                     \
-    static unsigned long long lds_set = 0;                                                       \
-    e = ensure_dynamic_lds(&k_dense<CC>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set);           \
-    if (e != hipSuccess) return e;                                                               \
-    hipLaunchKernelGGL(k_dense<CC>, dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);   \
+    static unsigned long long lds_set = 0, lds_set_c = 0;                                        \
+    if (conf) {                                                                                  \
+      e = ensure_dynamic_lds(&k_dense<CC, true>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set_c); \
+      if (e != hipSuccess) return e;                                                             \
+      hipLaunchKernelGGL((k_dense<CC, true>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);   \
+    } else {                                                                                     \
+      e = ensure_dynamic_lds(&k_dense<CC, false>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set);  \
+      if (e != hipSuccess) return e;                                                             \
+      hipLaunchKernelGGL((k_dense<CC, false>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);  \
+    }                                                                                            \
     break;                                                                                       \
   }
   switch (w.C) {
