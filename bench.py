@@ -102,13 +102,18 @@ class Pair:
         # partner is a textureless cell in 'mixed' data (the textureless cells themselves - near-zero descriptors - are
         # certified dead by the sparse sum kernel and cost nothing); 'peaky' takes the common 4 launches
         self.dense = dist != "peaky"
-        # ... and in 'mixed' data those peakless rows sit next to peaked ones: more candidates than slots until the exact
-        # screening pass (FM_MODE_EXACT_SCREENING) has the denominators
-        self.exact = dist == "mixed"
+        # ... and in 'mixed' data those peakless rows sit next to peaked ones: more candidates than the default 8 slots.  The
+        # general answer is the exact screening pass (FM_MODE_EXACT_SCREENING: a second full sweep, k_corr<C,2>, 37 us);
+        # the caller that knows its data gets the same matches with 16 candidate slots and the int8 step from the images'
+        # true maxima (FM_MODE_EXACT_STEP: margins 1.5x narrower, so ~7 instead of ~20 entries of a peakless row pass the
+        # dense kernel's candidate test): 13.1 k against 11.3 k pairs/s (tools/time_flat.py slots; a row that still
+        # overflows reports FM_E_CANDIDATES - nothing is dropped silently)
+        self.exact = False
         # ... and the caller that knows ALL its samples are like that (what FM_DEV_ALL_DENSE tells ops.coarse_match's mode
         # memory after the first call) passes the FM_MODE_FLAT hint: no screening sweep, planes from the prep kernel
         self.flat = dist != "peaky"
-        self.slots = None                # candidate slots per row / column (None: fm_default_cand_slots(thr))
+        self.slots = 16 if dist == "mixed" else None      # candidate slots per row / column (None: fm_default_cand_slots(thr))
+        self.exact_step = dist == "mixed"                 # FM_MODE_EXACT_STEP: the int8 step from the images' true maxima
         # NCHW float32 maps on the maps path: image 1's channels-last copy rides in the assignment kernel's launch
         # (fm_coarse_match_maps) instead of being fm_fine_match_maps' first launch
         self.fuse_maps = layout == "nchw" and fine_path == "maps"
@@ -124,6 +129,7 @@ class Pair:
         else:
             buf = ops.coarse_match_async(self.f0, self.f1, self.hw_c, self.hw_c, self.hw_i[0] / self.hw_c[0],
                                          cap=self.cap, cand_slots=self.slots, dense=self.dense, exact_screening=self.exact,
+                                         exact_step=self.exact_step,
                                          conf_matrix=self.conf_matrix, flat=(self.flat and self.dense and not self.conf_matrix),
                                          side_map=(self.ff1 if self.fuse_maps else None),
                                          side_scratch=(self.scratch if self.fuse_maps else None),
@@ -427,7 +433,7 @@ def cpu_baseline(wl, window, seed, budget_s=18.0):
 
 
 def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, check=True, layout="nchw", fine_path="maps",
-                flat_hint=True, slots=None, exact=None):
+                flat_hint=True, slots=None, exact=None, exact_step=False):
     """Pairs/s of the same step for another workload / distribution / pairs per launch: `nsets` resident input sets
     (generated on the device) cycled through on `nstreams` streams by hipGraph replay, `steps` timed steps.  Returns
     (pairs/s, verification of the first input set's last step against the oracle, matches per pair)."""
@@ -437,7 +443,9 @@ def stream_rate(wl, window, dev, dist, batch, nstreams, steps=240, nsets=6, chec
         pairs.append(Pair(wb, 5000 + 31 * p, window, dev, dist, share=pairs[p % nstreams] if p >= nstreams else None,
                           device_data=True, layout=layout, fine_path=fine_path))
         pairs[-1].flat = pairs[-1].flat and flat_hint
-        pairs[-1].slots = slots
+        if slots is not None:
+            pairs[-1].slots = slots
+        pairs[-1].exact_step = pairs[-1].exact_step or exact_step
         if exact is not None:
             pairs[-1].exact = exact
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
@@ -1028,7 +1036,8 @@ def extras(a, wl, dev, streams, flops):
             "'peaky' descriptors with 20 % near-zero cells in both images (textureless regions, missing partners): the "
             "near-zero rows / columns are certified dead by the sparse sum kernel (||a||_1 max|b| / (C T) bounds their "
             "softmax terms below thr) and cost nothing; the cells whose partner is missing are rows without a peak and "
-            "send the sample through the dense sum kernel and the exact screening pass")))
+            "send the sample through the dense sum kernel (FM_MODE_FLAT, 16 candidate slots, FM_MODE_EXACT_STEP instead of "
+            "the exact screening pass)")))
 
         def cfg3_line():
             w3 = dict(WORKLOADS["cfg3"])

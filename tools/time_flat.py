@@ -36,11 +36,11 @@ def slots_experiment():
     """'mixed' data under the flat hint: more candidate slots instead of the exact screening pass"""
     dev = torch.device("cuda:0")
     wl = bench.WORKLOADS["cfg2"]
-    for slots, exact in ((8, True), (16, False), (32, False), (64, False), (16, True)):
+    for slots, exact, es in ((8, True, False), (8, False, True), (8, True, True), (16, False, True), (8, True, False), (8, False, True)):
         try:
-            r, ver, _ = bench.stream_rate(wl, 5, dev, "mixed", 1, 4, steps=400, nsets=8, slots=slots, exact=exact)
-            r1, _, _ = bench.stream_rate(wl, 5, dev, "mixed", 1, 1, steps=200, nsets=4, slots=slots, exact=exact, check=False)
-            print(f"  mixed slots {slots} exact {exact}: 4 streams {r:9.1f}, 1 stream {r1:9.1f}, verified {ver['ok'] if ver else None}", flush=True)
+            r, ver, _ = bench.stream_rate(wl, 5, dev, "mixed", 1, 4, steps=400, nsets=8, slots=slots, exact=exact, exact_step=es)
+            r1, _, _ = bench.stream_rate(wl, 5, dev, "mixed", 1, 1, steps=200, nsets=4, slots=slots, exact=exact, exact_step=es, check=False)
+            print(f"  mixed slots {slots} exact screening {exact} exact step {es}: 4 streams {r:9.1f}, 1 stream {r1:9.1f}, verified {ver['ok'] if ver else None}", flush=True)
         except Exception as e:
             print(f"  mixed slots {slots} exact {exact}: {e!r}", flush=True)
 
