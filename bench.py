@@ -598,7 +598,16 @@ def self_launch(ngpus, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries ONE JSON line: whatever else the ranks' libraries write there (gloo's connection notes, ...) goes
+    # to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        if line.startswith("{") and line.rstrip().endswith("}"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def init_ranks(world, backend, dev=None):

@@ -123,9 +123,9 @@ def test_bench_launches_its_own_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step", "--steps", "4",
                         "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
+    # stdout is ONE JSON line and nothing else (what the ranks' libraries print - gloo's connection notes - is on stderr)
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout
+    out = json.loads(r.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["stub"] is True and out["value"] is None
     assert out["gather_ms"] > 0
     # two ranks, pair blocks [0,1) and [1,2): 50 + 57 stand-in records, gathered on every rank in pair order
