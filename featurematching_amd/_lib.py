@@ -76,6 +76,7 @@ SIGNATURES = {
     "fm_fine_tf_pack_weights": (_i, [_p, _p, _p, _p]),
     "fm_fine_transformer": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),
     "fm_fine_transformer_status": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "fm_fine_transformer_start": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p]),
     "fm_epipolar_errors": (_i, [_p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     "fm_fine_match": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p]),
     "fm_fine_maps_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),

@@ -413,7 +413,8 @@ template <int WW, int NW>
 __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const float* win1, int m_max,
                                                       const int32_t* __restrict__ d_count, const half8* __restrict__ wpack,
                                                       const float* __restrict__ lnp, float* out0, float* out1,
-                                                      const int32_t* __restrict__ pack_status, int32_t* d_status) {
+                                                      const int32_t* __restrict__ pack_status, int32_t* d_status,
+                                                      int start_e2, int32_t* d_lowered) {
   extern __shared__ __attribute__((aligned(16))) char lds[];      // region A (64 KiB), region B (64 KiB)
   __shared__ float ksum[NW][64];
   const int lane = threadIdx.x & 63;
@@ -438,7 +439,9 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
   // 16x smaller one (the calls read win0 / win1 first and run in place on the outputs afterwards, so a restart is
   // clean).  The waves of a workgroup share the staged weights and their barriers: all of them repeat the pass when any
   // of them has to, the ones that were inside the range with their own scale (and the same result).
-  int e2 = (int)kLog2ActScale;          // (scalar registers: the exponent and the three floats made from it)
+  // (the first attempt's scale: 2^8 unless the caller knows better - fm_fine_transformer_start: a module that saw its
+  // matches lower the scale in the previous call starts there, and the repeated passes are gone)
+  int e2 = start_e2;                    // (scalar registers: the exponent and the three floats made from it)
   // (every pass in which some wave lowers its scale is followed by another: at most 3 lowerings per wave)
 #pragma unroll 1
   for (;;) {
@@ -491,6 +494,9 @@ __global__ __launch_bounds__(NW * 64) void k_fine_tf(const float* win0, const fl
   // an operand left the float16 range (or is not finite), or a packed weight did (|w| >= 16): the results of this
   // match are not trustworthy - report it instead of clamping silently
   if (d_status && __any(!(amax <= 65504.f)) && lane == 0) atomicOr(d_status, (int)FM_DEV_RANGE);
+  // how far below the starting scale this match ended (0, 4, 8, 12): only waves that lowered report (none in the steady
+  // state of a caller that feeds the value back)
+  if (d_lowered && e2 < start_e2 && lane == 0) atomicMax(d_lowered, start_e2 - e2);
   if (d_status && blockIdx.x == 0 && threadIdx.x == 0 && *pack_status) atomicOr(d_status, (int)FM_DEV_RANGE);
 }
 
@@ -559,6 +565,14 @@ extern "C" int fm_fine_tf_pack_weights(const float* const* layer0, const float* 
 extern "C" int fm_fine_transformer_status(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW,
                                           int Cf, const void* packed, float* out0, float* out1, int32_t* d_status,
                                           void* stream) {
+  return fm_fine_transformer_start(win0, win1, m_max, d_count, WW, Cf, packed, out0, out1, d_status, (int)kLog2ActScale, nullptr,
+                                   stream);
+}
+
+extern "C" int fm_fine_transformer_start(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW,
+                                         int Cf, const void* packed, float* out0, float* out1, int32_t* d_status,
+                                         int start_log2_scale, int32_t* d_lowered, void* stream) {
+  if (start_log2_scale != 8 && start_log2_scale != 4 && start_log2_scale != 0 && start_log2_scale != -4) return FM_E_UNSUPPORTED;
   if (m_max == 0) return FM_OK;
   if (!win0 || !win1 || !packed || !out0 || !out1) return FM_E_NULL;
   if (m_max < 0) return FM_E_SHAPE;
@@ -574,11 +588,11 @@ extern "C" int fm_fine_transformer_status(const float* win0, const float* win1, 
   if (WW == 49) {
     hipError_t e = ensure_dynamic_lds(&k_fine_tf<49, NW>, smem, &set49);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_fine_tf<49, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1, pstat, d_status);
+    hipLaunchKernelGGL((k_fine_tf<49, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1, pstat, d_status, start_log2_scale, d_lowered);
   } else {
     hipError_t e = ensure_dynamic_lds(&k_fine_tf<25, NW>, smem, &set25);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_fine_tf<25, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1, pstat, d_status);
+    hipLaunchKernelGGL((k_fine_tf<25, NW>), dim3(blocks), dim3(NW * 64), smem, st, win0, win1, m_max, d_count, frag, ln, out0, out1, pstat, d_status, start_log2_scale, d_lowered);
   }
   return (int)hipGetLastError();
 }

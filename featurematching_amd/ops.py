@@ -708,15 +708,21 @@ def pack_fine_transformer(state_dict: dict, device) -> torch.Tensor:
 
 
 def fine_transformer(win0: torch.Tensor, win1: torch.Tensor, packed: torch.Tensor, count: Optional[torch.Tensor] = None,
-                     status: Optional[torch.Tensor] = None):
+                     status: Optional[torch.Tensor] = None, start_scale: int = 8):
     """The fine context layers (network/net.py:79-80) on the windows [M, WW, 64] of both images, WW in {25, 49}.
     `status` = a zeroed int32 device tensor: the kernel ORs FM_DEV_RANGE into element 0 when a value did not fit its
-    float16 operand halves at any of its activation scales (see fmatch.h) - the outputs must then be discarded."""
+    float16 operand halves at any of its activation scales (see fmatch.h) - the outputs must then be discarded; with two
+    elements, element 1 receives by how much the matches went below `start_scale` (log2 of the first attempt's activation
+    scale: 8, 4, 0 or -4; fm_fine_transformer_start)."""
     lib = _lib.load()
     win0, win1 = _f32c(win0, "win0"), _f32c(win1, "win1")
     m, ww, cf = win0.shape
     out0, out1 = torch.empty_like(win0), torch.empty_like(win1)
     if m:
-        _lib.check(lib.fm_fine_transformer_status(_ptr(win0), _ptr(win1), m, _ptr(count), ww, cf, _ptr(packed), _ptr(out0),
-                                                  _ptr(out1), _ptr(status), _stream(win0.device)), "fm_fine_transformer")
+        lowered = None
+        if status is not None and status.numel() > 1:
+            lowered = C.c_void_p(status.data_ptr() + 4)
+        _lib.check(lib.fm_fine_transformer_start(_ptr(win0), _ptr(win1), m, _ptr(count), ww, cf, _ptr(packed), _ptr(out0),
+                                                 _ptr(out1), _ptr(status), int(start_scale), lowered, _stream(win0.device)),
+                   "fm_fine_transformer")
     return out0, out1

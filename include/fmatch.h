@@ -374,6 +374,15 @@ int fm_fine_transformer(const float* win0, const float* win1, int m_max, const i
                         const void* packed, float* out0, float* out1, void* stream);
 int fm_fine_transformer_status(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
                                const void* packed, float* out0, float* out1, int32_t* d_status, void* stream);
+/* The same with the FIRST attempt's activation scale chosen by the caller: start_log2_scale in {8, 4, 0, -4} (8 = the
+ * default above).  d_lowered ([dev] int32, zeroed by the caller, or NULL) receives by how much the matches of this call
+ * went below it (0, 4, 8 or 12 = the largest lowering of any match): a caller that feeds start - lowered back into its
+ * next call on similar data (the Python module does) no longer pays for the repeated passes - 0.74 -> 0.45 ms at 3769
+ * matches of a random-weight network whose activations leave 2^8 in nearly every workgroup.  A smaller starting scale
+ * costs the precision a lowering costs (see above), nothing else. */
+int fm_fine_transformer_start(const float* win0, const float* win1, int m_max, const int32_t* d_count, int WW, int Cf,
+                              const void* packed, float* out0, float* out1, int32_t* d_status, int start_log2_scale,
+                              int32_t* d_lowered, void* stream);
 
 /*
  * Match post-processing (the step after the path; utils/metrics.py:33-81): squared symmetric epipolar distance

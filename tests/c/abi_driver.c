@@ -63,6 +63,7 @@ static __typeof__(fm_epipolar_errors)* p_fm_epipolar_errors;
 static __typeof__(fm_coarse_match_maps)* p_fm_coarse_match_maps;
 static __typeof__(fm_read_count_info)* p_fm_read_count_info;
 static __typeof__(fm_debug_launch_flat)* p_fm_debug_launch_flat;
+static __typeof__(fm_fine_transformer_start)* p_fm_fine_transformer_start;
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s libfmatch_hip.so\n", argv[0]); return 2; }
@@ -76,7 +77,7 @@ int main(int argc, char** argv) {
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
   RESOLVE(fm_coarse_tf_packed_bytes); RESOLVE(fm_coarse_tf_workspace_bytes); RESOLVE(fm_coarse_tf_pack_weights);
   RESOLVE(fm_coarse_transformer);
-  RESOLVE(fm_coarse_match_maps); RESOLVE(fm_read_count_info); RESOLVE(fm_debug_launch_flat);
+  RESOLVE(fm_coarse_match_maps); RESOLVE(fm_read_count_info); RESOLVE(fm_debug_launch_flat); RESOLVE(fm_fine_transformer_start);
 
   EXPECT(p_fm_version(), FM_VERSION);
   for (int s = FM_E_INTERNAL; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
@@ -228,6 +229,10 @@ int main(int argc, char** argv) {
   /* FM_LAYOUT_NCHW_PREPARED: the scratch a fm_coarse_match_maps call filled is mandatory; float32 maps only */
   EXPECT(p_fm_fine_match_maps(f, f, FM_LAYOUT_NCHW_PREPARED, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_NULL);
   EXPECT(p_fm_fine_match_maps_dtype(f, f, FM_F16, FM_LAYOUT_NCHW_PREPARED, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, (void*)f, f, f, NULL), FM_E_UNSUPPORTED);
+  /* fine context layers: the caller's starting scale is one of the kernel's four */
+  EXPECT(p_fm_fine_transformer_start(f, f, 4, NULL, 49, 64, (const void*)f, f, f, NULL, 6, NULL, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_fine_transformer_start(f, f, 0, NULL, 49, 64, (const void*)f, f, f, NULL, 4, NULL, NULL), FM_OK);      /* M == 0 */
+  EXPECT(p_fm_fine_transformer_start(NULL, f, 4, NULL, 49, 64, (const void*)f, f, f, NULL, 4, NULL, NULL), FM_E_NULL);
   /* training surface: argument checks of the dual-softmax entries */
   {
     const float* pr = NULL; const float* pc = NULL; const float* sr = NULL; const float* sc = NULL; int qr = 0, qc = 0;

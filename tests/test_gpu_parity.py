@@ -1195,6 +1195,37 @@ def test_fine_transformer_follows_the_data_and_reports_what_it_cannot_hold(gain,
     assert (a0.cpu() - r0).abs().max().item() <= tol and (a1.cpu() - r1).abs().max().item() <= tol
 
 
+def test_fine_transformer_starts_where_the_previous_call_ended():
+    """fm_fine_transformer_start: windows whose activations leave the first scale (2^8) make the kernel repeat its passes
+    at 2^4; the call reports the lowering, the module starts the next call there (no lowering reported any more) and the
+    outputs of both calls agree with the oracle within the tolerance of a lowered scale; an explicit start below what
+    the data needs only costs precision."""
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    ww, m = 49, 600
+    wnp = synth.transformer_weights(5, 64, 2)
+    wts = {k: torch.as_tensor(v) for k, v in wnp.items()}
+    tf = LocalFeatureTransformer(dict(d_model=64, nhead=8, layer_names=['self', 'cross'], attention='linear')).to(DEV).eval()
+    tf.load_state_dict(wts)
+    x0 = (120.0 * synth.normal(11, 1, (m, ww, 64))).astype(np.float32)     # beyond 255.9: every match lowers its scale
+    x1 = (120.0 * synth.normal(11, 2, (m, ww, 64))).astype(np.float32)
+    r0, r1 = orc.local_feature_transformer(x0, x1, wnp, 8, ['self', 'cross'])
+    t0, t1 = torch.as_tensor(x0, device=DEV), torch.as_tensor(x1, device=DEV)
+    tol = 2e-5 * max(1.0, float(r0.abs().max()))
+    a0, a1 = tf(t0, t1)
+    first = tf.last_status.tolist()
+    assert first[0] == 0 and first[1] in (4, 8, 12) and tf._fine_start == 8 - first[1]
+    b0, b1 = tf(t0, t1)
+    assert tf.last_status.tolist() == [0, 0]                # started where the first call ended: nothing to lower
+    for g in (a0, a1, b0, b1):
+        assert torch.isfinite(g).all()
+    assert (a0.cpu() - r0).abs().max().item() <= tol and (b0.cpu() - r0).abs().max().item() <= tol
+    assert (a1.cpu() - r1).abs().max().item() <= tol and (b1.cpu() - r1).abs().max().item() <= tol
+    # the C entry point refuses a scale it does not have
+    packed = ops.pack_fine_transformer(wts, DEV)
+    with pytest.raises(_lib.FMatchError):
+        ops.fine_transformer(t0, t1, packed, start_scale=6)
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf")])
 def test_fine_transformer_reports_non_finite_windows(bad):
     """fmatch.h: NaN / Inf activations are reported as FM_DEV_RANGE.  NaN never wins the kernel's running maximum, so
@@ -1219,7 +1250,7 @@ def test_fine_transformer_reports_non_finite_windows(bad):
     assert tf.range_fallbacks == 1 and not torch.isfinite(a0[4]).all() and torch.isfinite(a0[ok]).all()
     tf.check_range = False
     tf(t0, t1)
-    assert tf.range_fallbacks == 1 and int(tf.last_status.item()) & _lib.FM_DEV_RANGE
+    assert tf.range_fallbacks == 1 and int(tf.last_status[0].item()) & _lib.FM_DEV_RANGE
 
 
 def test_fine_transformer_weights_beyond_the_scale_are_reported_and_large_sums_are_held():
