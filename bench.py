@@ -576,6 +576,10 @@ def context_layer_times(wl, dev, iters=10):
     res["fine"] = {"kernel": "k_fine_tf<49> (hi/lo-split f16 MFMA, 32-token slices)", "matches": mm, "ms": round(t_f, 4),
                    "torch_module_ms": round(t_f_t, 4)}
     res["fine"]["range_fallbacks"] = int(m.fine.range_fallbacks)
+    res["fine"]["start_log2_scale"] = int(getattr(m.fine, "_fine_start", 8))
+    res["fine"]["note"] = ("the module starts a call at the activation scale the previous one ended at "
+                           "(fm_fine_transformer_start): this random-weight network's activations leave 2^8 in nearly every "
+                           "workgroup, and the first call's repeated passes (0.73 ms) are gone from the steady state")
     res["forward_features"] = {"ms": round(t_all, 4), "image_pairs_per_s": round(1e3 * n / t_all, 1),
                                "range_fallbacks": int(m.fine.range_fallbacks),
                                "note": "net.forward after the backbone: coarse context layers -> coarse matching -> "
