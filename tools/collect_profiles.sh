@@ -38,6 +38,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/borderline -- python 
 echo "borderline done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mixed -- python bench.py --dist mixed --steps 100 --warmup 10 --skip-cpu --quick --streams 1 --pairs 1 --no-graph > $O/mixed.json 2> $O/mixed.err
 echo "mixed done"
+# (5c) BASELINE config 3's HBM-bound mode: the coarse stage with data['conf_matrix'] at 64 pairs (the 5.9 GB write)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/conf -- python tools/time_conf_matrix.py > $O/conf.log 2> $O/conf.err
+echo "conf done"
 # (6) the context layers either side of the path: kernel time, then matrix-core counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ctx -- python tools/time_matcher.py > $O/ctx.log 2> $O/ctx.err
 echo "ctx done"

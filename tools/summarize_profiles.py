@@ -8,6 +8,7 @@ committed under profiles/:
   profiles/<round>_bench_cfg2_serial_kernel_stats.csv    same step, one stream, eager (no overlap)
   profiles/<round>_bench_cfg3_kernel_stats.csv, ..._cfg5_...
   profiles/<round>_bench_cfg2_borderline_serial_kernel_stats.csv, ..._mixed_...   flat-similarity data (dense path)
+  profiles/<round>_conf_matrix_cfg3_kernel_stats.csv     tools/time_conf_matrix.py: the coarse stage writing data['conf_matrix'] for 64 pairs
   profiles/<round>_pmc_fetch_write_cfg2.json             FETCH_SIZE / WRITE_SIZE per launch and kernel (KiB)
   profiles/<round>_pmc_sq_cfg2.csv, ..._cfg3.csv         matrix-core busy / wait fractions per kernel
   profiles/<round>_forward_features_kernel_stats.csv     rocprofv3 --stats of tools/time_matcher.py (net.forward tail)
@@ -69,6 +70,7 @@ def main():
     stats("cfg5", f"{rnd}_bench_cfg5_kernel_stats.csv")
     stats("borderline", f"{rnd}_bench_cfg2_borderline_serial_kernel_stats.csv")
     stats("mixed", f"{rnd}_bench_cfg2_mixed_serial_kernel_stats.csv")
+    stats("conf", f"{rnd}_conf_matrix_cfg3_kernel_stats.csv")
 
     fw = {}
     for tag in ("fetch", "write"):
