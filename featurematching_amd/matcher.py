@@ -112,11 +112,19 @@ class Matcher(nn.Module):
         feat_c0 = feat_c0.flatten(2).transpose(1, 2).contiguous()       # n c h w -> n (h w) c
         feat_c1 = feat_c1.flatten(2).transpose(1, 2).contiguous()
         feat_c0, feat_c1 = self.coarse(feat_c0, feat_c1)                # :74
+        self.fine_preprocess.prepare(feat_c0, feat_c1)                  # (match-independent GEMMs of :78, ahead of the sync of :75)
         self.coarse_matching(feat_c0, feat_c1, data)                    # :75
         win0, win1 = self.fine_preprocess(feat_f0, feat_f1, feat_c0, feat_c1, data)     # :78
         if win0.size(0) != 0:                                           # at least one coarse level predicted
-            win0, win1 = self.fine(win0, win1)                          # :79-80
+            self.fine.defer_range_check = True                          # (its report is read behind the next launch)
+            try:
+                win0, win1 = self.fine(win0, win1)                      # :79-80
+            finally:
+                self.fine.defer_range_check = False
         self.fine_matching(win0, win1, data)                            # :83
+        redo = self.fine.resolve_range_check()
+        if redo is not None:                                            # the fine kernel could not hold the values: float32 layers
+            self.fine_matching(redo[0], redo[1], data)
         data.update({'feat_c0': feat_c0, 'feat_c1': feat_c1, 'feat_f0': feat_f0, 'feat_f1': feat_f1})
         return data
 

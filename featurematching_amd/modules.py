@@ -144,6 +144,21 @@ class FinePreprocess(nn.Module):
             self._merge_key = key
         return self._merge_cache
 
+    def prepare(self, feat_c0, feat_c1):
+        """Optional: enqueue the part of forward() that does not depend on the matches - the per-cell context tables
+        W_c.(down_proj(feat_c)) + bias, two plain GEMMs - ahead of time.  A caller that runs this BEFORE
+        CoarseMatching.forward (whose match count is a host sync) leaves only the crop launch behind the sync
+        (matcher.Matcher.forward_features does).  forward() uses the tables when it is handed the same tensors."""
+        self._ctx_ready = None
+        if not (self.cat_c_feat and self.fused_merge and not self.training and feat_c0.is_cuda):
+            return
+        if torch.is_grad_enabled() and (feat_c0.requires_grad or feat_c1.requires_grad):
+            return
+        with torch.no_grad():
+            _, e_w, e_b = self._merge_constants()
+            self._ctx_ready = ((feat_c0.data_ptr(), feat_c0._version, feat_c1.data_ptr(), feat_c1._version),
+                               F.linear(feat_c0.float(), e_w, e_b), F.linear(feat_c1.float(), e_w, e_b))
+
     def forward(self, feat_f0, feat_f1, feat_c0, feat_c1, data):
         W = self.W
         stride = data['hw0_f'][0] // data['hw0_c'][0]
@@ -166,8 +181,13 @@ class FinePreprocess(nn.Module):
             # reach memory.  The position-independent half of merge_feat becomes a per-cell table (plain GEMMs).
             with torch.no_grad():
                 packed, e_w, e_b = self._merge_constants()
-                ctx0 = F.linear(feat_c0.float(), e_w, e_b)          # [N, L, 64] = W_c.(down_proj(feat_c)) + bias
-                ctx1 = F.linear(feat_c1.float(), e_w, e_b)
+                ready = getattr(self, '_ctx_ready', None)
+                self._ctx_ready = None
+                if ready is not None and ready[0] == (feat_c0.data_ptr(), feat_c0._version, feat_c1.data_ptr(), feat_c1._version):
+                    ctx0, ctx1 = ready[1], ready[2]                 # prepare() ran on these very tensors
+                else:
+                    ctx0 = F.linear(feat_c0.float(), e_w, e_b)      # [N, L, 64] = W_c.(down_proj(feat_c)) + bias
+                    ctx1 = F.linear(feat_c1.float(), e_w, e_b)
                 if cells0 is not None and feat_f1.shape[1] == 64:
                     win0, win1 = ops.gather_windows_pair(feat_f0, feat_f1, b_ids, i_ids, j_ids, W, stride, hw0_c, hw1_c,
                                                          (cells0, cells1), packed_w=packed, ctx0=ctx0, ctx1=ctx1)

@@ -771,6 +771,35 @@ def test_matcher_tail_against_reference_fixture():
     assert np.abs(data['mkpts1_f'].cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= 2e-3
 
 
+def test_matcher_tail_redoes_the_fine_half_when_the_fine_kernel_reports_its_range():
+    """Matcher.forward_features reads the fine kernel's range report BEHIND the launch of the fine matching (the host
+    sync then waits behind work the GPU has).  A fine-layer weight of 20 lies outside the kernel's fixed weight scale
+    (|w| < 16): the report must send the call through the float32 layers and the fine matching must be redone on their
+    output - the same keypoints as a matcher whose fine layers never use the kernel."""
+    from featurematching_amd.matcher import Matcher
+    inp = net_tail_inputs()
+    t = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}
+    dev = lambda x: torch.as_tensor(x, device=DEV)
+    outs = []
+    for use_hip in (True, False):
+        torch.manual_seed(7)
+        m = Matcher().to(DEV).eval()
+        m.coarse.load_state_dict(t(inp['w_coarse']))
+        m.fine.load_state_dict(t(inp['w_fine']))
+        m.fine_preprocess.load_state_dict(t(inp['w_prep']))
+        with torch.no_grad():
+            m.fine.layers[0].q_proj.weight[0, 0] = 20.0
+        m.fine.use_hip = use_hip
+        data = {'bs': NET_TAIL['n'], 'hw0_i': inp['hw_i'], 'hw1_i': inp['hw_i']}
+        m.forward_features(dev(inp['feat_c0']), dev(inp['feat_c1']), dev(inp['feat_f0']), dev(inp['feat_f1']), data)
+        outs.append((data, m.fine.range_fallbacks))
+    (d_hip, fb_hip), (d_ref, fb_ref) = outs
+    assert fb_hip == 1 and fb_ref == 0
+    assert torch.equal(d_hip['i_ids'], d_ref['i_ids']) and d_hip['i_ids'].numel() > 80
+    assert torch.isfinite(d_hip['mkpts0_f']).all()
+    assert torch.equal(d_hip['mkpts0_f'], d_ref['mkpts0_f']) and torch.equal(d_hip['mkpts1_f'], d_ref['mkpts1_f'])
+
+
 # ------------------------------------------------------------------ match(img0, img1) facade
 def test_matcher_end_to_end_on_warped_images():
     """Seeded-random backbone, image1 = image0 shifted by (16, 8) px: the matcher must run end to
