@@ -38,11 +38,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // matrix cores, as in the coarse stage: window values and weights are split x = hi + lo (f16 each) and
 // hi*hi + lo*hi + hi*lo is accumulated in f32 (~2^-22 relative).  wpack = the weights pre-split into MFMA B
 // fragments by fm_merge_pack_weights: [n-tile 2][k-step 4][hi|lo][lane 64] x 8 halfs.
-// Both operands carry exact power-of-two scales (window values x kMergeActScale, weights x kMergeWgtScale, undone on
-// the accumulator): the matrix cores flush float16 SUBNORMAL inputs, and the lo half of anything below 2^-3 - every
-// weight of a 128-wide Linear layer - would be one (see fine_tf.hip).
-constexpr float kMergeActScale = 256.f;       // |window value| < 256 stays inside float16
+// Both operands carry exact power-of-two scales, undone on the accumulator: the matrix cores flush float16 SUBNORMAL
+// inputs, and the lo half of anything below 2^-3 - every weight of a 128-wide Linear layer - would be one (see
+// fine_tf.hip).  Weights x kMergeWgtScale (fixed: |w| < 16, merge_feat is a 128-wide Linear layer).  Window values x a
+// scale that FOLLOWS THE WINDOW (round 4): the power of two that brings the window's largest magnitude into
+// [2^13, 2^14) - a fixed 2^8 turned every window value beyond 255.9 into inf without a word (un-normalised backbone
+// features; found by a matcher test on maps of magnitude 3e5).
 constexpr float kMergeWgtScale = 4096.f;
+// exact power of two s with amax * s in [2^13, 2^14), clamped to [2^-100, 2^40] (a window of zeros / denormals: the
+// context term alone decides, and c * s * 2^12 must stay inside float32)
+__device__ __forceinline__ float merge_act_scale(float amax) {
+  const unsigned bits = __float_as_uint(amax);
+  const int e = (int)((bits >> 23) & 0xffu);           // amax in [2^(e-127), 2^(e-126))
+  int k = 140 - e;                                     // 13 - (e - 127)
+  if (e == 255) k = 0;                                 // (Inf / NaN window: the result is NaN either way)
+  k = k > 40 ? 40 : (k < -100 ? -100 : k);
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
 template <int W>
 __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const half8* __restrict__ wpack,
                                                 const float* __restrict__ ctx_row) {
@@ -57,6 +69,22 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
       bhi[nt][ks] = wpack[((nt * 4 + ks) * 2 + 0) * 64 + lane];
       blo[nt][ks] = wpack[((nt * 4 + ks) * 2 + 1) * 64 + lane];
     }
+  // the window's largest magnitude (every lane reads the values it will split below: the 64 lanes cover the tile)
+  float amax = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = min(32 * mt + r, WW - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float4 p = *reinterpret_cast<const float4*>(tile + row * PITCH + ks * 16 + 8 * h);
+      const float4 q = *reinterpret_cast<const float4*>(tile + row * PITCH + ks * 16 + 8 * h + 4);
+      amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), fabsf(p.w))),
+                               fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)))));
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+  const float act_scale = merge_act_scale(amax);
   // A fragments of all window rows first (the tile is overwritten below): lane (r, h) holds row r,
   // channels 16*ks + 8*h .. +7; rows beyond the window re-read its last row (their outputs are dropped)
   half8 ahi[MT][4], alo[MT][4];
@@ -70,7 +98,7 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
       const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float xs = x[e] * kMergeActScale;
+        const float xs = x[e] * act_scale;
         const _Float16 hh = (_Float16)xs;
         ahi[mt][ks][e] = hh;
         alo[mt][ks][e] = (_Float16)(xs - (float)hh);
@@ -78,13 +106,14 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
     }
   }
   __builtin_amdgcn_wave_barrier();
+  const float inv_scale = (1.0f / act_scale) * (1.0f / kMergeWgtScale);      // (both exact powers of two)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       f32x16 acc;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) acc[g] = (nt ? c1 : c0) * (kMergeActScale * kMergeWgtScale);   // column n = 32*nt + r
+      for (int g = 0; g < 16; ++g) acc[g] = (nt ? c1 : c0) * (act_scale * kMergeWgtScale);   // column n = 32*nt + r
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mt][ks], bhi[nt][ks], acc, 0, 0, 0);
@@ -94,7 +123,7 @@ __device__ __forceinline__ void wave_merge_tile(float* tile, int lane, const hal
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int row = 32 * mt + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (row < WW) tile[row * PITCH + 32 * nt + r] = acc[g] * (1.0f / (kMergeActScale * kMergeWgtScale));
+        if (row < WW) tile[row * PITCH + 32 * nt + r] = acc[g] * inv_scale;
       }
     }
   }

@@ -1038,6 +1038,32 @@ def test_cell_ordered_gather_equals_list_ordered_gather(w):
 
 
 # ------------------------------------------------------------------ crop fused with the context merge (row a5)
+@pytest.mark.parametrize("gain", [1e-6, 1.0, 300.0, 3e5])
+def test_fused_context_merge_follows_the_magnitude_of_the_maps(gain):
+    """The fused crop + merge kernel splits the window values into float16 halves at a power-of-two scale that follows
+    every window's largest magnitude: fine maps of magnitude 1e-6 .. 3e5 (a fixed 2^8 scale returned inf beyond 255.9,
+    silently) against the oracle, relative to the magnitude of the output."""
+    g = load_golden("merge_cfg1_w7")
+    c = case_inputs(g['meta'][:6], "peaky")
+    hc, wc = c['hw_c']
+    dw, db, mw, mb = (torch.as_tensor(a, device=DEV) for a in synth.merge_weights(c['cfg']['seed'], c['cfg']['c'], 64))
+    w_c = mw[:, 64:]
+    e_w, e_b = (w_c @ dw).contiguous(), (w_c @ db + mb).contiguous()
+    packed = ops.pack_merge_weights(mw)
+    ff0 = (c['ff0'] * np.float32(gain)).astype(np.float32)
+    ff0[0, :, 40:44, 40:44] *= np.float32(1e-3)               # one cell's window three orders of magnitude smaller
+    ref0, _ = orc.fine_preprocess(ff0, ff0, c['f0'], c['f1'], g['b_ids'], g['i_ids'], g['i_ids'], 7, 4, wc, wc,
+                                  down_proj=(dw.cpu(), db.cpu()), merge_feat=(mw.cpu(), mb.cpu()))
+    ctx = torch.nn.functional.linear(torch.as_tensor(c['f0'], device=DEV), e_w, e_b)
+    ids = torch.as_tensor(g['i_ids'].astype(np.int64), device=DEV)
+    bids = torch.as_tensor(g['b_ids'].astype(np.int64), device=DEV)
+    got = ops.gather_merge_windows(torch.as_tensor(ff0, device=DEV), packed, ctx, bids, ids, 7, 4, hc, wc).cpu()
+    assert torch.isfinite(got).all()
+    # per window: 2^-20 of the window's own largest output (float32-equivalent product of 64 terms + the context term)
+    scale = ref0.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+    assert ((got - ref0).abs() / scale).max().item() <= 2.0 ** -20
+
+
 @pytest.mark.parametrize("name,dist", [("merge_cfg1_w7", "peaky"), ("merge_cfg2_w5", "borderline")])
 def test_fused_crop_and_context_merge(name, dist):
     """fm_gather_merge_windows (crop + merge_feat(cat[window, down_proj(feat_c)]), fine_preprocess.py:43-60) against
