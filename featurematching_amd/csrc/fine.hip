@@ -816,7 +816,10 @@ __global__ __launch_bounds__(256) void k_merge_pack(const float* __restrict__ me
   half8 hh, ll;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float x = src[j] * kMergeWgtScale;
+    float x = src[j] * kMergeWgtScale;
+    // a weight beyond the fixed scale (|w| >= 16) would turn into +-inf here and into a wrong finite number or NaN
+    // somewhere downstream: make it NaN for certain - every output that touches it then says so
+    if (!(fabsf(x) <= 65504.f)) x = __builtin_nanf("");
     hh[j] = (_Float16)x;
     ll[j] = (_Float16)(x - (float)hh[j]);
   }

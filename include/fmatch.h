@@ -255,7 +255,7 @@ int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int Hf, int Wf, 
  * per weight update by fm_merge_pack_weights(merge_feat.weight [64,128] row-major).  The product runs as
  * hi/lo-split f16 MFMAs with f32 accumulation (f32-equivalent, ~2^-22 relative); the window operand carries a
  * power-of-two scale that follows every window's largest magnitude (any finite float32 map), the weights a fixed one:
- * |merge_feat.weight| < 16.
+ * |merge_feat.weight| < 16 (a larger weight is packed as NaN: the outputs it touches are NaN, never a wrong number).
  * cell_to_match / ties as in fm_gather_windows_cells, or both NULL for list order.  NCHW, Cf = 64, W in {5,7}.
  */
 int fm_merge_pack_weights(const float* merge_w, int Cf, void* packed_w, void* stream);
