@@ -252,6 +252,43 @@ def test_assignment_launch_carries_the_map_copy(name, w):
         assert np.abs(a1.cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= FINE_TOL_PX
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 17, 50), (1, 64, 9, 200), (2, 64, 33, 64)])
+def test_map_copy_side_job_on_ragged_maps(shape):
+    """The side job of fm_coarse_match_maps takes any [Nf, 64, Hf, Wf] float32 map (its shape is independent of the
+    coarse problem): widths that are not multiples of 64 (a short last piece) or of 4 (the scalar loader), several
+    samples - the scratch buffer is the permuted map bit for bit, the coarse outputs are untouched."""
+    g = load_golden("cfg1_peaky")
+    inp = case_inputs(g['meta'], "peaky", with_fine=False)
+    t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    side = torch.as_tensor(synth.normal(17, 3, shape), device=DEV)
+    buf = ops.coarse_match_async(t0, t1, inp['hw_c'], inp['hw_c'], 8.0, side_map=side)
+    m = buf.read_count()
+    _assert_coarse(buf.sliced(m), g)
+    n, c, hf, wf = shape
+    got = buf.side_scratch[:side.numel() * 4].view(torch.float32).view(n, hf, wf, c)
+    assert torch.equal(got, side.permute(0, 2, 3, 1).contiguous())
+
+
+def test_flat_hint_on_a_batch_with_one_peaked_and_one_flat_sample():
+    """FM_MODE_FLAT on a batch whose samples differ (sample 0 peaked, sample 1 flat): the hint is wrong for one of them
+    and must only cost time - both samples against the oracle, and the same matches as the call without the hint."""
+    l, c, hw = 1200, 128, (30, 40)
+    a0, a1 = synth.coarse_descriptors(61, 1, l, c, "peaky")
+    b0, b1 = synth.coarse_descriptors(62, 1, l, c, "borderline")
+    f0, f1 = np.concatenate([a0, b0]), np.concatenate([a1, b1])
+    ref = orc.coarse_match(f0, f1, (240, 320), hw, hw, 0.2, 2, 0.1)
+    t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
+    hint = ops.coarse_match_async(t0, t1, hw, hw, 8.0, dense=True, flat=True)
+    mh = hint.read_count()
+    assert hint.info & _lib.FM_DEV_ALL_DENSE
+    _assert_coarse(hint.sliced(mh), ref)
+    plain = ops.coarse_match_async(t0, t1, hw, hw, 8.0, dense=True)
+    mp = plain.read_count()
+    assert not (plain.info & _lib.FM_DEV_ALL_DENSE)            # sample 0 stayed with the screening kernel
+    _assert_coarse(plain.sliced(mp), ref)
+    assert mh == mp and int((hint.sliced(mh)['b_ids'] == 1).sum()) > 300
+
+
 def test_cfg5_coarse_against_reference_fixture():
     g = load_golden("cfg5_peaky")                       # 1024x1024 -> L = S = 16384
     inp = case_inputs(g['meta'], "peaky", with_fine=False)
