@@ -103,7 +103,7 @@ class Pair:
         # certified dead by the sparse sum kernel and cost nothing); 'peaky' takes the common 4 launches
         self.dense = dist != "peaky"
         # ... and in 'mixed' data those peakless rows sit next to peaked ones: more candidates than the default 8 slots.  The
-        # general answer is the exact screening pass (FM_MODE_EXACT_SCREENING: a second full sweep, k_corr<C,2>, 37 us);
+        # general answer is the exact screening pass (FM_MODE_EXACT_SCREENING: a second full sweep, k_dense<C, RESCREEN>, 37 us);
         # the caller that knows its data gets the same matches with 16 candidate slots and the int8 step from the images'
         # true maxima (FM_MODE_EXACT_STEP: margins 1.5x narrower, so ~7 instead of ~20 entries of a peakless row pass the
         # dense kernel's candidate test): 13.1 k against 11.3 k pairs/s (tools/time_flat.py slots; a row that still

@@ -305,7 +305,7 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
     if (e != hipSuccess) return (int)e;
   }
   if (exact) {                 // exits immediately unless the sum kernels' screening overflowed a row's slots
-    e = launch_corr(2, w, base, inv_ct, thr, st);
+    e = launch_dense(w, base, inv_ct, thr, st, nullptr, 1);
     if (e != hipSuccess) return (int)e;
   }
   if (conf_matrix) {           // dense data['conf_matrix'] on request (one more sweep)
@@ -364,7 +364,7 @@ extern "C" int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C,
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0) return (int)launch_max_i8(w, (char*)workspace, st);
   if (mode == 1) return (int)launch_dense(w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st);
-  return (int)launch_corr(mode, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st);
+  return (int)launch_dense(w, (char*)workspace, 1.0f / ((float)C * temperature), thr, st, nullptr, 1);      // mode 2: the re-screening
 }
 
 // Diagnostic: launch the sparse sum kernel alone on a workspace a previous fm_coarse_match filled.

@@ -77,8 +77,15 @@ __device__ __forceinline__ unsigned lds_addr_d(T* p) { return (unsigned)(size_t)
 // tile ring whose epilogue - and with it every store - ran behind the MFMA chain).  The epilogue slice of a register is
 // two fused multiply-adds, two exp2, one multiply and ONE store (a scalar row base + a per-lane offset: 32 consecutive
 // floats of two rows per instruction), spread over the next unit's k-steps like the sums' slices.
-template <int C, bool CONF = false>
+// RESCREEN (round 4; replaces k_corr<C,2>, the last user of the tile-based sweep of rounds 1-3): the exact re-screening
+// of FM_MODE_EXACT_SCREENING - only when the sum sweep overflowed a row's or a column's candidate slots: the same
+// product again, the candidate test with the now-known softmax denominators (log2 P_row > log2 thr and log2 P_col >
+// log2 thr: at most 1/thr entries of a row can pass), no sums; the lists of the samples the sum sweep served are
+// refilled from scratch (k_reduce_sums cleared their counters).  Enqueued always, exits at once when not needed.
+enum { kDenseSums = 0, kDenseConf = 1, kDenseRescreen = 2 };
+template <int C, int VAR = kDenseSums>
 __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
+  constexpr bool CONF = VAR == kDenseConf, RESCREEN = VAR == kDenseRescreen, SUMS = VAR == kDenseSums;
   constexpr int KSTEPS = C / 16;
   constexpr int PLANE = KSTEPS * 1024;              // bytes of one plane (hi or lo) of a unit
   constexpr int UNIT_BYTES = 2 * PLANE;             // hi then lo
@@ -90,7 +97,8 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   __shared__ int s_qkey[8 * kDenseQueue];           // wave-private candidate queue: (col << 5) | local row
   __shared__ float s_qx[8 * kDenseQueue];
 
-  if (!CONF && *a.dense_units == 0) return;         // uniform: the screening kernel handled every sample
+  if (SUMS && *a.dense_units == 0) return;          // uniform: the screening kernel handled every sample
+  if (RESCREEN && !(*a.flags & FM_INT_SCREEN_OVERFLOW)) return;     // uniform: the sum sweep's screening sufficed
 #ifdef FM_DIAG_CLOCK       // diagnostic build only: shader-clock stamps per phase of every wave (tools/diag_clock.py)
   const unsigned long long dg0 = __builtin_amdgcn_s_memtime(), dgr0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long dg_chain = 0, dg_bar = 0, dg_pro = 0, dg_loop_end = 0;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   }
   float* colout = a.colpart + ((long)b * a.panels + panel) * a.Sp;
   auto fold_columns = [&](int u) {                  // the 8 waves' sums of unit u's 32 columns, in wave order
-    if (CONF || wv != (u & 7) || lane >= 32) return;
+    if (!SUMS || wv != (u & 7) || lane >= 32) return;
     const unsigned ad = colred_a + (((u - u0) % 3) * 8 * 32 + lane) * 4;
     float pv[8];
 #pragma unroll
@@ -299,6 +307,18 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
                   : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [vo] "v"(conf_voff), [sb] "s"(rowbase)
                   : "memory");
             }
+          } else if constexpr (RESCREEN) {
+            // log2 P_row and log2 P_col of register g's entry against log2 thr: the hit goes into the lane's bit mask
+            float t1, t2;
+            asm volatile(
+                "v_fma_f32 %[t1], %[x], %[kq], %[nm]\n\t"
+                "v_fma_f32 %[t2], %[x], %[kq], %[nmc]\n\t"
+                "v_min_f32 %[t1], %[t1], %[t2]\n\t"
+                "v_cmp_lt_f32 vcc, %[lt], %[t1]\n\t"
+                "v_addc_co_u32 %[bm], vcc, %[bm], %[bm], vcc"
+                : [t1] "=&v"(t1), [t2] "=&v"(t2), [bm] "+v"(bm)
+                : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [lt] "v"(ltv)
+                : "vcc");
           } else {
           float t1, t2, t3;
           asm volatile(
@@ -338,8 +358,10 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
       }
     }
     if (DC && !CONF) {
-      cstat = halves_sum_d(cstat);                  // this wave's 32 rows of column r
-      if (h == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(colred_a + ((((uc - u0) % 3) * 8 + wv) * 32 + r) * 4), "v"(cstat) : "memory");
+      if constexpr (SUMS) {
+        cstat = halves_sum_d(cstat);                // this wave's 32 rows of column r
+        if (h == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(colred_a + ((((uc - u0) % 3) * 8 + wv) * 32 + r) * 4), "v"(cstat) : "memory");
+      }
       {
         // (padded rows / columns carry x = -inf: never marked)
         unsigned long long hitl = __ballot(bm != 0);
@@ -366,7 +388,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
               const int pos = atomicAdd(&a.cand_count[grow], 1), cpos = atomicAdd(&a.ccand_count[gcol], 1);
               if (pos < a.slots) { a.cand_j[grow * a.slots + pos] = key >> 5; a.cand_x[grow * a.slots + pos] = xv; }
               if (cpos < a.slots) { a.ccand_i[gcol * a.slots + cpos] = wrow0 + (key & 31); a.ccand_x[gcol * a.slots + cpos] = xv; }
-              if (pos >= a.slots || cpos >= a.slots) atomicOr(a.flags, (unsigned)FM_INT_SCREEN_OVERFLOW);
+              if (pos >= a.slots || cpos >= a.slots) atomicOr(a.flags, RESCREEN ? (unsigned)FM_DEV_CANDIDATES : (unsigned)FM_INT_SCREEN_OVERFLOW);
             }
             ++qn;
           }
@@ -429,17 +451,19 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
     }
   }
   // ---- row sums of this workgroup's column range: reduce over the 32 lanes of each half ----
+  if constexpr (SUMS) {
 #pragma unroll
-  for (int g = 0; g < 16; ++g) rstat[g] = half_sum32_d(rstat[g]);
-  if (r == 0) {
-    float* out = a.rowpart + ((long)b * a.splits + split) * a.Lp + wrow0 + 4 * h;
+    for (int g = 0; g < 16; ++g) rstat[g] = half_sum32_d(rstat[g]);
+    if (r == 0) {
+      float* out = a.rowpart + ((long)b * a.splits + split) * a.Lp + wrow0 + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) out[(g & 3) + 8 * (g >> 2)] = rstat[g];
+      for (int g = 0; g < 16; ++g) out[(g & 3) + 8 * (g >> 2)] = rstat[g];
+    }
   }
   if (q_pos >= 0) {
     if (q_pos < a.slots) { a.cand_j[q_row * a.slots + q_pos] = q_key >> 5; a.cand_x[q_row * a.slots + q_pos] = q_x; }
     if (q_cpos < a.slots) { a.ccand_i[q_col * a.slots + q_cpos] = wrow0 + (q_key & 31); a.ccand_x[q_col * a.slots + q_cpos] = q_x; }
-    if (q_pos >= a.slots || q_cpos >= a.slots) atomicOr(a.flags, (unsigned)FM_INT_SCREEN_OVERFLOW);
+    if (q_pos >= a.slots || q_cpos >= a.slots) atomicOr(a.flags, RESCREEN ? (unsigned)FM_DEV_CANDIDATES : (unsigned)FM_INT_SCREEN_OVERFLOW);
   }
 #ifdef FM_DIAG_CLOCK       // the screening kernel's row-list slots of the padded rows (>= L, never used) carry 64 waves' stamps
   if (split == 0 && panel < 8 && (a.Lp - a.L) * a.slots >= 512 && lane < 8) {
@@ -454,12 +478,13 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
 #endif
 }
 
-hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st, float* conf) {
+hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st, float* conf, int rescreen) {
   DenseArgs a;
   a.conf = conf;
+  const bool offsets = conf != nullptr || rescreen;      // both read the log-softmax offsets of k_reduce_sums
   a.hi0 = (const _Float16*)(base + w.hi0); a.lo0 = (const _Float16*)(base + w.lo0);
   a.hi1 = (const _Float16*)(base + w.hi1); a.lo1 = (const _Float16*)(base + w.lo1);
-  a.nmr = (const float*)(base + (conf ? w.nmr2 : w.nmr)); a.nmc = (const float*)(base + (conf ? w.nmc2 : w.nmc));
+  a.nmr = (const float*)(base + (offsets ? w.nmr2 : w.nmr)); a.nmc = (const float*)(base + (offsets ? w.nmc2 : w.nmc));
   a.rowpart = (float*)(base + w.rowB); a.colpart = (float*)(base + w.colB);
   a.dense_cnt = (const int*)(base + w.dense_cnt);
   a.dense_units = &((const Scalars*)(base + w.scalars))->dense_units;
@@ -481,20 +506,25 @@ hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, 
     a.pgroup = pgr < 1 ? 1 : (pgr > w.panels ? w.panels : pgr);
     if (a.splits == 1) a.pgroup = w.panels;
   }
-  a.k = inv_ct * kLog2e; a.lt = log2f(thr);
+  a.k = inv_ct * kLog2e;
+  a.lt = log2f(thr) - (rescreen ? 2e-4f : 0.f);      // the re-screening compares rounded log-softmax values: small guard
   const int blocks = w.N * a.splits * w.panels;
   hipError_t e = hipSuccess;
 #define FM_DENSE_CASE(CC)                                                                        \
   case CC: {                                                                                     \
-    static unsigned long long lds_set = 0, lds_set_c = 0;                                        \
+    static unsigned long long lds_set = 0, lds_set_c = 0, lds_set_r = 0;                         \
     if (conf) {                                                                                  \
-      e = ensure_dynamic_lds(&k_dense<CC, true>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set_c); \
+      e = ensure_dynamic_lds(&k_dense<CC, kDenseConf>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set_c); \
       if (e != hipSuccess) return e;                                                             \
-      hipLaunchKernelGGL((k_dense<CC, true>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);   \
+      hipLaunchKernelGGL((k_dense<CC, kDenseConf>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);   \
+    } else if (rescreen) {                                                                       \
+      e = ensure_dynamic_lds(&k_dense<CC, kDenseRescreen>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set_r); \
+      if (e != hipSuccess) return e;                                                             \
+      hipLaunchKernelGGL((k_dense<CC, kDenseRescreen>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);   \
     } else {                                                                                     \
-      e = ensure_dynamic_lds(&k_dense<CC, false>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set);  \
+      e = ensure_dynamic_lds(&k_dense<CC, kDenseSums>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set);  \
       if (e != hipSuccess) return e;                                                             \
-      hipLaunchKernelGGL((k_dense<CC, false>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);  \
+      hipLaunchKernelGGL((k_dense<CC, kDenseSums>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);  \
     }                                                                                            \
     break;                                                                                       \
   }

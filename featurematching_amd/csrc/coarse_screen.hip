@@ -18,7 +18,7 @@
 //                  a list of <= cand_slots (index, x) pairs per row and per column carries the same information.
 //   * significant, many (flat similarity: untrained network, repetitive texture, a partner that is missing) : a unit with
 //                  more than kMaxExact significant entries, or a row / column with more than cand_slots, flags its
-//                  SAMPLE for the dense sum kernel (k_corr<C,1>: float32-equivalent hi/lo product on the matrix cores
+//                  SAMPLE for the dense sum kernel (k_dense: float32-equivalent hi/lo product on the matrix cores
 //                  for all 1024 entries of every live unit), which redoes that sample when the call runs with
 //                  FM_MODE_DENSE; without it the call reports FM_E_DENSE and the caller repeats it with the flag.
 //                  A sample is handled by ONE of the two kernels: their float32 products agree to ~1e-7 but not bit
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void k_screen(ScreenArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
-  // workgroup order as in k_corr: sample, groups of a.pgroup panels, split-major inside a group, through the
+  // workgroup order as in k_dense: sample, groups of a.pgroup panels, split-major inside a group, through the
   // bijective XCD remap - one XCD's share is a compact (panels x splits) block (speed only)
   int kk = xcd_remap_s(blockIdx.x, gridDim.x);
   const int per_sample = a.panels * a.splits;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_dsm_entries(const float* __restrict__ f
   }
 }
 
-// Dense data['conf_matrix'] (k_corr<C,3>: hi/lo-split float16 products, 22 significant bits - 2e-4 in a conf near 1 at
+// Dense data['conf_matrix'] (k_dense<C, CONF>: hi/lo-split float16 products, 22 significant bits - 2e-4 in a conf near 1 at
 // |sim| ~ 200): every entry that matters takes the exact float32 route.  For the samples the screening kernel served,
 // the rows' lists hold every entry with a row term above 2^-32 (all entries with conf > 2.4e-10 are among them) together
 // with its exact dot product; their conf is rewritten from that number and the same log-softmax offsets.

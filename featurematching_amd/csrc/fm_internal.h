@@ -97,10 +97,10 @@ hipError_t launch_stab(const CoarseWs& w, char* base, float inv_ct, float thr, i
 hipError_t launch_prep_f16(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                            int force, hipStream_t st);
 hipError_t launch_max_i8(const CoarseWs& w, char* base, hipStream_t st);
-hipError_t launch_corr(int mode, const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st,
-                       float* conf = nullptr);
-// (conf != NULL: the CONF variant - writes the dense conf_matrix of every sample from the log-softmax offsets)
-hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st, float* conf = nullptr);
+// (conf != NULL: the CONF variant - writes the dense conf_matrix of every sample from the log-softmax offsets;
+// rescreen: the exact re-screening of FM_MODE_EXACT_SCREENING with the same offsets)
+hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, hipStream_t st, float* conf = nullptr,
+                        int rescreen = 0);
 hipError_t launch_reduce(int mode, const CoarseWs& w, char* base, float inv_ct, hipStream_t st);
 // side job of the assignment launch (fm_coarse_match_maps): channels-last copy of a float32 NCHW map, or src == NULL
 struct MapCopyJob {

@@ -5,8 +5,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 OUT=$ROOT/build/variants; mkdir -p $OUT/obj_$NAME; rm -f $OUT/obj_$NAME/*.o
-CORR=coarse_corr
-for f in api coarse_prep $CORR coarse_dense coarse_max_i8 coarse_screen coarse_select fine fine_tf coarse_tf post dsm_grad; do
+for f in api coarse_prep coarse_dense coarse_max_i8 coarse_screen coarse_select fine fine_tf coarse_tf post dsm_grad; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -I$ROOT/featurematching_amd/csrc "$@" \
     -c $ROOT/featurematching_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &
 done

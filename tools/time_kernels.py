@@ -64,12 +64,12 @@ def main():
     rows.append(("coarse (whole fm_coarse_match)",
                  timed(lambda: ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap), a.iters)))
     if p.n * p.l * p.l * 4 <= 8e9:      # dense conf_matrix (training surface): one more sweep + N*L*S*4 bytes written
-        rows.append(("coarse + dense conf_matrix (k_corr<.,3>)",
+        rows.append(("coarse + dense conf_matrix (k_dense<., CONF>)",
                      timed(lambda: ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, conf_matrix=True),
                            max(3, a.iters // 4))))
-    rows.append(("  corr max pass (k_corr<.,0>)",
+    rows.append(("  corr max pass (k_max_i8)",
                  timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 0, st), a.iters)))
-    rows.append(("  corr sum pass (k_corr<.,1>)",
+    rows.append(("  corr sum pass (k_dense)",
                  timed(lambda: lib.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 1, st), a.iters, reset)))
     p.step()                        # the sweep timings above reset this workspace
     buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, cell_maps=True)   # windows path: with cell maps
@@ -103,8 +103,8 @@ def main():
             extra = f"   {flops / (med * 1e-6) / 1e12:8.1f} TFLOP/s algorithmic"
         print(f"{name:36s} median {med:9.1f} us   min {mn:9.1f} us{extra}")
     t = dict((n, v[0]) for n, v in rows)
-    if "coarse + dense conf_matrix (k_corr<.,3>)" in t:
-        dt = t["coarse + dense conf_matrix (k_corr<.,3>)"] - t["coarse (whole fm_coarse_match)"]
+    if "coarse + dense conf_matrix (k_dense<., CONF>)" in t:
+        dt = t["coarse + dense conf_matrix (k_dense<., CONF>)"] - t["coarse (whole fm_coarse_match)"]
         gb = p.n * p.l * p.l * 4 / 1e9
         print(f"dense conf_matrix: {gb:.2f} GB written in {dt:.0f} us more than the fused path -> {gb / (dt * 1e-6) / 1e3:.2f} TB/s")
     wbytes = 2 * m * w * w * 64 * 4
