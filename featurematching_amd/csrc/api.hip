@@ -86,7 +86,6 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.zero_end = o;
   w.q0 = take(rows * C); w.q1 = take(cols * C);
   w.sigimg = take((size_t)N * 2 * 4);
-  w.amax_u = take((size_t)N * 2 * 4);
   w.imgstat = take((size_t)N * 8 * 4);
   w.l1_0 = take(rows * 4); w.l1_1 = take(cols * 4);
   w.bstat0 = take(rows / 32 * 16); w.bstat1 = take(cols / 32 * 16);
@@ -300,7 +299,12 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
   // The assignment folds the softmax denominators of its candidates from the partial sums itself.  The
   // denominators / log-softmax offsets of EVERY row and column are only needed by the exact screening and by the
   // dense conf_matrix:
-  if (exact || conf_matrix || stats) {
+  // (FM_MODE_FLAT with more than the default 8 candidate slots - rows without a peak next to peaked ones: every sample's
+  // denominators are folds of the dense kernel's 13 + 19 partials, and the assignment would redo them for every
+  // candidate and every competing row - 35 us at 16 slots against 21 us with one reduction launch (5 us) in front; at 8
+  // slots the rows hold one or two candidates and the launch costs more than it saves)
+  const bool reduced = exact || conf_matrix || stats || (flat && cand_slots > 8);   // (the assignment then reads the folded denominators)
+  if (reduced) {
     e = launch_reduce(1, w, base, inv_ct, st);
     if (e != hipSuccess) return (int)e;
   }
@@ -317,7 +321,8 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
     if (e != hipSuccess) return (int)e;
   }
   e = launch_select(w, base, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1,
-                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, dense ? (mode | FM_MODE_DENSE) : mode, st, job);
+                    b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count,
+                    (dense ? (mode | FM_MODE_DENSE) : mode) | (reduced ? FM_MODE_STATS : 0), st, job);
   return (int)e;
 }
 

@@ -23,7 +23,7 @@ struct PrepArgs {
   const float4* bstat0r; const float4* bstat1r; int N;
   signed char* q0; signed char* q1;   // int8 screening planes (fragment-major for v_mfma_i32_32x32x32_i8)
   float* sigimg;                      // [N][2] the quantisation step of image 0 / image 1 of every sample
-  unsigned* amax_u;                   // FM_MODE_EXACT_STEP: [N][2] ord_encode'd largest |x| of every image (k_prep_amax), else NULL
+  int exact_step;                     // FM_MODE_EXACT_STEP: k_prep_amax left every block's largest |x| in bstat*.z
   float* l1_0; float* l1_1;           // L1 norm of every descriptor
   float4* bstat0; float4* bstat1;     // per 32-row block: {largest L1 norm (+inf: the block holds a bad value), largest
                                       // clipped L1 mass of a descriptor, largest |x|, 0}
@@ -121,11 +121,17 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
   // workgroup of the image: max is order independent, so all of them arrive at the same step).  <= 8 loads per
   // thread, all in flight together and ahead of the block's own rows ----
   float amax_s = 0.f;
-  const bool exact_step = a.amax_u != nullptr;       // (uniform)
+  const bool exact_step = a.exact_step != 0;         // (uniform)
   if (exact_step) {
-    // FM_MODE_EXACT_STEP: the image's true maximum (k_prep_amax ran before this kernel); a hair of headroom so that the
-    // roundings of x / sigma cannot push the largest element beyond +-127: nothing is clipped
-    amax_s = ord_decode(a.amax_u[b * 2 + (img1 ? 1 : 0)]) * (1.0f + 1e-5f) / kPrepHeadroom;
+    // FM_MODE_EXACT_STEP: the image's true maximum from the block maxima k_prep_amax left in bstat*.z (one load per
+    // lane; a block whose own workgroup of THIS kernel has already rewritten its bstat entry holds the same .z: the
+    // block's largest |x| either way); a hair of headroom so that the roundings of x / sigma cannot push the largest
+    // element beyond +-127: nothing is clipped.  (Round 4: an atomicMax per block on a memset-cleared word before - the
+    // memset node alone cost 4.6 us per call.)
+    const int nb = rows_pad / 32;
+    const float* bz = reinterpret_cast<const float*>((img1 ? a.bstat1r : a.bstat0r) + (long)b * nb) + 2;
+    for (int i2 = tid; i2 < nb; i2 += 256) amax_s = fmaxf(amax_s, bz[4 * i2]);
+    amax_s = amax_s * (1.0f + 1e-5f) / kPrepHeadroom;
   } else {
     const int ns = min(kPrepSampleRows, rows);
     const int vpr = a.c_in >> 2;                       // 4-channel vectors per row (c_in % 4 == 0)
@@ -285,9 +291,8 @@ __global__ __launch_bounds__(256) void k_prep_split(PrepArgs a) {
 // split: the matrix cores flush float16 SUBNORMAL inputs, so without it the lo half of every value below 2^-3 -
 // |lo| ~ 2^-12 |x| < 2^-14 - would be lost (such elements would carry 11 instead of 22 bits).  f16inv[b] = 1 / (scale0
 // scale1) turns the accumulator back into the dot product.
-// FM_MODE_EXACT_STEP: the largest |x| of every image of every sample (one atomicMax per workgroup on an order-preserving
-// code; the array is cleared by a memset node in front of this kernel).  Same grid as k_prep_split: one workgroup per
-// 32-row block.  NaN never wins a maximum (k_prep_split reports it), Inf does and is reported there too.
+// FM_MODE_EXACT_STEP: the largest |x| of every 32-row block, left in bstat*.z (k_prep_split folds them per image).  Same
+// grid as k_prep_split: one workgroup per 32-row block.  NaN never wins a maximum (k_prep_split reports it), Inf does and is reported there too.
 __global__ __launch_bounds__(256) void k_prep_amax(PrepArgs a) {
   const int tid = threadIdx.x;
   const bool img1 = (int)blockIdx.x >= a.blocks0;
@@ -311,8 +316,8 @@ __global__ __launch_bounds__(256) void k_prep_amax(PrepArgs a) {
   __shared__ float wred[4];
   if ((tid & 63) == 0) wred[tid >> 6] = amax;
   __syncthreads();
-  if (tid == 0 && nrows > 0)
-    atomicMax(&a.amax_u[b * 2 + (img1 ? 1 : 0)], ord_encode(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]))));
+  if (tid == 0)        // (every block of the padded range writes: k_prep_split reads all of them)
+    (img1 ? a.bstat1 : a.bstat0)[rb] = make_float4(0.f, 0.f, fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3])), 0.f);
 }
 
 template <int C>
@@ -386,7 +391,7 @@ static void fill_prep_args(PrepArgs& a, const void* feat0, const void* feat1, in
   a.hi1 = (_Float16*)(base + w.hi1); a.lo1 = (_Float16*)(base + w.lo1);
   a.q0 = (signed char*)(base + w.q0); a.q1 = (signed char*)(base + w.q1);
   a.sigimg = (float*)(base + w.sigimg);
-  a.amax_u = nullptr;
+  a.exact_step = 0;
   a.l1_0 = (float*)(base + w.l1_0); a.l1_1 = (float*)(base + w.l1_1);
   a.bstat0 = (float4*)(base + w.bstat0); a.bstat1 = (float4*)(base + w.bstat1);
   a.zero = (uint4*)(base + w.zero_begin); a.zero_vec = (int)((w.zero_end - w.zero_begin) / 16);
@@ -418,9 +423,7 @@ hipError_t launch_prep(const void* feat0, const void* feat1, int in_dtype, int c
   fill_prep_args(a, feat0, feat1, in_dtype, c_in, w, base);
   const int blocks = a.blocks0 + (int)((long)w.N * w.Sp / 32);
   if (exact_step) {
-    a.amax_u = (unsigned*)(base + w.amax_u);
-    hipError_t e = hipMemsetAsync(a.amax_u, 0, (size_t)w.N * 2 * sizeof(unsigned), st);
-    if (e != hipSuccess) return e;
+    a.exact_step = 1;
     hipLaunchKernelGGL(k_prep_amax, dim3(blocks), dim3(256), 0, st, a);
   }
 #define FM_PREP_CASE(CC)                                                                                  \

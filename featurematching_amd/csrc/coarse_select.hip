@@ -25,6 +25,10 @@ struct SelArgs {
   const int* cand_count_b; const int* cand_j_b; const float* cand_x_b;    // the dense one's (samples with dense_cnt > 0)
   const int* ccand_count_b; const int* ccand_i_b; const float* ccand_x_b;
   const int* dense_cnt;
+  const float* rsum; const float* csum;   // softmax denominators of every row / column (k_reduce_sums), when sums_ready
+  int sums_ready;                         // k_reduce_sums ran before this kernel (exact screening, conf_matrix, statistics,
+                                          // FM_MODE_FLAT): a dense sample's denominators are ONE load each instead of a
+                                          // fold of 13 + 19 partials per candidate and per competing row
   int* blocktot; Scalars* scal;
   int N, L, S, C, Lp, Sp, splits, splits_s, panels, slots;
   int h0c, w0c, h1c, w1c, border;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   // the denominator of row `row` (of sample b_c): its list (lane s = entry s) or its partial sums
   auto row_denominator = [&](int row, float nm) {
     const long g = (long)b_c * a.Lp + row;
-    if (dense) return group_sum(share(a.rowB + (long)b_c * a.splits * a.Lp + row, a.splits, a.Lp));
+    if (dense) return a.sums_ready ? a.rsum[g] : group_sum(share(a.rowB + (long)b_c * a.splits * a.Lp + row, a.splits, a.Lp));
     const int c2 = min(cand_count[g], a.slots);
     const int k2 = cand_j[g * a.slots + slot];
     const float x2 = cand_x[g * a.slots + slot];
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   const int cnt = row_ok ? min(cnt_raw, a.slots) : 0;
   const bool live = slot < cnt;
   float rs;
-  if (dense) rs = group_sum(share(a.rowB + (long)b_c * a.splits * a.Lp + i_c, a.splits, a.Lp));
+  if (dense) rs = a.sums_ready ? a.rsum[grow_c] : group_sum(share(a.rowB + (long)b_c * a.splits * a.Lp + i_c, a.splits, a.Lp));
   else rs = list_sum(__builtin_amdgcn_exp2f(__builtin_fmaf(x_raw, a.k, nmr_i)), j_raw, live, a.slots, base, wave_max_int(cnt));
   bool keep = false;
   int j = live ? j_raw : 0x7fffffff;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
     const int ci = ccand_i[gcol * a.slots + slot];
     const float cx = ccand_x[gcol * a.slots + slot];
     float cs;
-    if (dense) cs = group_sum(share(a.colB + (long)b_c * a.panels * a.Sp + jt, a.panels, a.Sp));
+    if (dense) cs = a.sums_ready ? a.csum[gcol] : group_sum(share(a.colB + (long)b_c * a.panels * a.Sp + jt, a.panels, a.Sp));
     else cs = list_sum(__builtin_amdgcn_exp2f(__builtin_fmaf(cx, a.k, nmc)), ci, slot < ccnt, a.slots, base, wave_max_int(ccnt));
     // (an entry that is negligible for its column - not in that column's list - has conf < 2^-32)
     const bool col_sig = dense || __builtin_fmaf(xt, a.k, nmc) > -kSkipLog2;
@@ -359,6 +363,8 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   a.ccand_count_b = (const int*)(base + w.ccand_count_b); a.ccand_i_b = (const int*)(base + w.ccand_i_b);
   a.ccand_x_b = (const float*)(base + w.ccand_x_b);
   a.dense_cnt = (const int*)(base + w.dense_cnt);
+  a.rsum = (const float*)(base + w.rsum); a.csum = (const float*)(base + w.csum);
+  a.sums_ready = (mode & (FM_MODE_EXACT_SCREENING | FM_MODE_STATS | FM_MODE_FLAT)) ? 1 : 0;
   a.blocktot = (int*)(base + w.blocktot);
   a.scal = (Scalars*)(base + w.scalars);
   a.N = w.N; a.L = w.L; a.S = w.S; a.C = w.C; a.Lp = w.Lp; a.Sp = w.Sp; a.splits = w.splits; a.splits_s = w.splits_s; a.panels = w.panels;

@@ -53,7 +53,6 @@ struct CoarseWs {
   // per-row / per-column statistics
   size_t q0, q1;                              // int8 screening planes
   size_t sigimg;                              // [N][2] the int8 step of image 0 / image 1 of every sample
-  size_t amax_u;                              // [N][2] FM_MODE_EXACT_STEP: ord_encode'd largest |x| of image 0 / image 1
   size_t imgstat;                             // [N][8] per sample {largest L1 norm, largest clipped mass, largest |x|} of
                                               // image 0, then of image 1 (max pass: the block statistics folded once)
   size_t l1_0, l1_1;                          // L1 norm per descriptor
