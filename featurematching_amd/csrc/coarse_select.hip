@@ -364,7 +364,7 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c,
   a.ccand_x_b = (const float*)(base + w.ccand_x_b);
   a.dense_cnt = (const int*)(base + w.dense_cnt);
   a.rsum = (const float*)(base + w.rsum); a.csum = (const float*)(base + w.csum);
-  a.sums_ready = (mode & (FM_MODE_EXACT_SCREENING | FM_MODE_STATS | FM_MODE_FLAT)) ? 1 : 0;
+  a.sums_ready = (mode & (FM_MODE_EXACT_SCREENING | FM_MODE_STATS)) ? 1 : 0;     // (the caller ORs FM_MODE_STATS in whenever k_reduce_sums ran)
   a.blocktot = (int*)(base + w.blocktot);
   a.scal = (Scalars*)(base + w.scalars);
   a.N = w.N; a.L = w.L; a.S = w.S; a.C = w.C; a.Lp = w.Lp; a.Sp = w.Sp; a.splits = w.splits; a.splits_s = w.splits_s; a.panels = w.panels;
