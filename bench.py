@@ -106,7 +106,7 @@ class Pair:
         # general answer is the exact screening pass (FM_MODE_EXACT_SCREENING: a second full sweep, k_dense<C, RESCREEN>, 37 us);
         # the caller that knows its data gets the same matches with 16 candidate slots and the int8 step from the images'
         # true maxima (FM_MODE_EXACT_STEP: margins 1.5x narrower, so ~7 instead of ~20 entries of a peakless row pass the
-        # dense kernel's candidate test): 13.1 k against 11.3 k pairs/s (tools/time_flat.py slots; a row that still
+        # dense kernel's candidate test): 13.8 k against 11.3 k pairs/s (tools/time_flat.py; a row that still
         # overflows reports FM_E_CANDIDATES - nothing is dropped silently)
         self.exact = False
         # ... and the caller that knows ALL its samples are like that (what FM_DEV_ALL_DENSE tells ops.coarse_match's mode
