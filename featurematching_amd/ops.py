@@ -208,7 +208,7 @@ class ModeMemory:
         import threading
         from collections import OrderedDict
         self._lock = threading.Lock()
-        self._d = OrderedDict()          # key -> {'dense', 'exact', 'step', 'flat': bool, 'calls': int, 'learnt': int}
+        self._d = OrderedDict()          # key -> {'dense', 'exact', 'step', 'flat', 'wide': bool, 'calls': int, 'learnt': int}
         self.capacity, self.reprobe = capacity, reprobe
 
     def start(self, key):
@@ -236,10 +236,21 @@ class ModeMemory:
             e = self._d.get(key)
             return bool(e and e.get('flat') and not probing)
 
-    def learn(self, key, dense=False, exact=False, step=False, flat=None):
+    def wide(self, key, probing=False):
+        """start the call with 16 candidate slots (and the exact int8 step)?  Learnt when a DENSE call of this shape
+        overflowed the default 8 slots - rows without a peak next to peaked ones hold ~20 near-candidates at the sampled
+        step's margins, ~7 at the exact step's: twice the slots and FM_MODE_EXACT_STEP then serve the call without the
+        exact re-screening sweep (37 us per 640x480 pair)."""
         with self._lock:
-            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'step': False, 'flat': False, 'calls': 0,
-                                         'learnt': 0})
+            e = self._d.get(key)
+            return bool(e and e.get('wide') and not probing)
+
+    def learn(self, key, dense=False, exact=False, step=False, flat=None, wide=None):
+        with self._lock:
+            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'step': False, 'flat': False, 'wide': False,
+                                         'calls': 0, 'learnt': 0})
+            if wide is not None:
+                e['wide'] = bool(wide)
             e['dense'] |= bool(dense)
             e['exact'] |= bool(exact)
             e['step'] |= bool(step)
@@ -281,6 +292,7 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
     every sample went to the dense sum kernel (FM_DEV_ALL_DENSE), dropped with the other flags at the next re-probe."""
     lib = _lib.load()
     key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
+    all_auto = exact_screening is None and dense is None and exact_step is None and flat is None
     mem_dense, mem_exact, probing = (False, False, False)
     if exact_screening is None or dense is None or exact_step is None:
         mem_dense, mem_exact, probing = MODE_MEMORY.start(key)
@@ -295,6 +307,11 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
         flat = bool(dense) and MODE_MEMORY.flat(key, probing)
     kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening),
               dense=bool(dense) or bool(flat), exact_step=bool(exact_step), flat=bool(flat))
+    managed = all_auto and not conf_matrix and not stats             # (the caller left every mode to the memory)
+    tried_wide = False
+    if managed and kw['dense'] and kw['cand_slots'] < 16 and MODE_MEMORY.wide(key, probing):
+        kw['cand_slots'], kw['exact_step'], tried_wide = 16, True, True
+        kw['exact_screening'] = False                                 # (what the wider lists replace)
     retried_internal = False
     for _ in range(8):
         buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
@@ -315,7 +332,18 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
                 MODE_MEMORY.learn(key, dense=True)
                 probing = False
                 continue
+            if e.status == _lib.FM_E_CANDIDATES and managed and kw['dense'] and not tried_wide and kw['cand_slots'] < 16 \
+                    and not kw['exact_screening']:
+                # a dense call whose rows hold more near-candidates than 8 slots: twice the slots + the exact int8 step
+                # (margins 1.5x narrower) before the exact re-screening sweep
+                kw['cand_slots'], kw['exact_step'], tried_wide = 16, True, True
+                MODE_MEMORY.learn(key, dense=True, wide=True)
+                probing = False
+                continue
             if e.status == _lib.FM_E_CANDIDATES and not kw['exact_screening']:
+                if tried_wide:                       # the wider lists did not hold them either: back to the default
+                    kw['cand_slots'] = int(lib.fm_default_cand_slots(float(thr)))
+                    MODE_MEMORY.learn(key, wide=False)
                 kw['exact_screening'] = True
                 MODE_MEMORY.learn(key, exact=True)
                 probing = False

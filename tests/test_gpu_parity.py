@@ -181,6 +181,26 @@ def test_flat_hint_against_reference_fixture(name, dist):
     _assert_coarse(buf.sliced(m), {k: v for k, v in _np(buf2.sliced(m2)).items()}, conf_tol=2e-6)
 
 
+def test_mode_memory_learns_the_wider_lists_on_mixed_data():
+    """ops.coarse_match on 'mixed' data (peaked rows next to rows without a partner), nothing passed by the caller:
+    FM_E_DENSE -> dense -> FM_E_CANDIDATES (rows with more near-candidates than 8 slots) -> 16 slots + the exact int8
+    step; the shape's next call starts there, with the flat hint, in ONE coarse call - every time the reference's
+    matches."""
+    g = load_golden("cfg2_mixed")
+    inp = case_inputs(g['meta'], "mixed", with_fine=False)
+    t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    ops.MODE_MEMORY.clear()
+    key = (tuple(t0.shape), tuple(t1.shape), 0.2, 0.1)
+    outs = [ops.coarse_match(t0, t1, inp['hw_c'], inp['hw_c'], 8.0) for _ in range(3)]
+    snap = ops.MODE_MEMORY.snapshot()[key]
+    assert snap['dense'] and snap['flat'] and (snap['wide'] or snap['exact'])
+    for o in outs:
+        assert _assert_coarse(o, g) <= 4
+    if snap['wide']:
+        assert outs[2]['_coarse_buffers']._shape[4] == 16            # the steady state runs with 16 slots
+    ops.MODE_MEMORY.clear()
+
+
 def test_mode_memory_learns_the_flat_hint():
     """ops.coarse_match on flat data: FM_E_DENSE -> repeated with FM_MODE_DENSE -> that call reports FM_DEV_ALL_DENSE ->
     the shape's next call carries FM_MODE_FLAT; same matches every time."""
@@ -483,7 +503,8 @@ def test_flat_rows_with_conf_matrix_run_the_coarse_stage_once(monkeypatch):
     ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
     n_first = len(calls)
     ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
-    assert 2 <= n_first <= 3 and calls[0] is False and calls[n_first - 1] is True and calls[n_first:] == [True]
+    # (first call: common path -> dense -> [16 slots + exact step, which repetitive texture overflows too] -> exact screening)
+    assert 2 <= n_first <= 4 and calls[0] is False and calls[n_first - 1] is True and calls[n_first:] == [True]
     # the memory is visible, bounded and decays: the `reprobe`-th call of the shape starts on the common path again,
     # fails there for this data and is repeated with the flags; peaked data of the same shape makes it forget them
     snap = ops.MODE_MEMORY.snapshot()

@@ -107,5 +107,11 @@ def test_mode_memory_is_bounded_decays_and_forgets():
     assert m.flat('c')
     m.learn('c', dense=True, flat=False)
     assert not m.flat('c')
+    # ... and the wider candidate lists (16 slots + exact step) a dense shape may need instead of the exact re-screening
+    assert not m.wide('c')
+    m.learn('c', dense=True, wide=True)
+    assert m.wide('c') and not m.wide('c', probing=True) and m.snapshot()['c']['wide']
+    m.learn('c', wide=False)
+    assert not m.wide('c')
     m.clear()
     assert not m.snapshot()
