@@ -28,6 +28,12 @@ echo "sq done"
 # (4b) the same counters in the regime where the matrix cores decide: the batch of 64 pairs
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/sq3 -- python bench.py --workload cfg3 --steps 4 --warmup 2 --skip-cpu --quick --streams 1 --pairs 1 --no-graph > $O/sq3.json 2> $O/sq3.err
 echo "sq3 done"
+# (4c) ... and on flat data (the dense sum kernel's matrix-core utilisation)
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/sqflat -- python bench.py --dist borderline $PM > $O/sqflat.json 2> $O/sqflat.err
+echo "sqflat done"
+# (5a) the batch of 64 pairs, one stream, eager: per-kernel durations without overlap
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3serial -- python bench.py --workload cfg3 --steps 6 --warmup 2 --skip-cpu --quick --streams 1 --pairs 1 --no-graph > $O/cfg3serial.json 2> $O/cfg3serial.err
+echo "cfg3serial done"
 # (5) the batch-of-64 workload (cfg3) and the 1024x1024 pair (cfg5): kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -- python bench.py --workload cfg3 --steps 20 --warmup 3 --skip-cpu --quick > $O/cfg3.json 2> $O/cfg3.err
 echo "cfg3 done"
@@ -47,6 +53,6 @@ echo "ctx done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/ctxsq -- python tools/time_matcher.py --hip-only > $O/ctxsq.log 2> $O/ctxsq.err
 echo "ctxsq done"
 # keep what is merged back small: stats + counter tables only (traces of 200 steps are large)
-find $O -name '*kernel_trace.csv' -size +8M -delete
+find $O -name '*kernel_trace.csv' -delete
 find $O -name '*.db' -delete
 du -sh $O

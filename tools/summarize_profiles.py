@@ -67,6 +67,7 @@ def main():
     stats("default", f"{rnd}_bench_cfg2_default_kernel_stats.csv")
     stats("serial", f"{rnd}_bench_cfg2_serial_kernel_stats.csv")
     stats("cfg3", f"{rnd}_bench_cfg3_kernel_stats.csv")
+    stats("cfg3serial", f"{rnd}_bench_cfg3_serial_kernel_stats.csv")
     stats("cfg5", f"{rnd}_bench_cfg5_kernel_stats.csv")
     stats("borderline", f"{rnd}_bench_cfg2_borderline_serial_kernel_stats.csv")
     stats("mixed", f"{rnd}_bench_cfg2_mixed_serial_kernel_stats.csv")
@@ -89,7 +90,7 @@ def main():
         print("wrote pmc_fetch_write")
 
     stats("ctx", f"{rnd}_forward_features_kernel_stats.csv")
-    for tag, out in (("sq", f"{rnd}_pmc_sq_cfg2.csv"), ("sq3", f"{rnd}_pmc_sq_cfg3.csv"),
+    for tag, out in (("sq", f"{rnd}_pmc_sq_cfg2.csv"), ("sq3", f"{rnd}_pmc_sq_cfg3.csv"), ("sqflat", f"{rnd}_pmc_sq_cfg2_borderline.csv"),
                      ("ctxsq", f"{rnd}_pmc_sq_forward_features.csv")):
         sq = counters(tag)
         if not sq:
