@@ -189,6 +189,55 @@ __global__ __launch_bounds__(256) void k_select(SelArgs a) {
   bool keep = false;
   int j = live ? j_raw : 0x7fffffff;
   float conf = 0.f, colbest = 0.f;
+  if (dense && a.sums_ready) {
+    // Dense samples whose denominators k_reduce_sums folded: FOUR entries of the row per pass.  Everything an entry needs
+    // is two levels of loads - its column's stabiliser, denominator and list (lane s: the s-th entry of that list), then
+    // the stabiliser and denominator of the ROW of every list entry, requested by the lane that holds it - and the four
+    // entries' loads of a level are in flight together: a row without a peak holds up to `slots` candidates, and one
+    // entry per pass with its two dependent round trips was 19 of this kernel's 21 us at 16 slots.
+    for (int t0 = 0; t0 < a.slots; t0 += 4) {
+      if (!__any(t0 < cnt)) break;                            // wave-uniform
+      bool act[4];
+      int jt[4], ccnt[4], ci[4];
+      float xt[4], nmc[4], cs[4], cx[4], nm2_l[4], rs2_l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = t0 + q;
+        act[q] = t < cnt;                                     // (a row's lanes agree)
+        jt[q] = act[q] ? __shfl(j_raw, base + (t & (a.slots - 1))) : 0;
+        xt[q] = __shfl(x_raw, base + (t & (a.slots - 1)));
+        const long gcol = (long)b_c * a.Sp + jt[q];
+        nmc[q] = a.nmc[gcol];
+        ccnt[q] = ccand_count[gcol];
+        ci[q] = ccand_i[gcol * a.slots + slot];
+        cx[q] = ccand_x[gcol * a.slots + slot];
+        cs[q] = a.csum[gcol];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ccnt[q] = act[q] ? min(ccnt[q], a.slots) : 0;
+        const long g2 = (long)b_c * a.Lp + ((act[q] && slot < ccnt[q]) ? ci[q] : i_c);
+        nm2_l[q] = a.nmr[g2];
+        rs2_l[q] = a.rsum[g2];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ct = act[q] ? entry_conf(xt[q], a.k, nmr_i, rs, nmc[q], cs[q]) : 0.f;
+        float cb = 0.f;
+        const int cmax = wave_max_int(ccnt[q]);
+        for (int e = 0; e < cmax; ++e) {                      // the column's entries: this entry among them
+          const bool ea = e < ccnt[q];
+          const int i2 = ea ? __shfl(ci[q], base + e) : i_c;
+          const float x2 = __shfl(cx[q], base + e);
+          const float nm2 = __shfl(nm2_l[q], base + e), rs2 = __shfl(rs2_l[q], base + e);
+          const float c2 = entry_conf(x2, a.k, nm2, rs2, nmc[q], cs[q]);
+          if (ea && i2 != i) cb = fmaxf(cb, c2);              // another row's entry of this column
+          if (ea && i2 == i) cb = fmaxf(cb, ct);
+        }
+        if (act[q] && slot == t0 + q) { conf = ct; colbest = cb; }
+      }
+    }
+  } else
   for (int t = 0; t < a.slots; ++t) {                         // entry t of every row of the wave that has one
     if (!__any(t < cnt)) break;                               // wave-uniform
     const bool act = t < cnt;                                 // (a row's lanes agree)
