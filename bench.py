@@ -588,6 +588,22 @@ def context_layer_times(wl, dev, iters=10):
     return res
 
 
+def masked_streams(dev, n, how, ncu=256):
+    """Experiment (--cu-mask): n HIP streams that each own ncu / n compute units (hipExtStreamCreateWithCUMask), wrapped
+    as torch external streams."""
+    hip = C.CDLL("libamdhip64.so")
+    out = []
+    for k in range(n):
+        bits = [(1 if ((i * n // ncu == k) if how == "blocks" else (i % n == k)) else 0) for i in range(ncu)]
+        words = (C.c_uint32 * (ncu // 32))(*[sum(bits[32 * w + j] << j for j in range(32)) for w in range(ncu // 32)])
+        st = C.c_void_p()
+        err = hip.hipExtStreamCreateWithCUMask(C.byref(st), ncu // 32, words)
+        if err != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask: {err}")
+        out.append(torch.cuda.ExternalStream(st.value, device=dev))
+    return out
+
+
 def self_launch(ngpus, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process per
     GPU under torch.distributed.run (the launcher of the reference's training glue, utils/comm.py:113-176 assumes the
@@ -749,6 +765,9 @@ def main():
     ap.add_argument("--no-fuse-maps", action="store_true",
                     help="A/B: fm_fine_match_maps transposes image 1 itself (its own launch) instead of the coarse call's "
                          "assignment launch carrying the copy (fm_coarse_match_maps)")
+    ap.add_argument("--cu-mask", default="", choices=["", "blocks", "interleaved"],
+                    help="experiment: every stream gets its own quarter (1 / streams) of the compute units "
+                         "(hipExtStreamCreateWithCUMask): contiguous blocks of the mask bits, or interleaved bits")
     ap.add_argument("--stub-step", action="store_true",
                     help="test hook: run the launcher / rank protocol with a CPU stand-in for the HIP step (no GPU needed; "
                          "the JSON line is marked as a stub and carries no measurement)")
@@ -798,6 +817,8 @@ def main():
     # the (mostly latency-bound, small-grid) kernels of different pairs overlap on the chip.  Every input
     # set has its own buffers and its own captured graph; the timed region still covers K complete steps.
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    if a.cu_mask:
+        streams = masked_streams(dev, nstreams, a.cu_mask)
     graphs = []
     for i, p in enumerate(pairs):
         with torch.cuda.stream(streams[i % nstreams]):
