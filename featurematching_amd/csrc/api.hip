@@ -59,7 +59,10 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.panels = w.Lp / kPanelRows;
   w.tiles = w.Sp / kTileCols;
   w.splits = choose_splits(N, w.panels, w.tiles);
-  w.splits0 = choose_splits(N, w.panels, w.tiles, kMaxPassTarget);
+  // (a batch that fills the resident slots by itself gets ~10 rounds of workgroups, so that the last round's tail is a
+  // small share of the launch: 1216 workgroups on 512 slots were "2.4 of 3 rounds"; 64 pairs of 640x480: 351 -> 333 us
+  // with 4 splits; 2 / 3 / 4 / 5 / 8 splits: 335 / 340 / 333 / 348 / 363 us)
+  w.splits0 = choose_splits(N, w.panels, w.tiles, N * w.panels >= kMaxPassTarget ? 10 * kMaxPassTarget : kMaxPassTarget);
 #ifdef FM_TUNE_ENV
   if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : kMaxPassTarget);
 #endif
@@ -95,6 +98,8 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   w.umax = take(rows / 32 * (cols / N / 32) * 4);
   w.cand_j = take(rows * slots * 4); w.cand_x = take(rows * slots * 4);
   w.ccand_i = take(cols * slots * 4); w.ccand_x = take(cols * slots * 4);
+  w.thr_r = take(rows * 4); w.thr_c = take(cols * 4);
+  w.wmaxb = take(rows / 32 * 4); w.cmaxu = take(cols / 32 * 4);
   w.common_total = o;
   // ---- FM_MODE_DENSE / FM_MODE_EXACT_SCREENING / conf_matrix ----
   w.hi0 = take(rows * C * 2); w.lo0 = take(rows * C * 2);

@@ -40,6 +40,7 @@
 // unit against 0.26k of matrix time).  Sharing a unit's fragments between the row blocks that need them halves the
 // bytes and takes the round trips out of the sweep.  The parked entries are resolved four at a time, eight in flight.
 // No LDS accumulators, no fold, no partial sums.
+#include <stdlib.h>
 #include <string.h>
 
 #include "fm_device.h"
@@ -526,6 +527,304 @@ __global__ __launch_bounds__(256) void k_stab(ScreenArgs a, float* f16inv) {
   (side ? a.nmc : a.nmr)[g] = nm;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// BATCHED screening (round 5): k_thresh + k_screen_rows.
+//
+// k_screen above is built for ONE pair per launch: everything in one memory round trip, all B fragments of a range by
+// LDS-DMA whether alive or not, one barrier - 361 workgroups that each live ~7 us.  At a batch of 64 pairs that shape
+// is 23 104 workgroups in 45 rounds of two per compute unit (LDS), every one the same latency chain: 523 us against
+// ~90 us of bytes.  With thousands of row blocks in a launch the latency of one wave does not matter - what matters is
+// that nothing couples waves to each other and that enough of them are resident:
+//   * k_thresh (one thread per row / column): stabilisers, integer significance thresholds, the largest stabiliser of
+//     every 32-row block and 32-column unit, the pair margin and the range checks - what every k_screen workgroup
+//     derives for its panel and range, computed once.
+//   * k_screen_rows: ONE WAVE per (row block, <= 64 units) item, no barrier, no LDS-DMA: the wave loads its A fragments
+//     and thresholds, derives its live mask from the unit maxima, and walks the LIVE units only - B fragments straight
+//     from global memory into registers (8 KiB per unit, the next unit's in flight while this one is screened: 16 KiB
+//     per wave, 12 waves per compute unit keep its 64 B/clk busy), 8 MFMAs, the same integer screening, the same exact
+//     float32 dot products and list reservations as k_screen.  Items are ordered so that an XCD works on one or two
+//     samples at a time (their int8 planes, 2.4 MiB, stay in its L2).
+// The two forms produce the same lists up to the order of appends (k_select sums in index order) and flag the same
+// kind of units for the dense kernel; which of them runs is a function of the shapes only.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RowsExtra {
+  int* thr_r; int* thr_c; float* wmaxb; float* cmaxu;
+  int nchunks, items;
+};
+
+// grid (chunks of 256 lines, N, 2): z = 0 rows, 1 columns; a 256-thread block = 8 row blocks / units of 32 lines
+__global__ __launch_bounds__(256) void k_thresh(ScreenArgs a, RowsExtra x) {
+  const int side = blockIdx.z, b = blockIdx.y;
+  const int len = side ? a.S : a.L, lenp = side ? a.Sp : a.Lp;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const float sig0 = a.sigimg[b * 2], sig1 = a.sigimg[b * 2 + 1];
+  const float* ist = a.imgstat + (long)b * 8;
+  const float l1A_max = ist[0], clipA = ist[1], infA = ist[2], l1B_max = ist[3], clipB = ist[4], infB = ist[5];
+  const float ss = sig0 * sig1;
+  const float kss = a.k * ss;
+  const bool screen_ok = kss > 1e-30f && kss < 1e30f;
+  const float inv_kss = screen_ok ? 1.0f / kss : 0.f;
+  if (blockIdx.x == 0 && side == 0 && threadIdx.x == 0) {      // (the same checks as k_screen's first workgroup)
+    const float emarg = margin_log2(q8_margin_raw(sig0, l1A_max, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
+    a.emarg[b] = emarg;
+    const bool clipped = clipA > 0.f || clipB > 0.f;
+    const float emarg0 = margin_log2(q8_margin_raw(sig0, l1A_max, 0.f, sig1, l1B_max, 0.f, a.cpad), a.inv_ct);
+    if (!(l1A_max < INFINITY) || !(l1B_max < INFINITY)) atomicOr(&a.scal->flags, (unsigned)FM_DEV_RANGE);
+    else if (!(emarg < 60.f)) atomicOr(&a.scal->flags, (unsigned)(clipped ? FM_DEV_STEP : FM_DEV_RANGE));
+    else if (clipped && emarg > 2.0f * emarg0 + 1.0f) atomicOr(&a.scal->flags, (unsigned)FM_DEV_STEP);
+  }
+  if (idx >= lenp) return;                 // (lenp is a multiple of 64: whole waves leave)
+  const long g = (long)b * lenp + idx;
+  const int blk = idx >> 5;                // row block / unit of this line
+  const int nblk = lenp / 32;
+  float nm = -INFINITY;                    // padded lines: no stabiliser, nothing significant on their account
+  float emu = 0.f;
+  if (idx < len) {
+    const float ln2 = 0.69314718f;
+    const float l1 = (side ? a.l1_1 : a.l1_0)[g];
+    const unsigned mx = (side ? a.colmax_u : a.rowmax_u)[g];
+    const float bl1 = (side ? a.bstat1 : a.bstat0)[(long)b * nblk + blk].x;       // largest L1 norm of the line's block
+    const bool dead = a.allow_dead && 2.002f * l1 * (side ? infA : infB) * a.inv_ct + 1e-3f <
+                                          (a.lt + __builtin_log2f((float)(side ? a.L : a.S))) * ln2;
+    const float mraw = side ? q8_margin_raw(sig0, l1A_max, clipA, sig1, l1, clipB, a.cpad)
+                            : q8_margin_raw(sig0, l1, clipA, sig1, l1B_max, clipB, a.cpad);
+    nm = dead ? -INFINITY : neg_stabiliser_log2(ss * q_decode(mx), mraw, a.inv_ct);
+    // margin of any entry of this line's block against the other image's largest L1 norm
+    emu = margin_log2(side ? q8_margin_raw(sig0, l1A_max, clipA, sig1, bl1, clipB, a.cpad)
+                           : q8_margin_raw(sig0, bl1, clipA, sig1, l1B_max, clipB, a.cpad), a.inv_ct);
+  }
+  (side ? a.nmc : a.nmr)[g] = nm;
+  (side ? x.thr_c : x.thr_r)[g] = idx < len ? sig_threshold(nm, emu, inv_kss) : 0x3fffffff;
+  const float bm = half_reduce32_max(nm);
+  if ((lane & 31) == 0) (side ? x.cmaxu : x.wmaxb)[(long)b * nblk + blk] = bm;
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 3) void k_screen_rows(ScreenArgs a, RowsExtra x) {
+  constexpr int KS8 = C / 32;
+  constexpr int LIST = 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  __shared__ int s_list[4][LIST];
+
+  // item = (sample, chunk, group of 4 row blocks) -> the 4 waves of a workgroup take 4 consecutive row blocks of one
+  // chunk: their live units overlap (L1 / L2 hits on the B fragments); through the bijective XCD remap one XCD's share
+  // is a contiguous range of items, i.e. one or two samples at a time
+  const int nrb = a.Lp / 32, nunits = a.Sp / 32;
+  const int item = xcd_remap_s(blockIdx.x, gridDim.x) * 4 + wv;
+  if (item >= x.items) return;                      // (wave-uniform; the kernel has no barrier)
+  const int per_sample = nrb * x.nchunks;
+  const int b = item / per_sample;
+  int kk = item - b * per_sample;
+  const int chunk = kk / nrb;
+  const int rb = kk - chunk * nrb;
+  const int wrow0 = rb * 32;
+  if (wrow0 >= a.L) return;                         // nothing but padding rows
+  const int u0 = chunk * 64;
+  const int U = min(64, nunits - u0);
+
+  // ---- one round trip: steps and statistics, thresholds of this lane's 16 rows, unit maxima / largest column
+  // stabilisers / largest L1 norms of the chunk's units (lane = unit), the A fragments ----
+  const float sig0 = a.sigimg[b * 2], sig1 = a.sigimg[b * 2 + 1];
+  const float* ist = a.imgstat + (long)b * 8;
+  const float clipA = ist[1], clipB = ist[4];
+  const float bl1A = a.bstat0[(long)b * nrb + rb].x;
+  const float wmax = x.wmaxb[(long)b * nrb + rb];
+  const int ul_c = min(lane, U - 1);
+  const float um = a.umax[((long)b * nrb + rb) * nunits + u0 + ul_c];
+  const float cm = x.cmaxu[(long)b * nunits + u0 + ul_c];
+  const float bl1B = a.bstat1[(long)b * nunits + u0 + ul_c].x;
+  int trr[16];
+  {
+    const int* tp = x.thr_r + (long)b * a.Lp + wrow0 + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 t4 = *reinterpret_cast<const int4*>(tp + 8 * q);
+      trr[4 * q] = t4.x; trr[4 * q + 1] = t4.y; trr[4 * q + 2] = t4.z; trr[4 * q + 3] = t4.w;
+    }
+  }
+  v4i aq[KS8];
+  {
+    const signed char* src = a.q0 + (((long)b * a.Lp + wrow0) / 32 * KS8 * 64 + lane) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS8; ++ks) aq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
+  }
+  const float ss = sig0 * sig1;
+  const float kss = a.k * ss;
+  const bool screen_ok = kss > 1e-30f && kss < 1e30f;
+
+  // ---- live units of this row block (the same bound as k_screen) ----
+  unsigned long long live;
+  {
+    const float emu = margin_log2(q8_margin_raw(sig0, bl1A, clipA, sig1, bl1B, clipB, a.cpad), a.inv_ct);
+    const float top = __builtin_fmaf(um, kss, emu);
+    const bool hot = lane < U && (!screen_ok || !((top + wmax < -kSkipLog2) && (top + cm < -kSkipLog2)));
+    live = __ballot(hot);
+  }
+  const int tot = __builtin_popcountll(live);
+  // more than half of the row block's units alive (and more than a handful): flat similarity, the dense kernel's job
+  const bool flat = (tot * 2 > U && tot >= 12) || !screen_ok;
+  int nd_units = flat ? tot : 0;
+  int nlist = 0;
+#ifdef FM_ABL_ROWS          // ablation builds (tools/): 1 = no sweep, 2 = no exact phase
+  if (FM_ABL_ROWS & 1) live = 0;
+#endif
+  if (!flat && live) {
+    const bool row_edge = (wrow0 + 32 > a.L);
+    const signed char* q1b = a.q1 + ((long)b * nunits + u0) * KS8 * 1024 + lane * 16;
+    const int* tcb = x.thr_c + (long)b * a.Sp + u0 * 32 + r;
+    auto load_unit = [&](int ul, v4i (&bq)[KS8], int& tcl) {
+      const signed char* src = q1b + (long)ul * KS8 * 1024;
+#pragma unroll
+      for (int ks = 0; ks < KS8; ++ks) bq[ks] = *reinterpret_cast<const v4i*>(src + ks * 1024);
+      tcl = tcb[ul * 32];
+    };
+    auto screen_unit = [&](int ul, const v4i (&bq)[KS8], int tcl) {
+      const int ucol0 = (u0 + ul) * 32;
+      v16i acc;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[g] = 0;
+#pragma unroll
+      for (int ks = 0; ks < KS8; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[ks], bq[ks], acc, 0, 0, 0);
+      if (row_edge || ucol0 + 32 > a.S) {
+        const bool cok = ucol0 + r < a.S;
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          if (!cok || wrow0 + (g & 3) + 8 * (g >> 2) + 4 * h >= a.L) acc[g] = kQMasked;
+      }
+      const int nlist0 = nlist;
+      unsigned bm = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) bm |= (acc[g] > min(trr[g], tcl)) ? (1u << g) : 0u;
+      unsigned long long hitl = __ballot(bm != 0);
+      while (hitl) {
+        const int l = __builtin_ctzll(hitl);
+        hitl &= hitl - 1;
+        unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)bm, l);
+        while (bits) {
+          const int g = __builtin_ctz(bits);
+          bits &= bits - 1;
+          const int rl = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+          if (lane == 0 && nlist < LIST) s_list[wv][nlist] = (ul << 10) | (rl << 5) | (l & 31);
+          ++nlist;
+        }
+      }
+      if (nlist - nlist0 > kMaxExact || nlist > LIST) { nlist = nlist0; ++nd_units; }
+    };
+    // the live units two at a time: the next unit's fragments are in flight while this one is screened
+    v4i bA[KS8], bB[KS8];
+    int tcA = 0, tcB = 0;
+    unsigned long long mask = live;
+    int ulA = __builtin_ctzll(mask), ulB = -1;
+    mask &= mask - 1;
+    load_unit(ulA, bA, tcA);
+    while (true) {
+      ulB = -1;
+      if (mask) { ulB = __builtin_ctzll(mask); mask &= mask - 1; load_unit(ulB, bB, tcB); }
+      screen_unit(ulA, bA, tcA);
+      if (ulB < 0) break;
+      ulA = -1;
+      if (mask) { ulA = __builtin_ctzll(mask); mask &= mask - 1; load_unit(ulA, bA, tcA); }
+      screen_unit(ulB, bB, tcB);
+      if (ulA < 0) break;
+    }
+  }
+
+  // ---- the parked entries: exact float32 dot products (as in k_screen; stabilisers from k_thresh's arrays) ----
+  int overflow = 0;
+#ifdef FM_ABL_ROWS
+  if (FM_ABL_ROWS & 2) nlist = 0;
+#endif
+  {
+    constexpr int NPASS = 4;
+    const int sub = lane >> 4, l16 = lane & 15;
+    const int vpr = a.c_in >> 2;
+    for (int e0 = 0; e0 < nlist; e0 += 4 * NPASS) {
+      int myres = 0;
+      float my_nmr = 0.f, my_nmc = 0.f;
+      if (lane < 4 * NPASS && e0 + lane < nlist) {
+        const int ky = s_list[wv][e0 + lane];
+        const int row = wrow0 + ((ky >> 5) & 31), col = (u0 + ((ky >> 10) & 63)) * 32 + (ky & 31);
+        const int pr = atomicAdd(&a.rcount[(long)b * a.Lp + row], 1);
+        const int pc = atomicAdd(&a.ccount[(long)b * a.Sp + col], 1);
+        my_nmr = a.nmr[(long)b * a.Lp + row];
+        my_nmc = a.nmc[(long)b * a.Sp + col];
+        myres = min(pr, 0xffff) | (min(pc, 0xffff) << 16);
+      }
+      int key[NPASS];
+      float xs[NPASS];
+#pragma unroll
+      for (int h2 = 0; h2 < NPASS; h2 += 2) {
+        float4 av[2][4], bv[2][4];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const int p = h2 + pp;
+          const int idx = e0 + 4 * p + sub;
+          key[p] = s_list[wv][min(idx, nlist - 1)];
+          const int row = wrow0 + ((key[p] >> 5) & 31), col = (u0 + ((key[p] >> 10) & 63)) * 32 + (key[p] & 31);
+          const long ro = ((long)b * a.L + row) * a.c_in, co = ((long)b * a.S + col) * a.c_in;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int v4 = l16 + 16 * q;
+            const bool in = v4 < vpr;
+            const int vc = in ? v4 : 0;
+            float4 ta, tb;
+            if (a.in_dtype == FM_F32) {
+              ta = reinterpret_cast<const float4*>((const float*)a.src0 + ro)[vc];
+              tb = reinterpret_cast<const float4*>((const float*)a.src1 + co)[vc];
+            } else {
+              ta = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)a.src0 + ro)[vc], a.in_dtype);
+              tb = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)a.src1 + co)[vc], a.in_dtype);
+            }
+            av[pp][q] = in ? ta : make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[pp][q] = tb;
+          }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          float sm = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sm = __builtin_fmaf(av[pp][q].x, bv[pp][q].x, sm);
+            sm = __builtin_fmaf(av[pp][q].y, bv[pp][q].y, sm);
+            sm = __builtin_fmaf(av[pp][q].z, bv[pp][q].z, sm);
+            sm = __builtin_fmaf(av[pp][q].w, bv[pp][q].w, sm);
+          }
+          xs[h2 + pp] = row_sum16(sm);
+        }
+        if (e0 + 4 * (h2 + 2) >= nlist) break;
+      }
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int idx = e0 + 4 * p + sub;
+        if (e0 + 4 * p >= nlist) break;
+        const int pos = __shfl(myres, 4 * p + sub);
+        const float nmr_e = __shfl(my_nmr, 4 * p + sub), nmc_e = __shfl(my_nmc, 4 * p + sub);
+        if (l16 == 0 && idx < nlist) {
+          const int row = wrow0 + ((key[p] >> 5) & 31), col = (u0 + ((key[p] >> 10) & 63)) * 32 + (key[p] & 31);
+          const float rr = __builtin_fmaf(xs[p], a.k, nmr_e);
+          const float cc = __builtin_fmaf(xs[p], a.k, nmc_e);
+          const int pr = pos & 0xffff, pc = (pos >> 16) & 0xffff;
+          const long grow = (long)b * a.Lp + row, gcol = (long)b * a.Sp + col;
+          if (pr < a.slots) { a.rlist_j[grow * a.slots + pr] = col; a.rlist_x[grow * a.slots + pr] = rr > -kSkipLog2 ? xs[p] : -INFINITY; }
+          else overflow = 1;
+          if (pc < a.slots) { a.clist_i[gcol * a.slots + pc] = row; a.clist_x[gcol * a.slots + pc] = cc > -kSkipLog2 ? xs[p] : -INFINITY; }
+          else overflow = 1;
+        }
+      }
+    }
+  }
+  nd_units += __builtin_popcountll(__ballot(overflow != 0));
+  if (nd_units && lane == 0) {
+    a.dense_cnt[b] = 1;
+    a.scal->dense_units = 1;
+    if (!a.dense_enabled) atomicOr(&a.scal->flags, (unsigned)FM_DEV_DENSE);
+  }
+}
+
 static void fill_screen_stats(ScreenArgs& a, const CoarseWs& w, char* base, float inv_ct, float thr, int allow_dead) {
   a.rowmax_u = (const unsigned*)(base + w.rowmax_u); a.colmax_u = (const unsigned*)(base + w.colmax_u);
   a.sigimg = (const float*)(base + w.sigimg); a.imgstat = (const float*)(base + w.imgstat);
@@ -573,6 +872,33 @@ hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype,
     a.pgroup = pgr < 1 ? 1 : (pgr > w.panels ? w.panels : pgr);
   }
   a.k = inv_ct * kLog2e; a.lt = log2f(thr); a.inv_ct = inv_ct; a.cpad = (float)w.C;
+  // The batched form (k_thresh + k_screen_rows: one independent wave per (row block, 64 units)) when the launch holds
+  // enough row blocks to fill the chip with such waves several times over; below that the one-round-trip kernel.
+  {
+    const long nrb = (long)w.N * (w.Lp / 32);
+    int min_rb = kRowsFormMinRowBlocks;
+#ifdef FM_TUNE_ENV
+    if (const char* ev = getenv("FM_ROWS_MIN_RB")) min_rb = atoi(ev);
+#endif
+    if (nrb >= min_rb) {
+      RowsExtra x;
+      x.thr_r = (int*)(base + w.thr_r); x.thr_c = (int*)(base + w.thr_c);
+      x.wmaxb = (float*)(base + w.wmaxb); x.cmaxu = (float*)(base + w.cmaxu);
+      x.nchunks = (w.Sp / 32 + 63) / 64;
+      x.items = (int)(nrb * x.nchunks);
+      a.allow_dead = allow_dead;
+      const int lenp = w.Lp > w.Sp ? w.Lp : w.Sp;
+      hipLaunchKernelGGL(k_thresh, dim3((lenp + 255) / 256, w.N, 2), dim3(256), 0, st, a, x);
+      const int blocks_r = (x.items + 3) / 4;
+      switch (w.C) {
+        case 64: hipLaunchKernelGGL(k_screen_rows<64>, dim3(blocks_r), dim3(256), 0, st, a, x); break;
+        case 128: hipLaunchKernelGGL(k_screen_rows<128>, dim3(blocks_r), dim3(256), 0, st, a, x); break;
+        case 256: hipLaunchKernelGGL(k_screen_rows<256>, dim3(blocks_r), dim3(256), 0, st, a, x); break;
+        default: return hipErrorInvalidValue;
+      }
+      return hipGetLastError();
+    }
+  }
   const int blocks = w.N * a.splits * w.panels;
   const int smem = a.units_s * (32 * 2 * 4 + w.C * 32);     // column stabilisers + thresholds + B fragments of the range
   hipError_t e = hipSuccess;

@@ -14,6 +14,9 @@ constexpr int kColParts = 1;         // column partials per 256-row panel (the 8
 constexpr int kTieCap = 1023;        // listed tie losers per image; beyond it the gathers scan the match list
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
 constexpr int kUnitsPerSplit = 64; // 32-column units one workgroup of the dense-path kernels covers at most (64-bit live mask)
+constexpr int kRowsFormMinRowBlocks = 448;    // 32-row blocks in a launch from which the batched screening (k_thresh + k_screen_rows)
+                                              // runs: 3 pairs of 640x480, one 1024x1024 pair (measured crossover: 2 pairs 30 vs 27 us,
+                                              // 4 pairs 33 vs 41 us, 64 pairs 270 vs 530 us, 1024x1024 32 vs 75 us)
 constexpr int kScreenUnits = 16;   // ... one workgroup of the screening kernel (their int8 B fragments share its LDS: 8 KiB each at C = 256)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kSkipLog2 = 32.f;    // terms more than 2^32 below every stabiliser are negligible (see coarse_sum_sparse.hip)
@@ -65,6 +68,8 @@ struct CoarseWs {
   size_t umax;                                // unit maxima [N][Lp/32][Sp/32] of the integer screening product (as float)
   size_t cand_j, cand_x;                      // k_screen: every significant entry of a row (column, exact dot product)
   size_t ccand_i, ccand_x;                    // ... of a column (row, exact dot product)
+  size_t thr_r, thr_c;                        // k_thresh (batched screening): integer significance threshold per row / column
+  size_t wmaxb, cmaxu;                        // ... largest -stabiliser*log2e of every 32-row block / 32-column unit
   size_t common_total;
   // ---- dense / exact-screening / conf_matrix only ----
   size_t hi0, lo0, hi1, lo1;                  // float16 planes
@@ -111,6 +116,8 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1
                          float* mconf, int cap, int32_t* d_count, int mode, hipStream_t st,
                          const MapCopyJob* job = nullptr);
 hipError_t launch_conf_patch(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
+// (the batched form of the screening - k_thresh + k_screen_rows, one wave per (row block, 64 units) - is chosen inside
+// launch_sum_sparse when the batch alone fills the chip with waves)
 hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                              float inv_ct, float thr, int dense_enabled, int allow_dead, hipStream_t st);
 

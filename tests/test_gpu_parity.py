@@ -399,6 +399,37 @@ def test_coarse_ragged_shapes_vs_oracle(hc, wc, c, n, dist):
     _assert_coarse(out, ref)
 
 
+def test_batched_screening_on_a_batch_of_small_pairs_vs_oracle():
+    """k_thresh + k_screen_rows (the screening form a launch with >= 448 row blocks takes: batches, 1024x1024 pairs) on
+    60 ragged 15x17-cell pairs of three kinds - peaked, flat ('borderline': every sample goes on to the dense sum
+    kernel), peaked with textureless cells ('mixed': dead rows next to rows without a partner) - plus an exact tie
+    (a duplicated descriptor in image 1: the reference keeps both entries, coarse_matching_new.py:105-106) inside one
+    of the peaked samples.  Every sample against the oracle; the batch equals its samples run alone (those take the
+    one-pair kernel k_screen)."""
+    hc, wc, c, n = 15, 17, 128, 60
+    l = hc * wc
+    f0 = np.empty((n, l, c), np.float32)
+    f1 = np.empty_like(f0)
+    kinds = ["peaky", "borderline", "mixed"]
+    for b in range(n):
+        f0[b:b + 1], f1[b:b + 1] = synth.coarse_descriptors(700 + b, 1, l, c, kinds[b % 3])
+    f1[3, 40] = f1[3, 41]                                   # sample 3 ('peaky'): columns 40 and 41 tie exactly
+    hw_i = (hc * 8, wc * 8)
+    ref = orc.coarse_match(f0, f1, hw_i, (hc, wc), (hc, wc), 0.2, 1, 0.1)
+    out = _run_coarse(f0, f1, hw_i, (hc, wc), (hc, wc), border=1)
+    assert out['_coarse_buffers']._shape[0] * 8 >= 448          # (the launch was large enough for the batched form)
+    ndiff = _assert_coarse(out, ref)
+    assert ndiff <= 4, f"{ndiff} guard-band flips"
+    got = _np(out)
+    tied = [(i, j) for b, i, j in zip(got['b_ids'], got['i_ids'], got['j_ids']) if b == 3 and j in (40, 41)]
+    assert len(tied) == 2 and tied[0][0] == tied[1][0]
+    for b in (0, 1, 2, 3):                                     # the same samples alone: same matches, conf within 2e-6
+        alone = _np(_run_coarse(f0[b:b + 1], f1[b:b + 1], hw_i, (hc, wc), (hc, wc), border=1))
+        sel = got['b_ids'] == b
+        assert np.array_equal(got['i_ids'][sel], alone['i_ids']) and np.array_equal(got['j_ids'][sel], alone['j_ids'])
+        assert np.abs(got['mconf'][sel] - alone['mconf']).max() <= 2e-6
+
+
 def test_coarse_rectangular_l_ne_s():
     f0 = 3.0 * synth.normal(31, 1, (2, 40 * 50, 128))
     f1 = f0[:, synth.permutation(31, 3, 2000)[:1500]] + 0.3 * synth.normal(31, 2, (2, 1500, 128))

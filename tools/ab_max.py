@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--env", default="", help="NAME=v1,v2,..: every library is timed once per value (FM_TUNE_ENV builds read "
                                               "their tuning variables at every call)")
+    ap.add_argument("--batch", type=int, nargs="*", default=[], help="pairs per launch to time instead of the workloads' own (cfg2-sized pairs)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -45,13 +46,15 @@ def main():
             vs.append(v); envs.append(ev)
             names.append(os.path.basename(path) + (f" {ename}={ev}" if ev else ""))
     libc = C.CDLL(None)
-    for wl in a.workloads:
-        p = bench.Pair(bench.WORKLOADS[wl], 1017, 5, dev, "peaky")
+    todo = [(wl, bench.WORKLOADS[wl]) for wl in a.workloads] if not a.batch else \
+        [(f"cfg2x{n}", dict(bench.WORKLOADS["cfg2"], n=n)) for n in a.batch]
+    for wl, wld in todo:
+        p = bench.Pair(wld, 1017, 5, dev, "peaky", device_data=True)
         buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)
         torch.cuda.synchronize()
         ws = buf.workspace
         ptr = C.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
-        n = 200 if wl == "cfg2" else 30
+        n = 200 if p.n * p.l <= 4 * 4800 else 30
         t = [[] for _ in vs]
         for rnd in range(a.rounds + 1):
             for k, v in enumerate(vs):
