@@ -665,8 +665,11 @@ __global__ __launch_bounds__(256, 3) void k_screen_rows(ScreenArgs a, RowsExtra 
     live = __ballot(hot);
   }
   const int tot = __builtin_popcountll(live);
-  // more than half of the row block's units alive (and more than a handful): flat similarity, the dense kernel's job
-  const bool flat = (tot * 2 > U && tot >= 12) || !screen_ok;
+  // more than half of the chunk's units alive AND more than 32 rows with one peak each can light up: flat similarity,
+  // the dense kernel's job.  (32 peaks that happen to fall into 12 of a short last chunk's 22 units are not: on a batch
+  // of 64 peaked pairs ~40 of the 9728 row blocks look like that.  A short chunk of truly flat data is swept and its
+  // units overflow kMaxExact instead.)
+  const bool flat = (tot * 2 > U && tot > 32) || !screen_ok;
   int nd_units = flat ? tot : 0;
   int nlist = 0;
 #ifdef FM_ABL_ROWS          // ablation builds (tools/): 1 = no sweep, 2 = no exact phase

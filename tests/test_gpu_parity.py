@@ -804,7 +804,14 @@ def test_properties_at_cfg3_size():
     f1 += 0.4 * torch.randn(n, l, c, device=DEV, generator=g)
     hw_c = (sh['hc'], sh['wc'])
     run = lambda a0, a1: _np(ops.coarse_match(a0, a1, hw_c, hw_c, 8.0))
+    # the common path alone serves peaked data at this size too (four launches + k_thresh: no sample flagged for the
+    # dense kernel - read_count would raise FM_E_DENSE - and ops.coarse_match below does not fall back silently)
+    ops.MODE_MEMORY.clear()
+    common = ops.coarse_match_async(f0, f1, hw_c, hw_c, 8.0)
+    m_common = common.read_count()
     a = run(f0, f1)
+    assert not ops.MODE_MEMORY.snapshot(), "the batch needed a retry of the coarse stage"
+    assert m_common == a['i_ids'].shape[0]
     b2 = run(f0, f1)
     for k in a:                                           # deterministic, bit for bit
         assert np.array_equal(a[k], b2[k]), k
