@@ -220,7 +220,7 @@ def time_kernels(pair):
         _lib.check(lib.fm_debug_reset_counters(ptr, *shape, st()), "reset")
 
     def sparse():
-        _lib.check(lib.fm_debug_launch_sum_sparse(ptr, f0, f1, *shape, 0.1, 0.2, st()), "sparse")
+        _lib.check(lib.fm_debug_launch_screen(ptr, f0, f1, *shape, 0.1, 0.2, st()), "sparse")
 
     t = {}
     t["max"] = _events(lambda: _lib.check(lib.fm_debug_launch_corr(ptr, *shape, 0.1, 0.2, 0, st()), "max"))

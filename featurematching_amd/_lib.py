@@ -45,9 +45,13 @@ SIGNATURES = {
                                    _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "fm_coarse_match_maps": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
                                   _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "fm_coarse_workspace_bytes_auto": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
+    "fm_coarse_match_auto": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p, _p,
+                                  _p, C.c_size_t, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p,
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _p]),
     "fm_debug_coarse_layout": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_int64), _i]),
     "fm_debug_launch_corr": (_i, [_p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
-    "fm_debug_launch_sum_sparse": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "fm_debug_launch_screen": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p]),
     "fm_debug_launch_prep": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fm_debug_launch_prep_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fm_debug_reset_counters": (_i, [_p, _i, _i, _i, _i, _i, _p]),
@@ -95,6 +99,12 @@ class FMatchError(RuntimeError):
         super().__init__(f"{where}: {msg} (status {status})")
 
 
+# the diagnostic entry points (declared in csrc/fm_debug.h, not in the public header): bench.py and tools/ only
+DEBUG_SIGNATURES = {k: v for k, v in SIGNATURES.items() if k.startswith("fm_debug_")}
+SIGNATURES = {k: v for k, v in SIGNATURES.items() if not k.startswith("fm_debug_")}
+ALL_SIGNATURES = {**SIGNATURES, **DEBUG_SIGNATURES}
+
+
 def load(path=None):
     """Load (once) and return the ctypes handle of featurematching_amd/lib/libfmatch_hip.so.  `path` is for the
     tuning tools under tools/ only: they may load an experimental build of the same ABI BEFORE anything else has
@@ -109,7 +119,7 @@ def load(path=None):
                 "Build it with `make -C featurematching_amd/csrc` (hipcc, --offload-arch=gfx950).")
         import torch  # noqa: F401  (loads torch's libamdhip64 first; same soname is then reused)
         lib = C.CDLL(lib_path)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in ALL_SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "fm_debug.h"
 #include "fm_internal.h"
 
 namespace fm {
@@ -287,7 +288,7 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
   // (FM_MODE_FLAT: the caller expects flat similarity everywhere - the sweep would only find that out again; a small
   // kernel forms the stabilisers and flags every sample for the dense sum kernel)
   if (flat) e = launch_stab(w, base, inv_ct, thr, (conf_matrix || stats) ? 0 : 1, st);
-  else e = launch_sum_sparse(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, (conf_matrix || stats) ? 0 : 1, st);
+  else e = launch_screen(feat0, feat1, in_dtype, C, w, base, inv_ct, thr, dense ? 1 : 0, (conf_matrix || stats) ? 0 : 1, st);
   if (e != hipSuccess) return (int)e;
   if (dense && !flat) {
     // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or
@@ -329,6 +330,129 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
                     b_ids, i_ids, j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count,
                     (dense ? (mode | FM_MODE_DENSE) : mode) | (reduced ? FM_MODE_STATS : 0), st, job);
   return (int)e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fm_coarse_match_auto: ONE call for any data (the reference's CoarseMatching.forward is one call,
+// network/utils/coarse_matching_new.py:43-73).  The data-dependent conditions the device reports - flat similarity,
+// candidate-slot overflow, a clipped int8 step, the assignment's bounded wait - are answered here, on the host, behind
+// the host sync the reference has too (torch.where, :109); what is left for the caller is FM_E_CAPACITY (its output
+// buffers are too small: *m_out = the capacity needed), FM_E_RANGE (bad input) and argument errors.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kAutoDataModes = FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_EXACT_STEP | FM_MODE_FLAT;
+
+// FM_E_DENSE after a call on the common path: the max pass, the screening kernel's lists and its per-sample flags in
+// the workspace are all valid - what is missing is the dense sum kernel's work on the flagged samples and an
+// assignment that reads it.  Continue from there instead of repeating prep, max pass and screening.
+int resume_with_dense(const void* feat0, const void* feat1, int in_dtype, int C, const CoarseWs& w, char* base,
+                      int h0c, int w0c, int h1c, int w1c, float inv_ct, float thr, int border_rm, float scale_px,
+                      const float* scale0, const float* scale1, int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                      float* mkpts0_c, float* mkpts1_c, float* mconf, int cap, int32_t* d_count, int mode, hipStream_t st) {
+  // what the first assignment launch left behind: its cell maps and tie lists, the workgroup totals of its look-back;
+  // and the FM_DEV_DENSE bit (dense_units, next to it, stays: the dense kernels read it)
+  hipError_t e = hipMemsetAsync(base + w.cell0, 0, w.rowmax_u - w.cell0, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(base + w.blocktot, 0, w.scalars - w.blocktot, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(base + w.scalars, 0, sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_prep_f16(feat0, feat1, in_dtype, C, w, base, 0, st);
+  if (e != hipSuccess) return (int)e;
+  e = launch_dense(w, base, inv_ct, thr, st);
+  if (e != hipSuccess) return (int)e;
+  return (int)launch_select(w, base, h0c, w0c, h1c, w1c, inv_ct, thr, border_rm, scale_px, scale0, scale1, b_ids, i_ids,
+                            j_ids, mkpts0_c, mkpts1_c, mconf, cap, d_count, mode | FM_MODE_DENSE, st, nullptr);
+}
+}  // namespace
+
+extern "C" int fm_coarse_workspace_bytes_auto(int N, int L, int S, int C, int max_cand_slots, size_t* bytes) {
+  if (max_cand_slots == 0) max_cand_slots = 64;
+  return fm_coarse_workspace_bytes(N, L, S, C, max_cand_slots, bytes);
+}
+
+extern "C" int fm_coarse_match_auto(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                                    int h0c, int w0c, int h1c, int w1c, float temperature, float thr, int border_rm,
+                                    float scale_px, const float* scale0, const float* scale1, void* workspace,
+                                    size_t workspace_bytes, int max_cand_slots, int mode, int64_t* b_ids, int64_t* i_ids,
+                                    int64_t* j_ids, float* mkpts0_c, float* mkpts1_c, float* mconf, int cap,
+                                    int32_t* d_count, float* conf_matrix, int32_t* hint_io, int32_t* m_out,
+                                    int32_t* info_out, void* stream) {
+  if (!m_out) return FM_E_NULL;
+  if (max_cand_slots == 0) max_cand_slots = 64;
+  if (!valid_slots(max_cand_slots)) return FM_E_UNSUPPORTED;
+  if (mode & ~kKnownModes) return FM_E_UNSUPPORTED;
+  if (!(thr > 0.f) || !(thr < 1.f)) return FM_E_UNSUPPORTED;
+  const int slots0 = fm_default_cand_slots(thr) < max_cand_slots ? fm_default_cand_slots(thr) : max_cand_slots;
+  // the caller's fixed options (cell maps, statistics) stay; the data-dependent bits it passes are a starting point
+  const int fixed = mode & ~kAutoDataModes;
+  const bool full_stats = conf_matrix != nullptr || (mode & FM_MODE_STATS) != 0;
+  int cur = mode & kAutoDataModes;
+  if (full_stats) cur |= FM_MODE_EXACT_SCREENING;        // (that path runs the denominator reduction the re-screening needs anyway)
+  int slots = slots0;
+  if (hint_io && *hint_io) {                             // what served the previous call of this kind
+    cur |= *hint_io & kAutoDataModes;
+    const int hs = (*hint_io >> 8) & 0xff;
+    if (valid_slots(hs) && hs <= max_cand_slots && hs > slots) slots = hs;
+  }
+  bool tried_wide = slots > slots0, retried_internal = false;
+  int st = FM_OK;
+  int32_t m = 0, info = 0;
+  int attempts = 0;
+  for (int attempt = 0; attempt < 10; ++attempt) {
+    ++attempts;
+    const int call_mode = fixed | cur | ((cur & FM_MODE_FLAT) ? FM_MODE_DENSE : 0);
+    // every attempt must fit the caller's workspace (sized by fm_coarse_workspace_bytes_auto for max_cand_slots)
+    st = fm_coarse_match_dtype(feat0, feat1, in_dtype, N, L, S, C, h0c, w0c, h1c, w1c, temperature, thr, border_rm, scale_px,
+                               scale0, scale1, workspace, workspace_bytes, slots, call_mode, b_ids, i_ids, j_ids, mkpts0_c,
+                               mkpts1_c, mconf, cap, d_count, conf_matrix, stream);
+    if (st != FM_OK) return st;
+    st = fm_read_count_info(d_count, cap, &m, &info, stream);
+    if (st == FM_E_DENSE && !(cur & FM_MODE_DENSE) && !conf_matrix && !(mode & FM_MODE_STATS)) {
+      // the common path's own results are still in the workspace: add the dense kernels' part and assign again
+      cur |= FM_MODE_DENSE;
+      const CoarseWs w = coarse_layout(N, L, S, C, slots);
+      if (workspace_bytes >= w.total) {
+        st = resume_with_dense(feat0, feat1, in_dtype, C, w, (char*)workspace, h0c, w0c, h1c, w1c,
+                               1.0f / ((float)C * temperature), thr, border_rm, scale_px, scale0, scale1, b_ids, i_ids, j_ids,
+                               mkpts0_c, mkpts1_c, mconf, cap, d_count, fixed | cur, (hipStream_t)stream);
+        if (st != FM_OK) return st;
+        st = fm_read_count_info(d_count, cap, &m, &info, stream);
+      } else {
+        continue;
+      }
+    }
+    if (st == FM_OK) break;
+    if (st == FM_E_STEP && !(cur & FM_MODE_EXACT_STEP)) { cur |= FM_MODE_EXACT_STEP; continue; }
+    if (st == FM_E_DENSE && !(cur & FM_MODE_DENSE)) { cur |= FM_MODE_DENSE; continue; }
+    if (st == FM_E_CANDIDATES && (cur & FM_MODE_DENSE) && !tried_wide && slots < 16 && max_cand_slots >= 16 &&
+        !(cur & FM_MODE_EXACT_SCREENING)) {
+      // rows without a peak next to peaked ones hold more near-candidates than the default slots: twice the slots and
+      // the int8 step from the images' true maxima (margins 1.5x narrower) before the exact re-screening sweep
+      slots = 16; cur |= FM_MODE_EXACT_STEP; tried_wide = true;
+      continue;
+    }
+    if (st == FM_E_CANDIDATES && !(cur & FM_MODE_EXACT_SCREENING)) {
+      if (tried_wide) slots = slots0;                    // the wider lists did not hold them either
+      cur |= FM_MODE_EXACT_SCREENING | FM_MODE_DENSE;
+      continue;
+    }
+    if (st == FM_E_CANDIDATES && slots < max_cand_slots) { slots *= 2; continue; }
+    if (st == FM_E_INTERNAL && !retried_internal) { retried_internal = true; continue; }
+    break;                                               // FM_E_CAPACITY, FM_E_RANGE, what persists: the caller's
+  }
+  *m_out = m;
+  if (info_out) *info_out = info;
+  if (hint_io && (st == FM_OK || st == FM_E_CAPACITY)) {
+    int learnt = cur & kAutoDataModes;
+    if (full_stats) learnt &= ~FM_MODE_EXACT_SCREENING | (mode & FM_MODE_EXACT_SCREENING);   // (implied by the request, not learnt)
+    // every sample went to the dense sum kernel: the next call of this kind skips the screening sweep (FM_MODE_FLAT)
+    if ((learnt & FM_MODE_DENSE) && !full_stats) {
+      if (info & FM_DEV_ALL_DENSE) learnt |= FM_MODE_FLAT; else learnt &= ~FM_MODE_FLAT;
+    }
+    *hint_io = learnt | (slots != slots0 ? slots << 8 : 0) | (attempts << 24);
+  }
+  return st;
 }
 
 // Device pointers of the cell -> (match index + 1) maps the coarse stage leaves in its workspace
@@ -378,13 +502,13 @@ extern "C" int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C,
 }
 
 // Diagnostic: launch the sparse sum kernel alone on a workspace a previous fm_coarse_match filled.
-extern "C" int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
+extern "C" int fm_debug_launch_screen(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
                                           int C, int cand_slots, float temperature, float thr, void* stream) {
   if (!workspace || !feat0 || !feat1) return FM_E_NULL;
   const int bad = check_coarse_shape(N, L, S, C, cand_slots);
   if (bad) return bad;
   const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
-  return (int)launch_sum_sparse(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, 1, 1,
+  return (int)launch_screen(feat0, feat1, FM_F32, C, w, (char*)workspace, 1.0f / ((float)C * temperature), thr, 1, 1,
                                 (hipStream_t)stream);
 }
 

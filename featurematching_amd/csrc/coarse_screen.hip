@@ -850,7 +850,7 @@ hipError_t launch_stab(const CoarseWs& w, char* base, float inv_ct, float thr, i
   return hipGetLastError();
 }
 
-hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
+hipError_t launch_screen(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                              float inv_ct, float thr, int dense_enabled, int allow_dead, hipStream_t st) {
   ScreenArgs a;
   a.in_dtype = in_dtype;

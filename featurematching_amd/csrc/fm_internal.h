@@ -117,8 +117,8 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1
                          const MapCopyJob* job = nullptr);
 hipError_t launch_conf_patch(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
 // (the batched form of the screening - k_thresh + k_screen_rows, one wave per (row block, 64 units) - is chosen inside
-// launch_sum_sparse when the batch alone fills the chip with waves)
-hipError_t launch_sum_sparse(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
+// launch_screen when the batch alone fills the chip with waves)
+hipError_t launch_screen(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
                              float inv_ct, float thr, int dense_enabled, int allow_dead, hipStream_t st);
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, device) instead of on every launch: the

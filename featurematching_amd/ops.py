@@ -119,7 +119,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
-    the up-cast tensors).  The common path is four launches (prep, int8 max pass, sparse sum kernel, assignment);
+    the up-cast tensors).  The common path is four launches (prep, int8 max pass, screening kernel, assignment);
     `dense` (FM_MODE_DENSE) adds the float16 planes and the dense sum kernel for samples with flat similarity (without
     it such samples report FM_E_DENSE through read_count), `exact_screening` (FM_MODE_EXACT_SCREENING) the two kernels
     that re-screen the candidates with exact softmax denominators (without it rows / columns that overflow their
@@ -202,182 +202,151 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     return out
 
 
-class ModeMemory:
-    """Which optional passes of the coarse stage a problem shape needed the last time it was seen.
+class HintMemory:
+    """The `hint_io` word of fm_coarse_match_auto, kept per problem kind.
 
-    `coarse_match` starts on the common path (four launches) and repeats a call with FM_MODE_DENSE / the exact
-    screening pass when the device reports FM_E_DENSE / FM_E_CANDIDATES.  Flat similarity - an untrained network, a
-    tiny thr, textureless images - would pay for the coarse stage twice on every forward, so the shape's flags are
-    remembered.  The memory is explicit and bounded:
+    fm_coarse_match_auto (C) answers what the data asks for by itself - flat similarity, candidate overflow, a clipped
+    int8 step - and leaves the mode that served the call in a hint word; a call that starts from that word does not
+    repeat the failing attempts (flat data runs FM_MODE_FLAT from its second call on).  This class only stores the word:
       * keyed by (shapes, thr, temperature); at most `capacity` keys, least recently used dropped first;
-      * it DECAYS: every `reprobe`-th call of a remembered shape runs on the common path again; when that call succeeds
-        the flags are forgotten (one flat sample does not tax a shape forever), when it fails it is repeated as before;
+      * it DECAYS: every `reprobe`-th call of a remembered key passes no hint; when the common path then serves the
+        call the key is forgotten, otherwise the new word replaces the old one;
       * guarded by a lock (module callers may run on several threads / streams);
-      * visible: `snapshot()` lists what is remembered and how often each flag was learnt, `clear()` forgets it.
-    Callers that know their data pass dense= / exact_screening= themselves and never touch it."""
+      * visible: `snapshot()` decodes what is remembered, `clear()` forgets it.
+    A hint is never wrong, only possibly slower than the common path.  Callers that pass modes themselves bypass it."""
 
     def __init__(self, capacity: int = 64, reprobe: int = 64):
         import threading
         from collections import OrderedDict
         self._lock = threading.Lock()
-        self._d = OrderedDict()          # key -> {'dense', 'exact', 'step', 'flat', 'wide': bool, 'calls': int, 'learnt': int}
+        self._d = OrderedDict()          # key -> [hint word, calls]
         self.capacity, self.reprobe = capacity, reprobe
 
     def start(self, key):
-        """(dense, exact_screening, probing) to begin a call with; `step(key)` tells the third flag"""
+        """(hint word to begin the call with, probing?)"""
         with self._lock:
             e = self._d.get(key)
             if e is None:
-                return False, False, False
+                return 0, False
             self._d.move_to_end(key)
-            e['calls'] += 1
-            if e['calls'] % self.reprobe == 0:
-                return False, False, True
-            return e['dense'], e['exact'], False
+            e[1] += 1
+            if e[1] % self.reprobe == 0:
+                return 0, True
+            return e[0], False
 
-    def step(self, key, probing=False):
-        """start the call with the exact int8 step (FM_MODE_EXACT_STEP)?"""
+    def finish(self, key, hint: int):
+        """store what fm_coarse_match_auto left in hint_io (0 = the common path served the call: forget the key)"""
+        hint &= 0xffff                   # (mode bits + slots; the attempts byte is per call)
         with self._lock:
+            if hint == 0:
+                self._d.pop(key, None)
+                return
             e = self._d.get(key)
-            return bool(e and e['step'] and not probing)
-
-    def flat(self, key, probing=False):
-        """start the call with the flat-similarity hint (FM_MODE_FLAT)?  Learnt when a dense call of this shape reported
-        that EVERY sample went to the dense sum kernel (FM_DEV_ALL_DENSE); forgotten with the other flags."""
-        with self._lock:
-            e = self._d.get(key)
-            return bool(e and e.get('flat') and not probing)
-
-    def wide(self, key, probing=False):
-        """start the call with 16 candidate slots (and the exact int8 step)?  Learnt when a DENSE call of this shape
-        overflowed the default 8 slots - rows without a peak next to peaked ones hold ~20 near-candidates at the sampled
-        step's margins, ~7 at the exact step's: twice the slots and FM_MODE_EXACT_STEP then serve the call without the
-        exact re-screening sweep (37 us per 640x480 pair)."""
-        with self._lock:
-            e = self._d.get(key)
-            return bool(e and e.get('wide') and not probing)
-
-    def learn(self, key, dense=False, exact=False, step=False, flat=None, wide=None):
-        with self._lock:
-            e = self._d.setdefault(key, {'dense': False, 'exact': False, 'step': False, 'flat': False, 'wide': False,
-                                         'calls': 0, 'learnt': 0})
-            if wide is not None:
-                e['wide'] = bool(wide)
-            e['dense'] |= bool(dense)
-            e['exact'] |= bool(exact)
-            e['step'] |= bool(step)
-            if flat is not None:
-                e['flat'] = bool(flat)
-            e['learnt'] += 1
+            if e is None:
+                self._d[key] = [hint, 0]
+            else:
+                e[0] = hint
             self._d.move_to_end(key)
             while len(self._d) > self.capacity:
                 self._d.popitem(last=False)
-
-    def forget(self, key):
-        with self._lock:
-            self._d.pop(key, None)
 
     def clear(self):
         with self._lock:
             self._d.clear()
 
+    @staticmethod
+    def decode(hint: int) -> dict:
+        return {'dense': bool(hint & (_lib.FM_MODE_DENSE | _lib.FM_MODE_FLAT)), 'exact': bool(hint & _lib.FM_MODE_EXACT_SCREENING),
+                'step': bool(hint & _lib.FM_MODE_EXACT_STEP), 'flat': bool(hint & _lib.FM_MODE_FLAT),
+                'slots': (hint >> 8) & 0xff, 'wide': ((hint >> 8) & 0xff) >= 16, 'attempts': (hint >> 24) & 0xff}
+
     def snapshot(self):
         with self._lock:
-            return {k: dict(v) for k, v in self._d.items()}
+            return {k: dict(self.decode(v[0]), calls=v[1], hint=v[0]) for k, v in self._d.items()}
 
 
-MODE_MEMORY = ModeMemory()
+MODE_MEMORY = HintMemory()
+_AUTO_WS_BYTES = {}
 
 
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
                  scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None,
                  dense: Optional[bool] = None, exact_step: Optional[bool] = None, stats: bool = False,
-                 flat: Optional[bool] = None) -> dict:
-    """Synchronous form: sliced outputs.  Retries with a larger capacity (exact ties can exceed
-    N*min(L,S)), with the dense sum kernel (FM_E_DENSE), with the exact screening pass, then with more candidate
-    slots when the device reports the corresponding condition, with the exact int8 step when the sampled one clipped an
-    outlier (FM_E_STEP), and once more when the assignment kernel's bounded wait ran out (FM_E_INTERNAL: "call again",
-    fmatch.h).  exact_screening=None: on when conf_matrix is
-    requested (that path already runs the denominator reduction the exact screening needs, and it is the training /
-    untrained-network mode in which flat rows occur) or when MODE_MEMORY holds it for this shape; dense=None likewise.
-    flat=None: the FM_MODE_FLAT hint is taken from MODE_MEMORY - learnt when a dense call of this shape reports that
-    every sample went to the dense sum kernel (FM_DEV_ALL_DENSE), dropped with the other flags at the next re-probe."""
+                 flat: Optional[bool] = None, cell_maps: bool = True) -> dict:
+    """Synchronous form: sliced outputs.  A thin caller of fm_coarse_match_auto - the ONE C entry point that serves any
+    data (flat similarity, candidate overflow, a clipped int8 step and the assignment's bounded wait are answered inside
+    it, behind the host sync the reference's torch.where has at coarse_matching_new.py:109).  What is left here: the
+    allocations, FM_E_CAPACITY (exact ties can exceed N*min(L,S): larger output buffers, once more) and the optional
+    hint word per problem kind (MODE_MEMORY: flat data starts its second call where the first ended).
+    exact_screening / dense / exact_step / flat: None = left to the library (and the hint); True = the mode to START
+    with (a caller that knows its data).  conf_matrix / stats as in coarse_match_async."""
     lib = _lib.load()
+    f0 = _desc(feat_c0, "feat_c0")
+    f1 = _desc(feat_c1, "feat_c1")
+    if f1.dtype != f0.dtype:
+        f1 = f1.to(f0.dtype)
+    n, l, c = f0.shape
+    s = f1.shape[1]
+    if f1.shape[0] != n or f1.shape[2] != c:
+        raise ValueError(f"feat_c0 {tuple(f0.shape)} and feat_c1 {tuple(f1.shape)} disagree")
+    dev = f0.device
     key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
-    all_auto = exact_screening is None and dense is None and exact_step is None and flat is None
-    mem_dense, mem_exact, probing = (False, False, False)
-    if exact_screening is None or dense is None or exact_step is None:
-        mem_dense, mem_exact, probing = MODE_MEMORY.start(key)
-    if exact_step is None:
-        exact_step = MODE_MEMORY.step(key, probing)
-    if exact_screening is None:
-        exact_screening = bool(conf_matrix) or bool(stats) or mem_exact
-    managed_flat = flat is None
-    if dense is None:
-        dense = mem_dense
-    if flat is None:
-        flat = bool(dense) and MODE_MEMORY.flat(key, probing)
-    kw = dict(cap=None, cand_slots=int(lib.fm_default_cand_slots(float(thr))), exact_screening=bool(exact_screening),
-              dense=bool(dense) or bool(flat), exact_step=bool(exact_step), flat=bool(flat))
-    managed = all_auto and not conf_matrix and not stats             # (the caller left every mode to the memory)
-    tried_wide = False
-    if managed and kw['dense'] and kw['cand_slots'] < 16 and MODE_MEMORY.wide(key, probing):
-        kw['cand_slots'], kw['exact_step'], tried_wide = 16, True, True
-        kw['exact_screening'] = False                                 # (what the wider lists replace)
-    retried_internal = False
-    for _ in range(8):
-        buf = coarse_match_async(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr, border_rm, temperature,
-                                 scale0, scale1, conf_matrix=conf_matrix, stats=stats, **kw)
-        try:
-            m = buf.read_count()
-        except _lib.FMatchError as e:
-            if e.status == _lib.FM_E_CAPACITY:
-                kw['cap'] = int(e.required)
-                continue
-            if e.status == _lib.FM_E_STEP and not kw['exact_step']:
-                kw['exact_step'] = True
-                MODE_MEMORY.learn(key, step=True)
-                probing = False
-                continue
-            if e.status == _lib.FM_E_DENSE and not kw['dense']:
-                kw['dense'] = True
-                MODE_MEMORY.learn(key, dense=True)
-                probing = False
-                continue
-            if e.status == _lib.FM_E_CANDIDATES and managed and kw['dense'] and not tried_wide and kw['cand_slots'] < 16 \
-                    and not kw['exact_screening']:
-                # a dense call whose rows hold more near-candidates than 8 slots: twice the slots + the exact int8 step
-                # (margins 1.5x narrower) before the exact re-screening sweep
-                kw['cand_slots'], kw['exact_step'], tried_wide = 16, True, True
-                MODE_MEMORY.learn(key, dense=True, wide=True)
-                probing = False
-                continue
-            if e.status == _lib.FM_E_CANDIDATES and not kw['exact_screening']:
-                if tried_wide:                       # the wider lists did not hold them either: back to the default
-                    kw['cand_slots'] = int(lib.fm_default_cand_slots(float(thr)))
-                    MODE_MEMORY.learn(key, wide=False)
-                kw['exact_screening'] = True
-                MODE_MEMORY.learn(key, exact=True)
-                probing = False
-                continue
-            if e.status == _lib.FM_E_CANDIDATES and kw['cand_slots'] < 64:
-                kw['cand_slots'] = min(64, kw['cand_slots'] * 2)
-                continue
-            if e.status == _lib.FM_E_INTERNAL and not retried_internal:
-                retried_internal = True
-                continue
-            raise
-        if probing:                      # the common path served a shape that once needed more: forget the flags
-            MODE_MEMORY.forget(key)
-        elif managed_flat and kw['dense'] and not conf_matrix and not stats:
-            all_dense = bool(getattr(buf, 'info', 0) & _lib.FM_DEV_ALL_DENSE)
-            if all_dense != kw['flat']:  # every sample went to the dense kernel: skip the screening sweep next time
-                MODE_MEMORY.learn(key, dense=True, flat=all_dense)
-        out = buf.sliced(m)
+    managed = exact_screening is None and dense is None and exact_step is None and flat is None
+    mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
+           (_lib.FM_MODE_EXACT_STEP if exact_step else 0) | (_lib.FM_MODE_FLAT if flat else 0) | \
+           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_STATS if stats else 0)
+    hint0, probing = MODE_MEMORY.start(key) if managed else (0, False)
+    sc0 = None if scale0 is None else _f32c(scale0.to(dev), "scale0")
+    sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
+    i64 = dict(dtype=torch.int64, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    cap = n * min(l, s)
+    max_slots = 16                      # (64 only when 16 slots and the exact re-screening still overflow: thr < 1/16)
+    conf = torch.empty(n, l, s, **f32) if conf_matrix else None
+    for _ in range(4):
+        wkey = (n, l, s, c, max_slots)
+        ws_bytes = _AUTO_WS_BYTES.get(wkey)
+        if ws_bytes is None:
+            nb = C.c_size_t(0)
+            _lib.check(lib.fm_coarse_workspace_bytes_auto(n, l, s, c, max_slots, C.byref(nb)), "fm_coarse_workspace_bytes_auto")
+            if len(_AUTO_WS_BYTES) > 256:
+                _AUTO_WS_BYTES.clear()
+            ws_bytes = _AUTO_WS_BYTES[wkey] = int(nb.value)
+        ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        out = CoarseBuffers(torch.empty(cap, **i64), torch.empty(cap, **i64), torch.empty(cap, **i64),
+                            torch.empty(cap, 2, **f32), torch.empty(cap, 2, **f32), torch.empty(cap, **f32),
+                            torch.empty(2, dtype=torch.int32, device=dev), cap, ws)
+        out.conf_matrix = conf
+        hint, m, info = C.c_int32(hint0), C.c_int32(0), C.c_int32(0)
+        st = lib.fm_coarse_match_auto(_ptr(f0), _ptr(f1), _DTYPES[f0.dtype], n, l, s, c, int(hw0_c[0]), int(hw0_c[1]),
+                                      int(hw1_c[0]), int(hw1_c[1]), float(temperature), float(thr), int(border_rm),
+                                      float(scale_px), _ptr(sc0), _ptr(sc1), C.c_void_p(ws.data_ptr() + off), ws_bytes,
+                                      max_slots, mode, _ptr(out.b_ids), _ptr(out.i_ids), _ptr(out.j_ids),
+                                      _ptr(out.mkpts0_c), _ptr(out.mkpts1_c), _ptr(out.mconf), cap, _ptr(out.count),
+                                      _ptr(conf), C.byref(hint), C.byref(m), C.byref(info), _stream(dev))
+        if st == _lib.FM_E_CAPACITY:
+            cap, hint0 = int(m.value), int(hint.value) & 0xffff
+            continue
+        if st == _lib.FM_E_CANDIDATES and max_slots < 64:
+            max_slots, hint0 = 64, int(hint.value) & 0xffff
+            continue
+        _lib.check(st, "fm_coarse_match_auto")
+        if managed:
+            MODE_MEMORY.finish(key, int(hint.value))
+        h = int(hint.value)
+        slots_used = ((h >> 8) & 0xff) or int(lib.fm_default_cand_slots(float(thr)))
+        out.info, out.hint, out.attempts = int(info.value), h & 0xffff, (h >> 24) & 0xff
+        out._keep = (f0, f1, sc0, sc1)
+        out._shape = (n, l, s, c, slots_used)
+        out._has_cell_maps = bool(cell_maps)
+        out._has_stats = bool(stats or conf_matrix)
+        out._temperature = float(temperature)
+        res = out.sliced(int(m.value))
         if conf_matrix:
-            out['conf_matrix'] = buf.conf_matrix
-        out['_coarse_buffers'] = buf          # keeps the workspace (and its cell maps) alive
-        return out
+            res['conf_matrix'] = conf
+        res['_coarse_buffers'] = out          # keeps the workspace (and its cell maps) alive
+        return res
     raise RuntimeError("coarse_match: overflow persisted after retries")
 
 

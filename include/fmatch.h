@@ -48,7 +48,7 @@ enum fm_status {
                             large (several thousand: |f0||f1| / (C*temperature)) that the int8 screening margin alone,
                             2^60 in the log2 domain, could overflow the float32 exponentials */
   FM_E_DENSE = -8,       /* (device status) a sample's similarity is flat (more significant entries per 32 x 32 unit
-                            than the sparse sum kernel resolves: an untrained network, textureless images); its result
+                            than the screening kernel resolves: an untrained network, textureless images); its result
                             is incomplete: call again with mode | FM_MODE_DENSE */
   FM_E_INTERNAL = -9,    /* (device status) the assignment kernel's bounded wait for its predecessor workgroups ran
                             out (never observed; the outputs are incomplete): call again */
@@ -64,7 +64,7 @@ enum fm_status {
 /* `mode` bits of fm_coarse_match / fm_coarse_workspace_bytes_mode (0 = the common path: 4 launches) */
 #define FM_MODE_EXACT_SCREENING 1 /* two more kernels re-screen the candidates with the exact softmax denominators */
 #define FM_MODE_DENSE 2           /* float16 planes + the dense sum kernel (float32-equivalent product on the matrix
-                                     cores) for the samples the sparse sum kernel flags; both exit at once otherwise */
+                                     cores) for the samples the screening kernel flags; both exit at once otherwise */
 #define FM_MODE_NO_CELL_MAPS 4    /* skip the cell -> match maps of fm_coarse_cell_maps (two returning atomics per match):
                                      for callers that do not use the cell-ordered window crops */
 #define FM_MODE_STATS 16          /* also leave the log-softmax offsets of EVERY row and column in the workspace
@@ -124,7 +124,7 @@ int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int cand_slots, i
  *   mconf float32[cap]; d_count int32[2] = {M, status bits}.
  *   conf_matrix: optional [dev] float32 [N,L,S] (data['conf_matrix'], :70) or NULL.
  *   mode (the former exact_screening flag, same values for 0 / 1): 0 = the common path - prep, int8 max pass,
- *   sparse sum kernel, assignment: candidates are screened in the sum sweep against lower bounds of the row / column
+ *   screening kernel, assignment: candidates are screened in that sweep against lower bounds of the row / column
  *   maxima, which is enough for dual-softmax-trained descriptors; flat similarity reports FM_E_DENSE (a whole sample
  *   has no peaks) or FM_E_CANDIDATES (single rows overflow their cand_slots) through the status word.
  *   FM_MODE_DENSE adds the float16 planes and the dense sum kernel for flagged samples, FM_MODE_EXACT_SCREENING
@@ -178,30 +178,46 @@ int fm_coarse_match_maps(const void* feat0, const void* feat1, int in_dtype, int
                          int cap, int32_t* d_count, float* conf_matrix,
                          const float* feat_f1, int Nf, int Cf, int Hf1, int Wf1, void* scratch1, void* stream);
 
-/* Diagnostic only: workspace layout of fm_coarse_match (40 values: 10 ints, byte offsets, the sparse
- * sum kernel's split geometry, total; order documented in csrc/api.hip) so tests can inspect
- * intermediate statistics. */
-int fm_debug_coarse_layout(int N, int L, int S, int C, int cand_slots, int64_t* out, int n_out);
-
-/* Diagnostic only: launch one kernel of the coarse stage (fm_debug_launch_corr: mode 0 = max pass,
- * 1 = dense sum kernel, 2 = exact screening sweep; fm_debug_launch_sum_sparse: the sparse sum kernel) on a
- * workspace filled by a previous fm_coarse_match of the same shapes and inputs / zero the candidate counters
- * and scalars so that the sum kernels can run again; used by bench.py to bracket the dominant kernels with
- * events on their own stream.  Modes 1 / 2 and fm_debug_launch_prep_f16 need a full-size workspace
- * (fm_coarse_workspace_bytes). */
-int fm_debug_launch_corr(void* workspace, int N, int L, int S, int C, int cand_slots,
-                         float temperature, float thr, int mode, void* stream);
-int fm_debug_launch_sum_sparse(void* workspace, const float* feat0, const float* feat1, int N, int L, int S,
-                               int C, int cand_slots, float temperature, float thr, void* stream);   /* float32 rows */
-int fm_debug_launch_prep(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
-                         int cand_slots, void* stream);      /* k_prep_split alone; clears the per-call counters */
-int fm_debug_launch_prep_f16(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
-                             int cand_slots, int force, void* stream);
-int fm_debug_reset_counters(void* workspace, int N, int L, int S, int C, int cand_slots, void* stream);
-/* FM_MODE_FLAT's two own launches alone: which = 0 k_prep_split with the float16 planes (clears the per-call counters
- * like fm_debug_launch_prep), which = 1 the stabiliser kernel k_stab.  Full-size workspace. */
-int fm_debug_launch_flat(void* workspace, const float* feat0, const float* feat1, int N, int L, int S, int C,
-                         int cand_slots, float temperature, float thr, int which, void* stream);
+/*
+ * ONE call for any data: CoarseMatching.forward is one call in the reference (coarse_matching_new.py:43-73), and so is
+ * this.  fm_coarse_match / _dtype enqueue exactly the kernels `mode` names and report what the data would have needed
+ * through the status word; this function runs the common path, reads that word (a host sync on `stream`, where the
+ * reference's torch.where syncs, :109) and answers it by itself:
+ *   flat similarity (FM_E_DENSE)          -> the dense sum kernel's part is ADDED to what the common path left in the
+ *                                            workspace (float16 planes, dense sums, a second assignment launch: the
+ *                                            max pass and the screening are not repeated)
+ *   candidate-slot overflow (FM_E_CANDIDATES) -> 16 slots + FM_MODE_EXACT_STEP on dense data, then the exact
+ *                                            re-screening (FM_MODE_EXACT_SCREENING), then more slots up to max_cand_slots
+ *   clipped int8 step (FM_E_STEP)         -> FM_MODE_EXACT_STEP
+ *   the assignment's bounded wait (FM_E_INTERNAL) -> once more
+ * Returns FM_OK with *m_out = M (the outputs hold M matches), FM_E_CAPACITY with *m_out = the capacity the outputs need
+ * (call again with larger buffers; exact ties can exceed N*min(L,S)), FM_E_RANGE for descriptors that are not finite
+ * or out of range, an argument error, or a hipError_t.  Never FM_E_DENSE / FM_E_STEP; FM_E_CANDIDATES only when
+ * max_cand_slots slots do not hold a row's candidates even after the exact re-screening (thr < 1 / max_cand_slots).
+ *   workspace: fm_coarse_workspace_bytes_auto(N, L, S, C, max_cand_slots) bytes (any mode, max_cand_slots slots;
+ *              max_cand_slots = 0 means 64); a smaller workspace is used as far as it goes (FM_E_WORKSPACE beyond).
+ *   mode: the options that do not depend on the data (FM_MODE_NO_CELL_MAPS, FM_MODE_STATS); data-dependent bits are
+ *         taken as the mode to START with (a caller that knows its data saves the first, failing attempt).
+ *   conf_matrix: optional [dev] float32 [N,L,S] or NULL, as in fm_coarse_match.
+ *   hint_io: optional HOST int32.  In: 0, or the value a previous call on data of this kind left there - the call
+ *            then starts where that one ended (flat data: FM_MODE_FLAT, no screening sweep; ...).  Out: the mode bits
+ *            (low byte) and cand_slots (second byte, 0 = default) that served this call, and the number of coarse
+ *            launches sequences it took (fourth byte, informational).  A hint is never wrong, only possibly slower
+ *            than the common path: pass 0 every so often to find out whether the data has changed (the Python layer
+ *            does, every 64th call of a shape).
+ *   info_out: optional, the raw FM_DEV_* status bits of the attempt that served the call.
+ * All other arguments as fm_coarse_match_dtype.
+ */
+int fm_coarse_workspace_bytes_auto(int N, int L, int S, int C, int max_cand_slots, size_t* bytes);
+int fm_coarse_match_auto(const void* feat0, const void* feat1, int in_dtype, int N, int L, int S, int C,
+                         int h0c, int w0c, int h1c, int w1c,
+                         float temperature, float thr, int border_rm, float scale_px,
+                         const float* scale0, const float* scale1,
+                         void* workspace, size_t workspace_bytes, int max_cand_slots, int mode,
+                         int64_t* b_ids, int64_t* i_ids, int64_t* j_ids,
+                         float* mkpts0_c, float* mkpts1_c, float* mconf,
+                         int cap, int32_t* d_count, float* conf_matrix,
+                         int32_t* hint_io, int32_t* m_out, int32_t* info_out, void* stream);
 
 /* Copy {M, status} to the host and wait for the stream (the one host sync of the
  * path, where the reference's torch.where syncs: coarse_matching_new.py:109).

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "fmatch.h"
+#include "../../featurematching_amd/csrc/fm_debug.h"
 
 static int checks = 0, failures = 0;
 #define EXPECT(expr, want)                                                                  \
@@ -35,7 +36,7 @@ static __typeof__(fm_coarse_match)* p_fm_coarse_match;
 static __typeof__(fm_coarse_match_dtype)* p_fm_coarse_match_dtype;
 static __typeof__(fm_debug_coarse_layout)* p_fm_debug_coarse_layout;
 static __typeof__(fm_debug_launch_corr)* p_fm_debug_launch_corr;
-static __typeof__(fm_debug_launch_sum_sparse)* p_fm_debug_launch_sum_sparse;
+static __typeof__(fm_debug_launch_screen)* p_fm_debug_launch_screen;
 static __typeof__(fm_debug_launch_prep_f16)* p_fm_debug_launch_prep_f16;
 static __typeof__(fm_debug_launch_prep)* p_fm_debug_launch_prep;
 static __typeof__(fm_fine_match_maps)* p_fm_fine_match_maps;
@@ -64,6 +65,8 @@ static __typeof__(fm_coarse_match_maps)* p_fm_coarse_match_maps;
 static __typeof__(fm_read_count_info)* p_fm_read_count_info;
 static __typeof__(fm_debug_launch_flat)* p_fm_debug_launch_flat;
 static __typeof__(fm_fine_transformer_start)* p_fm_fine_transformer_start;
+static __typeof__(fm_coarse_match_auto)* p_fm_coarse_match_auto;
+static __typeof__(fm_coarse_workspace_bytes_auto)* p_fm_coarse_workspace_bytes_auto;
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s libfmatch_hip.so\n", argv[0]); return 2; }
@@ -71,13 +74,14 @@ int main(int argc, char** argv) {
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   RESOLVE(fm_version); RESOLVE(fm_strerror); RESOLVE(fm_default_cand_slots); RESOLVE(fm_coarse_workspace_bytes); RESOLVE(fm_coarse_workspace_bytes_mode);
   RESOLVE(fm_coarse_match); RESOLVE(fm_coarse_match_dtype); RESOLVE(fm_debug_coarse_layout); RESOLVE(fm_debug_launch_corr);
-  RESOLVE(fm_debug_launch_sum_sparse); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_fine_match_maps); RESOLVE(fm_fine_match_maps_dtype); RESOLVE(fm_coarse_softmax_stats); RESOLVE(fm_dual_softmax_conf_at); RESOLVE(fm_dual_softmax_backward); RESOLVE(fm_dual_softmax_backward_workspace_bytes); RESOLVE(fm_fine_maps_scratch_bytes_dtype); RESOLVE(fm_fine_maps_scratch_bytes); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
+  RESOLVE(fm_debug_launch_screen); RESOLVE(fm_debug_launch_prep_f16); RESOLVE(fm_debug_launch_prep); RESOLVE(fm_fine_match_maps); RESOLVE(fm_fine_match_maps_dtype); RESOLVE(fm_coarse_softmax_stats); RESOLVE(fm_dual_softmax_conf_at); RESOLVE(fm_dual_softmax_backward); RESOLVE(fm_dual_softmax_backward_workspace_bytes); RESOLVE(fm_fine_maps_scratch_bytes_dtype); RESOLVE(fm_fine_maps_scratch_bytes); RESOLVE(fm_debug_reset_counters); RESOLVE(fm_read_count);
   RESOLVE(fm_gather_windows); RESOLVE(fm_coarse_cell_maps); RESOLVE(fm_gather_windows_cells);
   RESOLVE(fm_merge_pack_weights); RESOLVE(fm_gather_merge_windows); RESOLVE(fm_gather_windows_pair);
   RESOLVE(fm_fine_match); RESOLVE(fm_epipolar_errors);
   RESOLVE(fm_coarse_tf_packed_bytes); RESOLVE(fm_coarse_tf_workspace_bytes); RESOLVE(fm_coarse_tf_pack_weights);
   RESOLVE(fm_coarse_transformer);
   RESOLVE(fm_coarse_match_maps); RESOLVE(fm_read_count_info); RESOLVE(fm_debug_launch_flat); RESOLVE(fm_fine_transformer_start);
+  RESOLVE(fm_coarse_match_auto); RESOLVE(fm_coarse_workspace_bytes_auto);
 
   EXPECT(p_fm_version(), FM_VERSION);
   for (int s = FM_E_INTERNAL; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
@@ -166,6 +170,32 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, odd, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
   EXPECT(p_fm_coarse_match_dtype(one, one, 7, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match_dtype(NULL, one, FM_F16, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_NULL);
+  {   /* fm_coarse_match_auto: every refusal comes back before anything is enqueued */
+    size_t ab = 0, a16 = 0;
+    int32_t am = 0, ainfo = 0, hint = 0;
+    EXPECT(p_fm_coarse_workspace_bytes_auto(1, 4800, 4800, 256, 0, &ab), FM_OK);            /* 0 = 64 slots */
+    EXPECT(p_fm_coarse_workspace_bytes_auto(1, 4800, 4800, 256, 16, &a16), FM_OK);
+    EXPECT(ab > a16 && a16 >= full, 1);
+    EXPECT(p_fm_coarse_workspace_bytes_auto(1, 4800, 4800, 256, 12, &ab), FM_E_UNSUPPORTED);
+    EXPECT(p_fm_coarse_workspace_bytes_auto(0, 4800, 4800, 256, 0, &ab), FM_E_SHAPE);
+    EXPECT(p_fm_coarse_workspace_bytes_auto(1, 4800, 4800, 256, 0, NULL), FM_E_NULL);
+#define AUTO(f0, ws, wsb, slots, mode, thr, cntp, mp) \
+    p_fm_coarse_match_auto(f0, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, thr, 2, 8.f, NULL, NULL, ws, wsb, slots, mode, \
+                           one, one, one, one, one, one, 64, cntp, NULL, &hint, mp, &ainfo, NULL)
+    EXPECT(AUTO(one, one, 1u << 30, 0, 0, 0.2f, cnt, NULL), FM_E_NULL);                     /* m_out is required */
+    EXPECT(AUTO(NULL, one, 1u << 30, 0, 0, 0.2f, cnt, &am), FM_E_NULL);
+    EXPECT(AUTO(one, NULL, 1u << 30, 0, 0, 0.2f, cnt, &am), FM_E_NULL);
+    EXPECT(AUTO(one, one, 1u << 30, 0, 0, 0.2f, NULL, &am), FM_E_NULL);
+    EXPECT(AUTO(one, one, 1u << 30, 24, 0, 0.2f, cnt, &am), FM_E_UNSUPPORTED);               /* slots not a power of two */
+    EXPECT(AUTO(one, one, 1u << 30, 0, 64, 0.2f, cnt, &am), FM_E_UNSUPPORTED);               /* unknown mode bit */
+    EXPECT(AUTO(one, one, 1u << 30, 0, 0, 1.0f, cnt, &am), FM_E_UNSUPPORTED);                /* thr */
+    EXPECT(AUTO(one, one, 16, 0, 0, 0.2f, cnt, &am), FM_E_WORKSPACE);
+    EXPECT(AUTO(one, odd, 1u << 30, 0, 0, 0.2f, cnt, &am), FM_E_WORKSPACE);
+    EXPECT(p_fm_coarse_match_auto(one, one, FM_F32, 1, 63, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 0, 0,
+                                  one, one, one, one, one, one, 64, cnt, NULL, NULL, &am, NULL, NULL), FM_E_SHAPE);
+    EXPECT(hint, 0);                                                                        /* untouched by refusals */
+#undef AUTO
+  }
   int32_t m = 0;
   EXPECT(p_fm_read_count(NULL, 4, &m, NULL), FM_E_NULL);
   EXPECT(p_fm_read_count(cnt, 4, NULL, NULL), FM_E_NULL);
@@ -179,8 +209,8 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_debug_launch_corr(NULL, 1, 64, 64, 64, 8, 0.1f, 0.2f, 1, NULL), FM_E_NULL);
   EXPECT(p_fm_debug_launch_corr(one, 1, 64, 64, 64, 8, 0.1f, 0.2f, 9, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_debug_launch_corr(one, 0, 64, 64, 64, 8, 0.1f, 0.2f, 1, NULL), FM_E_SHAPE);
-  EXPECT(p_fm_debug_launch_sum_sparse(one, NULL, one, 1, 64, 64, 64, 8, 0.1f, 0.2f, NULL), FM_E_NULL);
-  EXPECT(p_fm_debug_launch_sum_sparse(one, one, one, 1, 64, 64, 64, 16 + 1, 0.1f, 0.2f, NULL), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_debug_launch_screen(one, NULL, one, 1, 64, 64, 64, 8, 0.1f, 0.2f, NULL), FM_E_NULL);
+  EXPECT(p_fm_debug_launch_screen(one, one, one, 1, 64, 64, 64, 16 + 1, 0.1f, 0.2f, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_debug_launch_prep_f16(one, one, NULL, 1, 64, 64, 64, 8, 1, NULL), FM_E_NULL);
   EXPECT(p_fm_debug_launch_prep(one, NULL, one, 1, 64, 64, 64, 8, NULL), FM_E_NULL);
   EXPECT(p_fm_debug_launch_prep(one, one, one, 1, 64, 64, 63, 8, NULL), FM_E_UNSUPPORTED);

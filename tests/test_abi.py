@@ -11,8 +11,8 @@ from featurematching_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "fmatch.h")).read()
+def declared_symbols(path=("include", "fmatch.h")):
+    text = open(os.path.join(ROOT, *path)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fm_[a-z_0-9]+)\s*\(", text)))
 
@@ -25,6 +25,13 @@ def test_header_symbols_are_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in fmatch.h but not exported"
     assert set(_lib.SIGNATURES) == set(syms)
+    # the public header is the boundary a maintainer of the reference reads: no diagnostics in it; those live in
+    # csrc/fm_debug.h (bench.py / tools/ bracket single kernels with them) and are exported too
+    assert not [s for s in syms if s.startswith("fm_debug_")]
+    dbg = declared_symbols(("featurematching_amd", "csrc", "fm_debug.h"))
+    assert dbg and all(s.startswith("fm_debug_") for s in dbg) and set(_lib.DEBUG_SIGNATURES) == set(dbg)
+    for s in dbg:
+        assert hasattr(lib, s), f"{s} declared in fm_debug.h but not exported"
 
 
 def test_version_and_messages():
@@ -112,8 +119,8 @@ def test_debug_entry_points_validate_their_shapes():
     assert lib.fm_debug_reset_counters(None, 1, 64, 64, 64, 8, None) == -1
     assert lib.fm_debug_launch_corr(one, 1, 0, 64, 64, 8, 0.1, 0.2, 1, None) == -2
     assert lib.fm_debug_launch_corr(one, 1, 64, 64, 64, 8, 0.1, 0.2, 7, None) == -3
-    assert lib.fm_debug_launch_sum_sparse(one, one, one, 1, 64, -1, 64, 8, 0.1, 0.2, None) == -2
-    assert lib.fm_debug_launch_sum_sparse(one, None, one, 1, 64, 64, 64, 8, 0.1, 0.2, None) == -1
+    assert lib.fm_debug_launch_screen(one, one, one, 1, 64, -1, 64, 8, 0.1, 0.2, None) == -2
+    assert lib.fm_debug_launch_screen(one, None, one, 1, 64, 64, 64, 8, 0.1, 0.2, None) == -1
 
 
 def test_layout_query_is_consistent():

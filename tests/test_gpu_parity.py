@@ -7,6 +7,8 @@ mconf within 1e-5 (abs) of the reference, coarse keypoints bit-exact, fine keypo
 the entry's conf lies within GUARD of thr, where float32 re-orderings of the reference's own
 sums already flip the decision (hard part 3).
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -517,41 +519,136 @@ def test_flat_rows_take_the_exact_screening_pass():
 
 
 def test_flat_rows_with_conf_matrix_run_the_coarse_stage_once(monkeypatch):
-    """Training-shaped call (conf_matrix requested) on flat rows: the exact screening is on from the first call, so
-    the coarse stage is enqueued once - not once to overflow and once more to recover."""
+    """Training-shaped call (conf_matrix requested) on flat rows: the exact screening is on from the first attempt, so
+    the coarse stage is enqueued once - not once to overflow and once more to recover.  And the hint word of
+    fm_coarse_match_auto, kept per shape by ops.MODE_MEMORY: learnt, used, re-probed, forgotten."""
     f0, f1 = _repetitive_texture()
     ref = orc.coarse_match(f0, f1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
-    calls = []
-    real = ops.coarse_match_async
-    monkeypatch.setattr(ops, "coarse_match_async", lambda *a, **k: (calls.append(k.get("exact_screening")), real(*a, **k))[1])
     t0, t1 = torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV)
     out = ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0, conf_matrix=True)
-    assert calls == [True]
+    assert out['_coarse_buffers'].attempts == 1
     _assert_coarse(out, ref)
-    # and a shape that overflowed once starts with the exact screening (and the dense sum kernel) the next time
-    calls.clear()
+    # a shape that overflowed once starts with the exact screening (and the dense sum kernel) the next time
     ops.MODE_MEMORY.clear()
-    ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
-    n_first = len(calls)
-    ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
-    # (first call: common path -> dense -> [16 slots + exact step, which repetitive texture overflows too] -> exact screening)
-    assert 2 <= n_first <= 4 and calls[0] is False and calls[n_first - 1] is True and calls[n_first:] == [True]
+    first = ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
+    second = ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)
+    # (first call: common path -> + dense part -> [16 slots + exact step, which repetitive texture overflows too] -> exact screening)
+    assert 2 <= first['_coarse_buffers'].attempts <= 4 and second['_coarse_buffers'].attempts == 1, first['_coarse_buffers'].attempts
+    _assert_coarse(first, ref)
+    _assert_coarse(second, ref)
     # the memory is visible, bounded and decays: the `reprobe`-th call of the shape starts on the common path again,
-    # fails there for this data and is repeated with the flags; peaked data of the same shape makes it forget them
+    # fails there for this data and ends with the flags again; peaked data of the same shape makes it forget them
     snap = ops.MODE_MEMORY.snapshot()
     assert len(snap) == 1 and list(snap.values())[0]['exact']
     monkeypatch.setattr(ops.MODE_MEMORY, "reprobe", 2)
-    calls.clear()
-    ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)            # 2nd remembered call: a probe of the common path
-    assert calls[0] is False and calls[-1] is True
+    third = ops.coarse_match(t0, t1, (30, 40), (30, 40), 8.0)    # 2nd remembered call: a probe of the common path
+    assert third['_coarse_buffers'].attempts >= 2 and list(ops.MODE_MEMORY.snapshot().values())[0]['exact']
     p0, p1 = synth.coarse_descriptors(77, f0.shape[0], 1200, f0.shape[2], "peaky")
     q0, q1 = torch.as_tensor(p0, device=DEV), torch.as_tensor(p1, device=DEV)
-    calls.clear()
-    ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)            # remembered flags
-    ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)            # probe: succeeds on this data, the shape is forgotten
-    ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)
-    assert calls == [True, False, False] and not ops.MODE_MEMORY.snapshot()
+    pref = orc.coarse_match(p0, p1, (240, 320), (30, 40), (30, 40), 0.2, 2, 0.1)
+    a = ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)        # remembered flags: correct, only slower
+    assert a['_coarse_buffers'].hint & _lib.FM_MODE_EXACT_SCREENING
+    b = ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)        # probe: succeeds on this data, the shape is forgotten
+    c = ops.coarse_match(q0, q1, (30, 40), (30, 40), 8.0)
+    assert b['_coarse_buffers'].hint == 0 and c['_coarse_buffers'].hint == 0 and not ops.MODE_MEMORY.snapshot()
+    for o in (a, b, c):
+        _assert_coarse(o, pref)
     ops.MODE_MEMORY.clear()
+
+
+def _auto_call(f0, f1, hw0, hw1, scale_px, thr=0.2, border=2, temp=0.1, hint=0, mode=0, cap=None, max_slots=0,
+               scale0=None, scale1=None):
+    """fm_coarse_match_auto through ctypes, nothing else: returns (status, M, info, hint, outputs dict)"""
+    lib = _lib.load()
+    t0, t1 = torch.as_tensor(f0, device=DEV).contiguous(), torch.as_tensor(f1, device=DEV).contiguous()
+    n, l, c = t0.shape
+    s = t1.shape[1]
+    nb = ctypes.c_size_t(0)
+    assert lib.fm_coarse_workspace_bytes_auto(n, l, s, c, max_slots, ctypes.byref(nb)) == 0
+    ws = torch.empty(nb.value + 256, dtype=torch.uint8, device=DEV)
+    base = ws.data_ptr() + (-ws.data_ptr()) % 256
+    cap = n * min(l, s) if cap is None else cap
+    o = dict(b_ids=torch.empty(cap, dtype=torch.int64, device=DEV), i_ids=torch.empty(cap, dtype=torch.int64, device=DEV),
+             j_ids=torch.empty(cap, dtype=torch.int64, device=DEV), mkpts0_c=torch.empty(cap, 2, device=DEV),
+             mkpts1_c=torch.empty(cap, 2, device=DEV), mconf=torch.empty(cap, device=DEV))
+    cnt = torch.zeros(2, dtype=torch.int32, device=DEV)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    s0 = None if scale0 is None else torch.as_tensor(scale0, device=DEV)
+    s1 = None if scale1 is None else torch.as_tensor(scale1, device=DEV)
+    h, m, info = ctypes.c_int32(hint), ctypes.c_int32(0), ctypes.c_int32(0)
+    st = lib.fm_coarse_match_auto(p(t0), p(t1), _lib.FM_F32, n, l, s, c, hw0[0], hw0[1], hw1[0], hw1[1], temp, thr, border,
+                                  scale_px, p(s0), p(s1), ctypes.c_void_p(base), nb.value, max_slots, mode,
+                                  p(o['b_ids']), p(o['i_ids']), p(o['j_ids']), p(o['mkpts0_c']), p(o['mkpts1_c']),
+                                  p(o['mconf']), cap, p(cnt), None, ctypes.byref(h), ctypes.byref(m), ctypes.byref(info),
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    mm = max(0, min(int(m.value), cap))
+    return st, int(m.value), int(info.value), int(h.value), {k: v[:mm] for k, v in o.items()}
+
+
+@pytest.mark.parametrize("name,dist", [("cfg2_peaky", "peaky"), ("cfg2_mixed", "mixed"), ("cfg2_borderline", "borderline"),
+                                       ("cfg1_borderline", "borderline")])
+def test_one_c_call_serves_any_data(name, dist):
+    """fm_coarse_match_auto - the ONE C entry point a drop-in caller needs (INTEGRATION.md option B) - driven through
+    ctypes with NO retry on the Python side, on peaked, mixed (textureless cells + rows without a partner) and flat
+    data, against the REFERENCE's fixtures; then once more from the hint word the first call left: one attempt."""
+    g = load_golden(name)
+    inp = case_inputs(g['meta'], dist, with_fine=False)
+    hw = inp['hw_c']
+    st, m, info, hint, out = _auto_call(inp['f0'], inp['f1'], hw, hw, inp['hw_i'][0] / hw[0])
+    assert st == 0 and m == out['i_ids'].shape[0]
+    assert _assert_coarse(out, g) <= 4
+    attempts = (hint >> 24) & 0xff
+    # (flat similarity alone is answered INSIDE the first attempt - the dense part is added to the common path's work;
+    # 'mixed' overflows the default candidate slots on top of that and takes a second, wider attempt)
+    assert attempts == 1 if dist != "mixed" else 2 <= attempts <= 4, attempts
+    assert (hint & 0xffff) == 0 if dist == "peaky" else (hint & _lib.FM_MODE_DENSE)
+    st2, m2, info2, hint2, out2 = _auto_call(inp['f0'], inp['f1'], hw, hw, inp['hw_i'][0] / hw[0], hint=hint & 0xffff)
+    assert st2 == 0 and (hint2 >> 24) & 0xff == 1 and (hint2 & 0xff) == (hint & 0xff) | (_lib.FM_MODE_FLAT if dist != "peaky" else 0)
+    assert _assert_coarse(out2, g) <= 4
+    if dist != "peaky":          # ... and the third call runs with the flat hint (no screening sweep): same matches
+        st3, m3, info3, hint3, out3 = _auto_call(inp['f0'], inp['f1'], hw, hw, inp['hw_i'][0] / hw[0], hint=hint2 & 0xffff)
+        assert st3 == 0 and (hint3 >> 24) & 0xff == 1 and (hint3 & _lib.FM_MODE_FLAT) and (info3 & _lib.FM_DEV_ALL_DENSE)
+        assert _assert_coarse(out3, g) <= 6
+
+
+def test_one_c_call_on_the_known_answer_cases():
+    """fm_coarse_match_auto on the reference's known-answer cases (exact two- and three-way ties, the thr straddle,
+    per-sample scales, a batch with different M, M == 0), on an outlier descriptor outside the int8 step's sample
+    (FM_E_STEP answered inside) and on output buffers that are too small (FM_E_CAPACITY: the needed capacity comes back,
+    the second call with that capacity is served)."""
+    for name, k in load_kats().items():
+        hw = [int(v) for v in k['hw']]
+        thr, brm, temp = float(k['cfg'][0]), int(k['cfg'][1]), float(k['cfg'][2])
+        st, m, info, hint, out = _auto_call(k['f0'], k['f1'], hw[4:6], hw[6:8], hw[0] / hw[4], thr, brm, temp,
+                                            scale0=k.get('scale0'), scale1=k.get('scale1'))
+        if st == _lib.FM_E_CAPACITY:          # exact ties: more matches than N * min(L, S)
+            st, m, info, hint, out = _auto_call(k['f0'], k['f1'], hw[4:6], hw[6:8], hw[0] / hw[4], thr, brm, temp, cap=m,
+                                                scale0=k.get('scale0'), scale1=k.get('scale1'))
+        assert st == 0, (name, st)
+        assert _assert_coarse(out, k, thr) == 0, name
+        if name == "empty":
+            assert m == 0
+    # an outlier row outside the sampled rows of the int8 step
+    l, c, hw = 1200, 128, (30, 40)
+    f0, f1 = synth.coarse_descriptors(91, 1, l, c, "peaky")
+    sampled = sorted({(t * l) // 32 for t in range(32)})
+    free = [r for r in range(l) if r not in sampled]
+    f0[0, free[5]] *= 4.0
+    ref = orc.coarse_match(f0, f1, (240, 320), hw, hw, 0.2, 2, 0.1)
+    st, m, info, hint, out = _auto_call(f0, f1, hw, hw, 8.0)
+    assert st == 0 and (hint & _lib.FM_MODE_EXACT_STEP) and m == ref['i_ids'].shape[0] > 700
+    _assert_coarse(out, ref)
+    # too small output buffers
+    st, m, info, hint, out = _auto_call(f0, f1, hw, hw, 8.0, cap=100)
+    assert st == _lib.FM_E_CAPACITY and m == ref['i_ids'].shape[0]
+    st, m2, info, hint, out = _auto_call(f0, f1, hw, hw, 8.0, cap=m, hint=hint & 0xffff)
+    assert st == 0 and m2 == m and (hint >> 24) & 0xff == 1
+    _assert_coarse(out, ref)
+    # bad input is the caller's: reported, not retried
+    f0[0, 3, 7] = np.nan
+    st, m, info, hint, out = _auto_call(f0, f1, hw, hw, 8.0)
+    assert st == _lib.FM_E_RANGE
 
 
 def test_coarse_without_cell_maps_gives_the_same_matches():

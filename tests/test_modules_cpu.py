@@ -87,31 +87,26 @@ def test_context_layers_with_padding_masks_match_the_reference():
     assert (y0 - z0).abs().max() > 1e-2          # the masks matter
 
 
-def test_mode_memory_is_bounded_decays_and_forgets():
-    """ops.ModeMemory: which optional coarse passes a shape needed before - LRU-bounded, re-probing every k-th call,
-    forgettable, behind a lock (no GPU involved)."""
-    from featurematching_amd.ops import ModeMemory
-    m = ModeMemory(capacity=2, reprobe=3)
-    assert m.start('a') == (False, False, False)
-    m.learn('a', dense=True); m.learn('b', exact=True); m.learn('c', dense=True)
+def test_hint_memory_is_bounded_decays_and_forgets():
+    """ops.HintMemory: the hint word of fm_coarse_match_auto per problem kind - LRU-bounded, passing no hint on every
+    k-th call (a probe of the common path), forgetting a key whose probe succeeded, behind a lock (no GPU involved)."""
+    from featurematching_amd import _lib
+    from featurematching_amd.ops import HintMemory
+    m = HintMemory(capacity=2, reprobe=3)
+    assert m.start('a') == (0, False)
+    dense, exact, flat, step = _lib.FM_MODE_DENSE, _lib.FM_MODE_EXACT_SCREENING, _lib.FM_MODE_FLAT, _lib.FM_MODE_EXACT_STEP
+    m.finish('a', dense); m.finish('b', exact | dense | (3 << 24)); m.finish('c', dense)
     assert set(m.snapshot()) == {'b', 'c'}                       # 'a' was the least recently used
-    assert m.start('b') == (False, True, False) and m.start('b') == (False, True, False)
-    assert m.start('b') == (False, False, True)                 # third remembered call: probe the common path
-    m.forget('b')
-    assert m.start('b') == (False, False, False)
-    # the flat-similarity hint (FM_MODE_FLAT): learnt with an explicit True / False, never on the probing call
-    assert not m.flat('c')
-    m.learn('c', dense=True, flat=True)
-    assert m.flat('c') and not m.flat('c', probing=True) and m.snapshot()['c']['flat']
-    m.learn('c', dense=True)                                     # (flat=None leaves it alone)
-    assert m.flat('c')
-    m.learn('c', dense=True, flat=False)
-    assert not m.flat('c')
-    # ... and the wider candidate lists (16 slots + exact step) a dense shape may need instead of the exact re-screening
-    assert not m.wide('c')
-    m.learn('c', dense=True, wide=True)
-    assert m.wide('c') and not m.wide('c', probing=True) and m.snapshot()['c']['wide']
-    m.learn('c', wide=False)
-    assert not m.wide('c')
+    assert m.snapshot()['b']['hint'] == exact | dense            # (the attempts byte is per call, not remembered)
+    assert m.start('b') == (exact | dense, False) and m.start('b') == (exact | dense, False)
+    assert m.start('b') == (0, True)                             # third remembered call: probe the common path
+    m.finish('b', 0)                                             # ... which served it: forgotten
+    assert m.start('b') == (0, False) and 'b' not in m.snapshot()
+    m.finish('c', dense | flat | step | (16 << 8))
+    d = m.snapshot()['c']
+    assert d['dense'] and d['flat'] and d['step'] and d['wide'] and d['slots'] == 16 and not d['exact']
+    m.finish('c', dense)
+    d = m.snapshot()['c']
+    assert d['dense'] and not d['flat'] and not d['wide']
     m.clear()
     assert not m.snapshot()

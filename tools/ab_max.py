@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--workloads", nargs="+", default=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--mode", type=int, default=0, help="fm_debug_launch_corr mode (0 = max pass)")
     ap.add_argument("--kernel", default="corr", choices=["corr", "sparse", "prep"],
-                    help="corr: fm_debug_launch_corr(--mode); sparse: counter reset + fm_debug_launch_sum_sparse")
+                    help="corr: fm_debug_launch_corr(--mode); sparse: counter reset + fm_debug_launch_screen")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--env", default="", help="NAME=v1,v2,..: every library is timed once per value (FM_TUNE_ENV builds read "
                                               "their tuning variables at every call)")
@@ -34,14 +34,14 @@ def main():
     lib = _lib.load()
     slots = lib.fm_default_cand_slots(0.2)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    res, args = _lib.SIGNATURES["fm_debug_launch_corr"]
+    res, args = _lib.ALL_SIGNATURES["fm_debug_launch_corr"]
     vs, names, envs = [], [], []
     ename, evals = (a.env.split("=")[0], a.env.split("=")[1].split(",")) if a.env else (None, [None])
     for path in a.libs:
         v = C.CDLL(os.path.abspath(path))
         v.fm_debug_launch_corr.restype, v.fm_debug_launch_corr.argtypes = res, args
-        for fn in ("fm_debug_launch_sum_sparse", "fm_debug_reset_counters", "fm_debug_launch_prep"):
-            getattr(v, fn).restype, getattr(v, fn).argtypes = _lib.SIGNATURES[fn]
+        for fn in ("fm_debug_launch_screen", "fm_debug_reset_counters", "fm_debug_launch_prep"):
+            getattr(v, fn).restype, getattr(v, fn).argtypes = _lib.ALL_SIGNATURES[fn]
         for ev in evals:
             vs.append(v); envs.append(ev)
             names.append(os.path.basename(path) + (f" {ename}={ev}" if ev else ""))
@@ -70,7 +70,7 @@ def main():
                         v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, a.mode, st)
                     else:
                         v.fm_debug_reset_counters(ptr, p.n, p.l, p.l, p.c, slots, st)
-                        v.fm_debug_launch_sum_sparse(ptr, f0p, f1p, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, st)
+                        v.fm_debug_launch_screen(ptr, f0p, f1p, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, st)
                 e1.record()
                 torch.cuda.synchronize()
                 if rnd:

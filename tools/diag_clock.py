@@ -33,7 +33,7 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     v = C.CDLL(os.path.abspath(a.lib))
     for name in ("fm_debug_launch_corr",):
-        res, args = _lib.SIGNATURES[name]
+        res, args = _lib.ALL_SIGNATURES[name]
         getattr(v, name).restype, getattr(v, name).argtypes = res, args
     buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)     # full-size workspace
     torch.cuda.synchronize()
@@ -46,7 +46,7 @@ def main():
         for rep in range(20):          # warm: the clock ramps with load
             lib.fm_debug_reset_counters(ptr, p.n, p.l, p.l, p.c, slots, st)
             # (the screening kernel flags the samples the dense kernel redoes)
-            lib.fm_debug_launch_sum_sparse(ptr, C.c_void_p(p.f0.data_ptr()), C.c_void_p(p.f1.data_ptr()), p.n, p.l, p.l, p.c,
+            lib.fm_debug_launch_screen(ptr, C.c_void_p(p.f0.data_ptr()), C.c_void_p(p.f1.data_ptr()), p.n, p.l, p.l, p.c,
                                            slots, 0.1, 0.2, st)
             v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, mode, st)
         torch.cuda.synchronize()

@@ -32,7 +32,7 @@ def main():
     packed = ops.pack_coarse_transformer(wts, a.layers, dev)
     v = C.CDLL(os.path.abspath(a.lib))
     for name in ("fm_coarse_tf_workspace_bytes", "fm_coarse_transformer"):
-        getattr(v, name).restype, getattr(v, name).argtypes = _lib.SIGNATURES[name]
+        getattr(v, name).restype, getattr(v, name).argtypes = _lib.ALL_SIGNATURES[name]
     g = torch.Generator(device=dev).manual_seed(1)
     x0 = torch.randn(1, a.l, 256, device=dev, generator=g)
     x1 = torch.randn(1, a.l, 256, device=dev, generator=g)

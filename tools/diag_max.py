@@ -33,7 +33,7 @@ def main():
     slots = lib.fm_default_cand_slots(0.2)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     v = C.CDLL(os.path.abspath(a.lib))
-    res, args = _lib.SIGNATURES["fm_debug_launch_corr"]
+    res, args = _lib.ALL_SIGNATURES["fm_debug_launch_corr"]
     v.fm_debug_launch_corr.restype, v.fm_debug_launch_corr.argtypes = res, args
     buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)     # full-size workspace
     torch.cuda.synchronize()

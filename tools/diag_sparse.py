@@ -32,8 +32,8 @@ def main():
     slots = lib.fm_default_cand_slots(0.2)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     v = C.CDLL(os.path.abspath(a.lib))
-    for name in ("fm_debug_launch_sum_sparse", "fm_debug_reset_counters"):
-        res, args = _lib.SIGNATURES[name]
+    for name in ("fm_debug_launch_screen", "fm_debug_reset_counters"):
+        res, args = _lib.ALL_SIGNATURES[name]
         getattr(v, name).restype, getattr(v, name).argtypes = res, args
     buf = ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, dense=True)     # full-size workspace
     torch.cuda.synchronize()
@@ -43,7 +43,7 @@ def main():
     lay = layout(p.n, p.l, p.l, p.c, slots)
     for rep in range(20):
         v.fm_debug_reset_counters(ptr, p.n, p.l, p.l, p.c, slots, st)
-        v.fm_debug_launch_sum_sparse(ptr, C.c_void_p(p.f0.data_ptr()), C.c_void_p(p.f1.data_ptr()), p.n, p.l, p.l, p.c,
+        v.fm_debug_launch_screen(ptr, C.c_void_p(p.f0.data_ptr()), C.c_void_p(p.f1.data_ptr()), p.n, p.l, p.l, p.c,
                                      slots, 0.1, 0.2, st)
     torch.cuda.synchronize()
     nwg = p.n * lay["panels"] * lay["splits_s"]

@@ -43,7 +43,7 @@ def kernels(k):
         "k_prep_split": lambda: lib.fm_debug_launch_prep(ws_ptr(bufs[k]), f0, f1, p.n, p.l, p.l, p.c, slots, sp()),
         "k_max_i8": lambda: lib.fm_debug_launch_corr(ws_ptr(bufs[k]), p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 0, sp()),
         "k_sum_sparse": lambda: (lib.fm_debug_reset_counters(ws_ptr(bufs[k]), p.n, p.l, p.l, p.c, slots, sp()),
-                                 lib.fm_debug_launch_sum_sparse(ws_ptr(bufs[k]), f0, f1, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, sp())),
+                                 lib.fm_debug_launch_screen(ws_ptr(bufs[k]), f0, f1, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, sp())),
         "coarse stage (4 kernels)": lambda: ops.coarse_match_async(p.f0, p.f1, p.hw_c, p.hw_c, 8.0, cap=p.cap, cell_maps=False),
         "transpose + k_fine_maps": lambda: p.fine_maps(buf),
     }

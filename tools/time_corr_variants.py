@@ -53,7 +53,7 @@ def main():
         if path != "<shipped>":
             v = C.CDLL(os.path.abspath(path))
             for name in ("fm_debug_launch_corr", "fm_debug_reset_counters"):
-                res, args = _lib.SIGNATURES[name]
+                res, args = _lib.ALL_SIGNATURES[name]
                 getattr(v, name).restype, getattr(v, name).argtypes = res, args
         # sum pass first (needs the real block map), max pass last (an ablated one may leave the map stale)
         s_med, s_min = timed(lambda: v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 1, st), a.iters,

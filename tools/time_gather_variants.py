@@ -49,7 +49,7 @@ def main():
         if path != "<shipped>":
             v = C.CDLL(os.path.abspath(path))
             for name in ("fm_gather_windows", "fm_gather_windows_cells", "fm_fine_match"):
-                res, args = _lib.SIGNATURES[name]
+                res, args = _lib.ALL_SIGNATURES[name]
                 getattr(v, name).restype, getattr(v, name).argtypes = res, args
         P = lambda t: C.c_void_p(t.data_ptr())
         out = []
