@@ -219,6 +219,10 @@ NET_TAIL = dict(seed=31, n=2, h=128, w=128, c=256, cf=64, nhead=8, layers_c=['se
                 layers_f=['self', 'cross'], gain=1.0, sigma=1.6)
 
 
+# the same chain at the size bench.py times forward_features at: ONE 640x480 pair (L = S = 4800, 240x320 fine maps)
+NET_TAIL_CFG2 = dict(NET_TAIL, seed=37, n=1, h=480, w=640)
+
+
 def net_tail_inputs(meta=NET_TAIL):
     """Seeded inputs of the net_tail fixture (feature maps as a backbone would hand them over + all weights), from
     the portable hash RNG: shared with the tests, which regenerate them instead of storing them."""
@@ -247,12 +251,12 @@ def net_tail_inputs(meta=NET_TAIL):
                 w_prep=w_prep, mix=mix, hw_i=(meta['h'], meta['w']))
 
 
-def net_tail_case(name="net_tail_small"):
+def net_tail_case(name="net_tail_small", meta=None):
     """Everything network/net.py:66-83 does after the backbone, run with the REFERENCE's own modules (coarse /
     fine LocalFeatureTransformer, CoarseMatching, FinePreprocess with its context merge, FineMatching) on seeded
     feature maps and weights: the row-a8 fixture."""
     from network.module.transformer import LocalFeatureTransformer
-    meta = NET_TAIL
+    meta = meta or NET_TAIL
     inp = net_tail_inputs(meta)
     sd = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}
     coarse = LocalFeatureTransformer(dict(d_model=meta['c'], nhead=meta['nhead'], layer_names=meta['layers_c'], attention='linear')).eval()
@@ -440,6 +444,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "net_tail":
         net_tail_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r5":     # the fixture added in round 5 only
+        net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epi":
         epipolar_case()
         sys.exit(0)
@@ -469,3 +476,5 @@ if __name__ == "__main__":
     masked_transformer_case()
     full_case("l9600_peaky", "l9600", "peaky")
     full_case("l9600_borderline", "l9600", "borderline", with_fine=False)
+    # round 5: the a8 chain (net.py:66-83) at the size the bench times it at
+    net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)

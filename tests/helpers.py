@@ -6,6 +6,7 @@ import numpy as np
 from featurematching_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FLIPS = []      # (test id, guard-band flips, reference matches, max |conf - reference|) of every match-set comparison
 
 
 def load_golden(name):
@@ -47,6 +48,9 @@ def compare_match_sets(got, ref, conf_tol=1e-5):
 
 NET_TAIL = dict(seed=31, n=2, h=128, w=128, c=256, cf=64, nhead=8, layers_c=['self', 'cross'] * 4,
                 layers_f=['self', 'cross'], gain=1.0, sigma=1.6)
+
+
+NET_TAIL_CFG2 = dict(NET_TAIL, seed=37, n=1, h=480, w=640)     # the same chain at the bench's size: one 640x480 pair
 
 
 def net_tail_inputs(meta=NET_TAIL):

@@ -8,6 +8,7 @@ the entry's conf lies within GUARD of thr, where float32 re-orderings of the ref
 sums already flip the decision (hard part 3).
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -16,7 +17,7 @@ import torch
 from featurematching_amd import modules, ops, synth
 from featurematching_amd import _lib
 from oracle import matcher_ref as orc
-from helpers import load_golden, load_kats, case_inputs, compare_match_sets, net_tail_inputs, NET_TAIL, epipolar_inputs
+from helpers import load_golden, load_kats, case_inputs, compare_match_sets, net_tail_inputs, NET_TAIL, NET_TAIL_CFG2, epipolar_inputs, FLIPS
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +42,9 @@ def _assert_coarse(got, ref, thr=0.2, conf_tol=CONF_TOL):
         assert np.array_equal(got['b_ids'], ref['b_ids'])                      # same (b,i,j) order
         assert np.array_equal(got['mkpts0_c'], ref['mkpts0_c']) and np.array_equal(got['mkpts1_c'], ref['mkpts1_c'])
     assert got['i_ids'].dtype == np.int64 and got['mkpts0_c'].dtype == np.float32
+    # every comparison reports how many entries flipped inside the guard band (the terminal summary lists them)
+    FLIPS.append((os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0].split('::')[-1], len(only_g) + len(only_r),
+                  len(ref['i_ids']), err))
     return len(only_g) + len(only_r)
 
 
@@ -927,16 +931,18 @@ def test_properties_at_cfg3_size():
 
 
 # ------------------------------------------------------------------ row a8: net.forward after the backbone
-def test_matcher_tail_against_reference_fixture():
+@pytest.mark.parametrize("name,meta", [("net_tail_small", NET_TAIL), ("net_tail_cfg2", NET_TAIL_CFG2)])
+def test_matcher_tail_against_reference_fixture(name, meta):
     """Matcher.forward_features (network/net.py:66-83: HIP coarse context layers (fm_coarse_transformer, 8 layers,
     d_model 256) -> HIP coarse matching -> HIP window crop fused with the context merge -> HIP fine context layers
-    (fm_fine_transformer) -> HIP fine matching) against the fixture the REFERENCE's own modules produced for the
-    same seeded feature maps and weights.  The context layers are float32-equivalent products in another summation
-    order than the fixture's, which moves the descriptors by ~1e-6 relative: the conf tolerance of this chain
-    test is 1e-4 (guard band likewise), fine keypoints 2e-3 px."""
+    (fm_fine_transformer) -> HIP fine matching) against the fixtures the REFERENCE's own five modules produced for the
+    same seeded feature maps and weights: two 128x128 pairs, and ONE 640x480 PAIR - the size bench.py times
+    forward_features at (L = S = 4800, 1624 matches with conf spread over (0.2, 1]).  The context layers are
+    float32-equivalent products in another summation order than the fixture's, which moves the descriptors by ~1e-6
+    relative: the conf tolerance of this chain test is 1e-4 (guard band likewise), fine keypoints 2e-3 px."""
     from featurematching_amd.matcher import Matcher
-    g = load_golden("net_tail_small")
-    inp = net_tail_inputs()
+    g = load_golden(name)
+    inp = net_tail_inputs(meta)
     m = Matcher().to(DEV).eval()
     t = lambda d: {k: torch.as_tensor(v) for k, v in d.items()}
     m.coarse.load_state_dict(t(inp['w_coarse']))
@@ -947,11 +953,12 @@ def test_matcher_tail_against_reference_fixture():
         m.fine_matching.mix_feat_0.weight.copy_(torch.as_tensor(w0).view(1, -1)); m.fine_matching.mix_feat_0.bias.fill_(float(b0))
         m.fine_matching.mix_feat_1.weight.copy_(torch.as_tensor(w1).view(1, -1)); m.fine_matching.mix_feat_1.bias.fill_(float(b1))
     dev = lambda x: torch.as_tensor(x, device=DEV)
-    data = {'bs': NET_TAIL['n'], 'hw0_i': inp['hw_i'], 'hw1_i': inp['hw_i']}
+    data = {'bs': meta['n'], 'hw0_i': inp['hw_i'], 'hw1_i': inp['hw_i']}
     m.forward_features(dev(inp['feat_c0']), dev(inp['feat_c1']), dev(inp['feat_f0']), dev(inp['feat_f1']), data)
     np.testing.assert_allclose(data['feat_c0'].double().sum((1, 2)).cpu().numpy(), g['c0_sum'], rtol=1e-5)
     got = _np({k: data[k] for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts0_c', 'mkpts1_c')})
     only_g, only_r, err = compare_match_sets(got, g)
+    FLIPS.append((f"test_matcher_tail_against_reference_fixture[{name}]", len(only_g) + len(only_r), len(g['i_ids']), err))
     assert all(abs(v - 0.2) < 1e-4 for _, v in only_g + only_r), (only_g, only_r)
     assert err <= 1e-4, err
     gk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(got['b_ids'], got['i_ids'], got['j_ids']))}

@@ -5,7 +5,7 @@ import torch
 
 from featurematching_amd import synth
 from oracle import matcher_ref as orc
-from helpers import load_golden, load_kats, case_inputs, net_tail_inputs, NET_TAIL, epipolar_inputs
+from helpers import load_golden, load_kats, case_inputs, net_tail_inputs, NET_TAIL, NET_TAIL_CFG2, epipolar_inputs
 
 
 def _check_coarse(out, g):
@@ -169,14 +169,17 @@ def test_context_merge_matches_reference(name, dist):
         np.testing.assert_allclose(s, g[key + '_sum'], rtol=0, atol=5e-2)       # sums of ~1e5 weighted terms
 
 
-def test_net_tail_matches_reference():
+@pytest.mark.parametrize("name,meta", [("net_tail_small", NET_TAIL), ("net_tail_cfg2", NET_TAIL_CFG2)])
+def test_net_tail_matches_reference(name, meta):
     """Row a8: everything network/net.py:66-83 does after the backbone (coarse context layers -> coarse matching ->
     window crop + context merge -> fine context layers -> fine matching), restated in oracle.net_tail, against the
-    fixture the reference's own modules produced for the same seeded feature maps and weights."""
-    g = load_golden("net_tail_small")
-    inp = net_tail_inputs()
+    fixtures the reference's own modules produced for the same seeded feature maps and weights (two 128x128 pairs; one
+    640x480 pair, the size the bench times the chain at)."""
+    g = load_golden(name)
+    inp = net_tail_inputs(meta)
+    torch.set_num_threads(8)
     out = orc.net_tail(inp['feat_c0'], inp['feat_c1'], inp['feat_f0'], inp['feat_f1'], inp['hw_i'], inp['w_coarse'],
-                       inp['w_fine'], inp['w_prep'], inp['mix'], NET_TAIL['layers_c'], NET_TAIL['layers_f'])
+                       inp['w_fine'], inp['w_prep'], inp['mix'], meta['layers_c'], meta['layers_f'])
     _check_coarse(out, g)
     assert g['i_ids'].shape[0] > 80 and g['mconf'].min() < 0.5 < g['mconf'].max()
     np.testing.assert_allclose(out['feat_c0'].double().sum((1, 2)).numpy(), g['c0_sum'], rtol=1e-6)
