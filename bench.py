@@ -897,6 +897,14 @@ def main():
             ver = verify(pairs[0])
             tk = time_kernels(pairs[0])
 
+    rank_devices = None
+    if world > 1:
+        # every rank's device identity, gathered on rank 0: a SCALE record then shows that N ranks ran on N devices
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"rank {rank}: cuda:{dev.index} {props.name} uuid={getattr(props, 'uuid', 'n/a')} pci={getattr(props, 'pci_bus_id', 'n/a')}"
+        gathered_ids = [None] * world
+        dist.all_gather_object(gathered_ids, ident)
+        rank_devices = gathered_ids
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -1007,6 +1015,9 @@ def main():
     if world > 1:
         out["gather_ms"] = round(gather_ms, 4)
         out["gathered_records"] = gathered
+        # what the collective backend saw: the world size torch.distributed reports and one device identity per rank
+        out["distributed"] = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+                              "world_size": dist.get_world_size(), "device_uuids": rank_devices}
     if world == 1 and not a.quick and a.stages == "all":
         out["extra"] = extras(a, wl, dev, streams, flops)
         # the headline is measured on 'peaky' descriptors (every conf is 1.0, one significant entry per row);

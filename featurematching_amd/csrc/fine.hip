@@ -288,8 +288,19 @@ __global__ __launch_bounds__(256) void k_gather_cellorder64(CellArgs a) {
   }
 }
 
-// generic fallback (any Cf / W): one workgroup per window, transposed through LDS
-__global__ __launch_bounds__(256) void k_gather_nchw(const float* __restrict__ feat, int Cf, int Hf, int Wf, int W,
+// element of a float32 / float16 / bfloat16 map as float32 (exact)
+template <int DT> struct MapElem { using type = float; };
+template <> struct MapElem<FM_F16> { using type = unsigned short; };
+template <> struct MapElem<FM_BF16> { using type = unsigned short; };
+template <int DT>
+__device__ __forceinline__ float map_value(const typename MapElem<DT>::type* p, long i) {
+  if constexpr (DT == FM_F32) return p[i];
+  else return half_bits_to_float(p[i], DT);
+}
+
+// generic fallback (any Cf / W, any element type): one workgroup per window, transposed through LDS
+template <int DT>
+__global__ __launch_bounds__(256) void k_gather_nchw(const typename MapElem<DT>::type* __restrict__ feat, int Cf, int Hf, int Wf, int W,
                                                      int stride, int pad, int w_c, const int64_t* __restrict__ b_ids,
                                                      const int64_t* __restrict__ ids, const int32_t* __restrict__ d_count,
                                                      int m_max, float* __restrict__ out) {
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(256) void k_gather_nchw(const float* __restrict__ f
   const int id = (int)ids[m];
   const int oy = (id / w_c) * stride - pad;
   const int ox = (id % w_c) * stride - pad;
-  const float* src = feat + (long)b * Cf * Hf * Wf;
+  const typename MapElem<DT>::type* src = feat + (long)b * Cf * Hf * Wf;
   const int total = Cf * WW;
   for (int idx = threadIdx.x; idx < total; idx += 256) {
     const int c = idx / WW;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256) void k_gather_nchw(const float* __restrict__ f
     const int wy = rem / W, wx = rem - wy * W;
     const int y = oy + wy, x = ox + wx;
     float v = 0.f;
-    if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)c * Hf + y) * Wf + x];
+    if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = map_value<DT>(src, ((long)c * Hf + y) * Wf + x);
     tile[rem * (Cf + 1) + c] = v;
   }
   __syncthreads();
@@ -322,8 +333,9 @@ __global__ __launch_bounds__(256) void k_gather_nchw(const float* __restrict__ f
   }
 }
 
-// NHWC storage: every window row is W*Cf contiguous floats - a straight float4 copy.
-__global__ __launch_bounds__(256) void k_gather_nhwc(const float* __restrict__ feat, int Cf, int Hf, int Wf, int W,
+// NHWC storage: every window row is W*Cf contiguous elements - a straight copy, four channels per thread and step.
+template <int DT>
+__global__ __launch_bounds__(256) void k_gather_nhwc(const typename MapElem<DT>::type* __restrict__ feat, int Cf, int Hf, int Wf, int W,
                                                      int stride, int pad, int w_c, const int64_t* __restrict__ b_ids,
                                                      const int64_t* __restrict__ ids, const int32_t* __restrict__ d_count,
                                                      int m_max, float* __restrict__ out) {
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(256) void k_gather_nhwc(const float* __restrict__ f
   const int oy = (id / w_c) * stride - pad;
   const int ox = (id % w_c) * stride - pad;
   const int c4 = Cf / 4;
-  const float4* src = reinterpret_cast<const float4*>(feat + (long)b * Hf * Wf * Cf);
+  const typename MapElem<DT>::type* src = feat + (long)b * Hf * Wf * Cf;
   float4* dst = reinterpret_cast<float4*>(out + (long)m * WW * Cf);
   for (int idx = threadIdx.x; idx < WW * c4; idx += 256) {
     const int rpos = idx / c4;
@@ -344,7 +356,11 @@ __global__ __launch_bounds__(256) void k_gather_nhwc(const float* __restrict__ f
     const int wy = rpos / W, wx = rpos - wy * W;
     const int y = oy + wy, x = ox + wx;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y >= 0 && y < Hf && x >= 0 && x < Wf) v = src[((long)y * Wf + x) * c4 + c];
+    if (y >= 0 && y < Hf && x >= 0 && x < Wf) {
+      const long e = ((long)y * Wf + x) * c4 + c;          // in units of four elements
+      if constexpr (DT == FM_F32) v = reinterpret_cast<const float4*>(src)[e];
+      else v = half4_to_float4(reinterpret_cast<const uint2*>(src)[e], DT);
+    }
     dst[idx] = v;
   }
 }
@@ -760,34 +776,60 @@ constexpr int kFineGridCap = 1 << 20;
 // one wave per cell, four per workgroup, grid a multiple of 8
 static int cell_blocks(long total) { return (int)(((total + 3) / 4 + 7) / 8 * 8); }
 
-extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int layout, int W, int stride,
-                                 int pad, int w_c, const int64_t* b_ids, const int64_t* ids, const int32_t* d_count,
-                                 int m_max, float* out, void* stream) {
+template <int DT>
+static void launch_generic_gather(const void* feat_f, int Cf, int Hf, int Wf, int layout, int W, int stride, int pad, int w_c,
+                                  const int64_t* b_ids, const int64_t* ids, const int32_t* d_count, int m_max, float* out,
+                                  hipStream_t st) {
+  using E = typename MapElem<DT>::type;
+  if (layout == 0) {
+    const size_t smem = (size_t)W * W * (Cf + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_gather_nchw<DT>, dim3(m_max), dim3(256), smem, st, (const E*)feat_f, Cf, Hf, Wf, W, stride, pad, w_c,
+                       b_ids, ids, d_count, m_max, out);
+  } else {
+    hipLaunchKernelGGL(k_gather_nhwc<DT>, dim3(m_max), dim3(256), 0, st, (const E*)feat_f, Cf, Hf, Wf, W, stride, pad, w_c,
+                       b_ids, ids, d_count, m_max, out);
+  }
+}
+
+extern "C" int fm_gather_windows_dtype(const void* feat_f, int map_dtype, int N, int Cf, int Hf, int Wf, int layout, int W,
+                                       int stride, int pad, int w_c, const int64_t* b_ids, const int64_t* ids,
+                                       const int32_t* d_count, int m_max, float* out, void* stream) {
   if (m_max == 0) return FM_OK;
   if (!feat_f || !b_ids || !ids || !out) return FM_E_NULL;
+  if (map_dtype != FM_F32 && map_dtype != FM_F16 && map_dtype != FM_BF16) return FM_E_UNSUPPORTED;
   if (N <= 0 || Cf <= 0 || Hf <= 0 || Wf <= 0 || W <= 0 || stride <= 0 || w_c <= 0 || m_max < 0) return FM_E_SHAPE;
   if (W > 15 || Cf > 512 || (layout == 1 && Cf % 4) || (layout != 0 && layout != 1)) return FM_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (layout == 0 && fast_nchw64(Cf, Hf, Wf, W)) {
-    launch_list64<false>(W, list_blocks(m_max), st, feat_f, Hf, Wf, stride, pad, w_c, b_ids, ids, d_count, m_max, out,
-                         nullptr, nullptr, 0);
-  } else if (layout == 0) {
-    const size_t smem = (size_t)W * W * (Cf + 1) * sizeof(float);
-    if (smem > 64 * 1024) return FM_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_gather_nchw, dim3(m_max), dim3(256), smem, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c,
-                       b_ids, ids, d_count, m_max, out);
-  } else if (Cf == 64 && (W == 5 || W == 7)) {      // channels-last fast path: one wave per window, 16-byte chunks
+  if (layout == 0 && (size_t)W * W * (Cf + 1) * sizeof(float) > 64 * 1024 &&
+      !(map_dtype == FM_F32 && fast_nchw64(Cf, Hf, Wf, W))) return FM_E_UNSUPPORTED;
+  if (map_dtype == FM_F32 && layout == 0 && fast_nchw64(Cf, Hf, Wf, W)) {
+    launch_list64<false>(W, list_blocks(m_max), st, (const float*)feat_f, Hf, Wf, stride, pad, w_c, b_ids, ids, d_count, m_max,
+                         out, nullptr, nullptr, 0);
+  } else if (map_dtype == FM_F32 && layout == 1 && Cf == 64 && (W == 5 || W == 7)) {
+    // channels-last fast path: one wave per window, 16-byte chunks
     if (W == 5)
-      hipLaunchKernelGGL(k_gather_nhwc64<5>, dim3(list_blocks(m_max)), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
-                         b_ids, ids, d_count, m_max, out);
+      hipLaunchKernelGGL(k_gather_nhwc64<5>, dim3(list_blocks(m_max)), dim3(256), 0, st, (const float*)feat_f, Hf, Wf, stride,
+                         pad, w_c, b_ids, ids, d_count, m_max, out);
     else
-      hipLaunchKernelGGL(k_gather_nhwc64<7>, dim3(list_blocks(m_max)), dim3(256), 0, st, feat_f, Hf, Wf, stride, pad, w_c,
-                         b_ids, ids, d_count, m_max, out);
+      hipLaunchKernelGGL(k_gather_nhwc64<7>, dim3(list_blocks(m_max)), dim3(256), 0, st, (const float*)feat_f, Hf, Wf, stride,
+                         pad, w_c, b_ids, ids, d_count, m_max, out);
+  } else if (map_dtype == FM_F32) {
+    launch_generic_gather<FM_F32>(feat_f, Cf, Hf, Wf, layout, W, stride, pad, w_c, b_ids, ids, d_count, m_max, out, st);
+  } else if (map_dtype == FM_F16) {
+    // half-precision maps (an autocast backbone's hand-over): read as they are - every value is exact in float32 -
+    // by the generic kernels; no up-cast pass over the whole map in front of the crop
+    launch_generic_gather<FM_F16>(feat_f, Cf, Hf, Wf, layout, W, stride, pad, w_c, b_ids, ids, d_count, m_max, out, st);
   } else {
-    hipLaunchKernelGGL(k_gather_nhwc, dim3(m_max), dim3(256), 0, st, feat_f, Cf, Hf, Wf, W, stride, pad, w_c, b_ids,
-                       ids, d_count, m_max, out);
+    launch_generic_gather<FM_BF16>(feat_f, Cf, Hf, Wf, layout, W, stride, pad, w_c, b_ids, ids, d_count, m_max, out, st);
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int layout, int W, int stride,
+                                 int pad, int w_c, const int64_t* b_ids, const int64_t* ids, const int32_t* d_count,
+                                 int m_max, float* out, void* stream) {
+  return fm_gather_windows_dtype(feat_f, FM_F32, N, Cf, Hf, Wf, layout, W, stride, pad, w_c, b_ids, ids, d_count, m_max, out,
+                                 stream);
 }
 
 extern "C" int fm_gather_windows_cells(const float* feat_f, int N, int Cf, int Hf, int Wf, int W, int stride, int pad,

@@ -471,7 +471,7 @@ def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor,
     if not feat_f.is_cuda:
         raise RuntimeError("feat_f must live on the GPU: the HIP path has no CPU fallback")
     n, cf, hf, wf = feat_f.shape
-    if feat_f.dtype != torch.float32:
+    if feat_f.dtype not in _DTYPES:             # float16 / bfloat16 maps go to the kernels as they are (no up-cast pass)
         feat_f = feat_f.float()
     if feat_f.is_contiguous():
         layout = 0
@@ -483,6 +483,11 @@ def gather_windows(feat_f: torch.Tensor, b_ids: torch.Tensor, ids: torch.Tensor,
     if out is None:
         out = torch.empty(m_max, w * w, cf, dtype=torch.float32, device=feat_f.device)
     if m_max == 0:
+        return out
+    if feat_f.dtype != torch.float32:
+        st = lib.fm_gather_windows_dtype(_ptr(feat_f), _DTYPES[feat_f.dtype], n, cf, hf, wf, layout, w, stride, pad, w_c,
+                                         _ptr(b_ids), _ptr(ids), _ptr(count), m_max, _ptr(out), _stream(feat_f.device))
+        _lib.check(st, "fm_gather_windows_dtype")
         return out
     if cells is not None and layout == 0 and cf == 64 and w in (5, 7) and h_c:
         st = lib.fm_gather_windows_cells(_ptr(feat_f), n, cf, hf, wf, w, stride, pad, int(h_c), int(w_c),

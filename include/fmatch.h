@@ -241,6 +241,13 @@ int fm_gather_windows(const float* feat_f, int N, int Cf, int Hf, int Wf, int la
                       int W, int stride, int pad, int w_c,
                       const int64_t* b_ids, const int64_t* ids,
                       const int32_t* d_count, int m_max, float* out, void* stream);
+/* The same with the element type of the map as an argument (enum fm_dtype): float16 / bfloat16 maps - what a backbone
+ * under autocast hands over (network/net.py:56-57) - are read as they are (every value is exact in float32), no up-cast
+ * pass over the whole map in front of the crop.  out is float32 either way. */
+int fm_gather_windows_dtype(const void* feat_f, int map_dtype, int N, int Cf, int Hf, int Wf, int layout,
+                            int W, int stride, int pad, int w_c,
+                            const int64_t* b_ids, const int64_t* ids,
+                            const int32_t* d_count, int m_max, float* out, void* stream);
 
 /*
  * Cell-ordered window crop for NCHW maps with Cf = 64 and W in {5,7}: one wave per coarse cell in raster

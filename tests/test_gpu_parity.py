@@ -821,6 +821,27 @@ def test_half_precision_fine_maps_need_no_upcast(w, channels_last, dtype):
     assert torch.isfinite(g0).all() and (g0[:, :2] - kc0).abs().max() < 16
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_half_precision_maps_are_cropped_without_an_upcast(channels_last, dtype):
+    """ops.gather_windows on float16 / bfloat16 maps (fm_gather_windows_dtype): read as they are - the crop of the up-cast
+    map bit for bit, zero padding on the borders included."""
+    n, (hc, wc) = 2, (9, 13)
+    ff = torch.as_tensor(np.stack([synth.normal(281 + b, 1, (64, hc * 4, wc * 4)) for b in range(n)]), device=DEV).to(dtype)
+    m = 90
+    b = torch.as_tensor(np.sort((synth.uniform(281, 3, m) * n).astype(np.int64)), device=DEV)
+    i = (synth.uniform(281, 4, m) * hc * wc).astype(np.int64)
+    i[:4] = [0, wc - 1, (hc - 1) * wc, hc * wc - 1]
+    it = torch.as_tensor(i, device=DEV)
+    if channels_last:
+        ff = ff.contiguous(memory_format=torch.channels_last)
+    for w in (5, 7):
+        got = ops.gather_windows(ff, b, it, w, 4, wc)
+        ref = ops.gather_windows(ff.float(), b, it, w, 4, wc)
+        assert got.dtype == torch.float32 and torch.equal(got, ref)
+        assert torch.equal(got.cpu(), orc.crop_windows(ff.float().cpu().contiguous().numpy(), b.cpu(), it.cpu(), w, 4, wc))
+
+
 # ------------------------------------------------------------------ drop-in modules
 def test_modules_follow_the_data_dict_protocol():
     g = load_golden("cfg1_peaky")
