@@ -202,7 +202,7 @@ def _events(fn, iters=10, before=None, group=6):
 def time_kernels(pair):
     """Event-timed launches of the kernels of one step on a workspace the step has filled: the whole coarse stage (one
     fm_coarse_match call: all its launches with their in-stream gaps), its kernels k_prep_split, k_max_i8 and
-    k_screen alone (+ the float16 planes and the dense sum kernel when the pair runs with FM_MODE_DENSE), the
+    k_thresh + k_screen_rows alone (+ the float16 planes and the dense sum kernel when the pair runs with FM_MODE_DENSE), the
     window crop and the fine kernel.  The assignment kernel cannot be re-run on its own outputs; its share is what
     remains of the coarse stage."""
     lib = _lib.load()
@@ -317,17 +317,17 @@ def committed_traffic(workload):
     next to them.  The newest round's file whose `kernel_src_sha16` equals the sources in this tree is used (the
     counters then belong to these kernels); None when there is none or the workload is another one."""
     import glob
-    if workload != "cfg2":
+    if workload not in ("cfg2", "cfg3"):
         return None, None
     sha = kernel_source_sha()
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_cfg2.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_fetch_write_{workload}.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
         if d.get("kernel_src_sha16") != sha:
             continue
         tot = 0.0
         for name, c in d.get("kernels", {}).items():
-            if ("k_max_i8" in name or "k_screen" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            if ("k_max_i8" in name or "k_screen" in name or "k_thresh" in name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 tot += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         if tot:
             return int(tot), os.path.relpath(path, ROOT)
@@ -957,7 +957,7 @@ def main():
         # (+ float16 planes and the dense sum kernel under FM_MODE_DENSE).  Priced against the int8 MFMA peak, the
         # matrix-core type the dominant kernel runs on.
         "roofline": {"bound": "mfma",
-                     "kernel": "coarse correlation: k_max_i8<256> + k_screen<256>"
+                     "kernel": "coarse correlation: k_max_i8<256> + k_thresh + k_screen_rows<256>"
                                + (" + k_prep_f16 + k_dense<256>" if pairs[0].dense else "")
                                + " (every launch on the L x S product; v_mfma_i32_32x32x32_i8)",
                      "achieved": round(ach, 2), "peak": PEAK_I8_DENSE_TOPS, "unit": "TFLOP/s",
@@ -1089,6 +1089,27 @@ def extras(a, wl, dev, streams, flops):
             rate, ver, m_pp = stream_rate(w3, a.window, dev, "peaky", w3["n"], 2, steps=6, nsets=2)
             res = {"value": round(rate, 2), "unit": "image-pairs/s", "pairs_per_step": w3["n"],
                    "verified": ver["ok"] if ver else None, "verification": ver, "matches_per_pair": round(m_pp, 1)}
+            # the coarse correlation's roofline at the batch - the regime in which the matrix cores decide: event-timed
+            # launches of the max pass and the screening kernels on a filled workspace, algorithmic 2 N L S C flop
+            with torch.cuda.stream(streams[0]):
+                p3 = Pair(w3, 9000, a.window, dev, "peaky")
+                p3.step()
+                torch.cuda.synchronize()
+                p3.last[0].read_count()
+                t3 = time_kernels(p3)
+                del p3
+            f3 = 2.0 * w3["n"] * (w3["h"] // 8 * (w3["w"] // 8)) ** 2 * w3["c"]
+            tc3 = t3["max"] + t3["sparse"]
+            tr3, tr3_src = committed_traffic("cfg3")
+            res["roofline"] = {"bound": "mfma", "kernel": "coarse correlation: k_max_i8<256> + k_thresh + k_screen_rows<256>",
+                               "achieved": round(f3 / (tc3 * 1e-3) / 1e12, 2), "peak": PEAK_I8_DENSE_TOPS, "unit": "TFLOP/s",
+                               "frac": round(f3 / (tc3 * 1e-3) / 1e12 / PEAK_I8_DENSE_TOPS, 4),
+                               "frac_of_f16_peak": round(f3 / (tc3 * 1e-3) / 1e12 / PEAK_F16_DENSE_TFLOPS, 4),
+                               "traffic": tr3, "traffic_source": tr3_src, "avg_ms": round(tc3, 5), "algorithmic_flop": f3,
+                               "max_pass": {"avg_ms": round(t3["max"], 5),
+                                            "frac": round(f3 / (t3["max"] * 1e-3) / 1e12 / PEAK_I8_DENSE_TOPS, 4)},
+                               "screening_avg_ms": round(t3["sparse"], 5), "k_prep_split_avg_ms": round(t3["prep"], 5),
+                               "coarse_stage_avg_ms": round(t3["coarse"], 5), "fine_avg_ms": round(t3["fine"], 5)}
             # materialise-conf mode (coarse_matching_new.py:70; BASELINE config 3 "HBM-bound stress"): the dense
             # [N,L,S] float32 conf_matrix is written by one more sweep
             p = Pair(w3, 9100, a.window, dev, "peaky")

@@ -23,27 +23,15 @@ int choose_splits(int N, int panels, int tiles, int target) {
   return s;
 }
 
-// column splits of the screening kernel: one round of the chip's compute units (a workgroup is 8 waves with ~200
-// registers and up to 140 KB of LDS: one per CU), never more than kScreenUnits 32-column units per workgroup (the B
-// fragments of the range's live units share its LDS).
-static int choose_splits_sparse(int N, int panels, int nunits, int* units_per_split) {
-  // (two workgroups per CU - ~100 registers, <= 64 KB of LDS at <= 8 units - measured best: 256 / 384 / 512 / 768
-  // workgroups at one 640x480 pair: 16.4 / 16.2 / 15.9 / 21.2 us alone, 24.3 / 25.9 / 25.6 / 24.5 k pairs/s on 4 streams)
-  int target = 512;
-#ifdef FM_TUNE_ENV
-  if (const char* e = getenv("FM_TARGET_WGS_S")) target = atoi(e) > 0 ? atoi(e) : 512;
-#endif
-  int s = target / (N * panels > 0 ? N * panels : 1);
-  // (a batch that fills the chip by itself: ranges of <= 8 units keep a workgroup's LDS under 80 KB - two per CU, the
-  // only latency hiding this kernel has; 64 x 640x480: 593 -> 527 us)
-  const int ucap = N * panels >= 256 ? 8 : kScreenUnits;
-  const int smin = (nunits + ucap - 1) / ucap;
-  if (s < smin) s = smin;
-  if (s > nunits) s = nunits;
-  if (s < 1) s = 1;
-  const int per = (nunits + s - 1) / s;
-  *units_per_split = per;
-  return (nunits + per - 1) / per;
+// Items of the screening kernel k_screen_rows: one wave per (32-row block, chunk of <= 64 column units).  64 units when the
+// launch holds thousands of items anyway (a batch, a 1024x1024 pair); 32 - shorter waves, more of them - for a pair or two
+// (one 640x480 pair on 4 streams: 27.0 / 28.0 / 27.3 / 26.1 k pairs/s at 64 / 32 / 16 / 8 units; 64 pairs: 286 / 309 /
+// 375 us at 64 / 32 / 16)
+static int choose_screen_chunks(int N, int Lp, int nunits, int* units_per_chunk) {
+  const long nrb = (long)N * (Lp / 32);
+  const int cu = nrb * ((nunits + 63) / 64) >= 4096 ? 64 : 32;
+  *units_per_chunk = cu;
+  return (nunits + cu - 1) / cu;
 }
 
 // k_max_i8's workgroups are 4 waves (256 rows x a range of tiles) and two of them fit a CU: two per CU when the batch
@@ -67,7 +55,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
 #ifdef FM_TUNE_ENV
   if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : kMaxPassTarget);
 #endif
-  w.splits_s = choose_splits_sparse(N, w.panels, w.Sp / 32, &w.units_s);
+  w.splits_s = choose_screen_chunks(N, w.Lp, w.Sp / 32, &w.units_s);
   const size_t rows = (size_t)N * w.Lp, cols = (size_t)N * w.Sp;
   const size_t nblk = (rows * slots + 255) / 256;
   size_t o = 0;

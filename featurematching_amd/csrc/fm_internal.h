@@ -14,10 +14,6 @@ constexpr int kColParts = 1;         // column partials per 256-row panel (the 8
 constexpr int kTieCap = 1023;        // listed tie losers per image; beyond it the gathers scan the match list
 constexpr int kTileCols = 64;     // coarse columns (image-1 cells) per streamed tile
 constexpr int kUnitsPerSplit = 64; // 32-column units one workgroup of the dense-path kernels covers at most (64-bit live mask)
-constexpr int kRowsFormMinRowBlocks = 448;    // 32-row blocks in a launch from which the batched screening (k_thresh + k_screen_rows)
-                                              // runs: 3 pairs of 640x480, one 1024x1024 pair (measured crossover: 2 pairs 30 vs 27 us,
-                                              // 4 pairs 33 vs 41 us, 64 pairs 270 vs 530 us, 1024x1024 32 vs 75 us)
-constexpr int kScreenUnits = 16;   // ... one workgroup of the screening kernel (their int8 B fragments share its LDS: 8 KiB each at C = 256)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kSkipLog2 = 32.f;    // terms more than 2^32 below every stabiliser are negligible (see coarse_sum_sparse.hip)
 // internal status bit (not reported): pass B's max-based screening overflowed a row's slots
@@ -40,7 +36,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 struct CoarseWs {
   int N, L, S, C, Lp, Sp, panels, tiles, splits, slots;
   int splits0;                                // column splits of the max pass (its own grid size)
-  int splits_s, units_s;                      // sparse sum kernel: column splits and 32-column units per split
+  int splits_s, units_s;                      // screening kernel: column chunks per row block and 32-column units per chunk (<= 64)
   // zeroed on every call (contiguous, starts at the base)
   size_t zero_begin, cand_count, ccand_count, cand_count_b, ccand_count_b, dense_cnt, scalars, zero_end;
                                               // cand_count / ccand_count: candidates per row / per column found by the

@@ -133,9 +133,8 @@ def test_layout_query_is_consistent():
     assert 1 <= v[8] <= 32 and v[6] * v[8] <= 256                            # one round of the 256 CUs
     offs = v[10:37] + v[39:]
     assert all(o % 256 == 0 for o in offs)
-    # sparse sum kernel: splits x units per split cover Sp/32, at most 64 units per split, at most half a round of
-    # the chip's workgroup slots at one pair
-    assert v[37] * v[38] >= 150 and v[38] <= 16 and v[6] * v[37] <= 512      # screening kernel: <= 16 units per workgroup, two per CU
+    # screening kernel: chunks x units per chunk cover Sp/32, at most 64 units per chunk (one ballot per chunk)
+    assert v[37] * v[38] >= 150 and v[38] in (32, 64) and (v[37] - 1) * v[38] < 150
     n = C.c_size_t(0)
     lib.fm_coarse_workspace_bytes(1, 4800, 4800, 256, 8, C.byref(n))
     assert offs[-1] == n.value

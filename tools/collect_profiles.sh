@@ -22,6 +22,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- pyt
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python bench.py $PM > $O/write.json 2> $O/write.err
 echo "write done"
+# (3b) the same two counters on the batch of 64 pairs (extra.cfg3.roofline.traffic)
+PM3="--workload cfg3 --steps 4 --warmup 2 --skip-cpu --quick --streams 1 --pairs 1 --no-graph"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch3 -- python bench.py $PM3 > $O/fetch3.json 2> $O/fetch3.err
+echo "fetch3 done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write3 -- python bench.py $PM3 > $O/write3.json 2> $O/write3.err
+echo "write3 done"
 # (4) matrix-core utilisation of the sweeps (SQ block, one pass)
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python bench.py $PM > $O/sq.json 2> $O/sq.err
 echo "sq done"
