@@ -34,9 +34,14 @@ static int choose_screen_chunks(int N, int Lp, int nunits, int* units_per_chunk)
   return (nunits + cu - 1) / cu;
 }
 
-// k_max_i8's workgroups are 4 waves (256 rows x a range of tiles) and two of them fit a CU: two per CU when the batch
-// alone cannot fill the chip
-constexpr int kMaxPassTarget = 512;
+// k_max_i8's workgroups are 4 waves (256 rows x a range of tiles) and two of them fit a CU.  When the batch alone cannot
+// fill the chip the grid aims at ONE workgroup per compute unit, not two: alone the kernel is 2.8 us slower at one
+// 640x480 pair (15.4 against 12.7 us), but on the bench's four streams the other half of every compute unit's registers and
+// LDS is what the other pairs' kernels run in - 128 / 192 / 256 / 384 / 512 workgroups: 28.4 / 28.9 / 28.7 / 28.3 / 27.9 k
+// pairs/s (round 5, with k_screen_rows; round 4's measurement with the 128-KiB-of-LDS screening kernel beside it saw no
+// difference).  A batch that fills the resident slots by itself gets ~10 rounds of 512.
+constexpr int kMaxPassTarget = 256;
+constexpr int kMaxPassSlots = 512;
 
 CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   CoarseWs w;
@@ -51,7 +56,7 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   // (a batch that fills the resident slots by itself gets ~10 rounds of workgroups, so that the last round's tail is a
   // small share of the launch: 1216 workgroups on 512 slots were "2.4 of 3 rounds"; 64 pairs of 640x480: 351 -> 333 us
   // with 4 splits; 2 / 3 / 4 / 5 / 8 splits: 335 / 340 / 333 / 348 / 363 us)
-  w.splits0 = choose_splits(N, w.panels, w.tiles, N * w.panels >= kMaxPassTarget ? 10 * kMaxPassTarget : kMaxPassTarget);
+  w.splits0 = choose_splits(N, w.panels, w.tiles, N * w.panels >= kMaxPassSlots ? 10 * kMaxPassSlots : kMaxPassTarget);
 #ifdef FM_TUNE_ENV
   if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : kMaxPassTarget);
 #endif
