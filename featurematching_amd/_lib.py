@@ -64,6 +64,7 @@ SIGNATURES = {
     "fm_dual_softmax_backward_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "fm_dual_softmax_backward": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, C.c_size_t, _p,
                                       _p, _p]),
+    "fm_dual_softmax_backward_dense": (_i, [_p, _p, _i, _i, _i, _i, _f, _p, _p, _i, _p, _p, _i, _p, _p, C.c_size_t, _p, _p, _p]),
     "fm_gather_windows": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "fm_gather_windows_dtype": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "fm_coarse_cell_maps": (_i, [_p, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_p),

@@ -85,12 +85,24 @@ __global__ __launch_bounds__(256) void k_dsm_uv(const int64_t* __restrict__ b_id
 // grid (ceil(R / 32), N, Z): workgroup = 32 owner rows x the z-th share of the other image's 32-descriptor tiles.
 // C = padded channel count (64 / 128 / 256), c_in <= C the rows' real length.  Partial gradients (one per z) go to
 // part[z][b][row][c_in]; k_dsm_combine adds them up and scales.
-template <int C>
+// MODE (round 5: a DENSE dL/dconf = G [N, L, S], what the reference's loss over all negatives hands back - losses/loss.py:44-50,
+// 62-65 - without any [N, L, S] temporary):
+//   kDsmSparse : as above (G lives in w_x / w_y and the entries' own kernel).
+//   kDsmStats  : v_k = sum_l G_kl conf_kl and u_l = sum_k G_kl conf_kl with conf recomputed tile by tile from exact float32
+//                dot products (conf = A B); no gradient phase.  Launched on side 0 only; v and u by float atomics
+//                (<= 4 adds per row, one per row tile and column).
+//   kDsmDense  : D_kl = 2 G_kl conf_kl - A_kl u_l - B_kl v_k, the whole of dL/dsim, accumulated into the rows' gradient.
+// G is read through a transposing LDS tile when the owner image is image 1 (g_t: element (owner row, other row) lives at
+// G[other][owner]): both sides read 128-byte row segments of G.  G is read three times in all (92 MB per 640x480 pair
+// each), nothing of its size is written.
+enum { kDsmSparse = 0, kDsmStats = 1, kDsmDense = 2 };
+template <int C, int MODE>
 __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, const float* __restrict__ Y, int R, int T, int c_in,
                                                  const float* __restrict__ ofs_x, const float* __restrict__ sum_x, int pitch_x,
                                                  const float* __restrict__ ofs_y, const float* __restrict__ sum_y,
                                                  int pitch_y, const float* __restrict__ w_x, const float* __restrict__ w_y,
-                                                 float k2, float* __restrict__ part) {
+                                                 float k2, float* __restrict__ part, const float* __restrict__ G, int g_t,
+                                                 float* __restrict__ v_out, float* __restrict__ u_out) {
   constexpr int P = C + 4;                   // row pitch (floats): 16-byte reads of 16 consecutive rows hit all banks
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Xs = sm;                            // [32][P]
@@ -113,13 +125,18 @@ __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, co
   };
   load_tile(Xs, Xb, k0, R);
   const int tx = tid & 31, ty = tid >> 5;                 // similarity phase: column tx, rows ty + 8 q
-  float ox[4], wx[4];
+  float ox[4], wx[4], isx[4], vacc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int k = k0 + ty + 8 * q;
     ox[q] = k < R ? ofs_x[(long)b * pitch_x + k] : 0.f;
-    wx[q] = k < R ? w_x[(long)b * R + k] / sum_x[(long)b * pitch_x + k] : 0.f;
+    isx[q] = k < R ? 1.0f / sum_x[(long)b * pitch_x + k] : 0.f;
+    if (MODE == kDsmSparse) wx[q] = k < R ? w_x[(long)b * R + k] / sum_x[(long)b * pitch_x + k] : 0.f;
+    else wx[q] = (MODE == kDsmDense && k < R) ? w_x[(long)b * R + k] : 0.f;
+    vacc[q] = 0.f;
   }
+  float* Gs = Dt + 32 * 36;                  // [32][33]: the tile of G (MODE != kDsmSparse)
+  const float* Gb = G ? G + (long)b * (g_t ? (long)T * R : (long)R * T) : nullptr;
   const int c4 = tid & 63, rg = tid >> 6;                 // gradient phase: channels 4 c4 .. + 3, rows 8 rg .. + 7
   float acc[8][4];
 #pragma unroll
@@ -132,8 +149,30 @@ __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, co
     load_tile(Ys, Yb, l0, T);
     const int l = l0 + tx;
     const float oy = l < T ? ofs_y[(long)b * pitch_y + l] : 0.f;
-    const float wy = l < T ? w_y[(long)b * T + l] / sum_y[(long)b * pitch_y + l] : 0.f;
+    const float isy = l < T ? 1.0f / sum_y[(long)b * pitch_y + l] : 0.f;
+    float wy;
+    if (MODE == kDsmSparse) wy = l < T ? w_y[(long)b * T + l] / sum_y[(long)b * pitch_y + l] : 0.f;
+    else wy = (MODE == kDsmDense && l < T) ? w_y[(long)b * T + l] : 0.f;
+    float gq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != kDsmSparse) {
+      // 128-byte row segments of G either way: g_t = 0 -> G[owner k0 + ty + 8q][other l0 + tx] straight into registers;
+      // g_t = 1 -> G[other l0 + ty + 8q][owner k0 + tx] into the LDS tile, read back transposed behind the barrier
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!g_t) {
+          const int k = k0 + ty + 8 * q;
+          gq[q] = (k < R && l < T) ? Gb[(long)k * T + l] : 0.f;
+        } else {
+          const int lo = l0 + ty + 8 * q, ko = k0 + tx;
+          Gs[(ty + 8 * q) * 33 + tx] = (lo < T && ko < R) ? Gb[(long)lo * R + ko] : 0.f;
+        }
+      }
+    }
     __syncthreads();
+    if (MODE != kDsmSparse && g_t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gq[q] = Gs[tx * 33 + ty + 8 * q];
+    }
     float sv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int c = 0; c < C; c += 4) {
@@ -150,11 +189,29 @@ __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, co
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool ok = l < T && k0 + ty + 8 * q < R;
-      const float a = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[q], k2, oy)) * wy;
-      const float bt = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[q], k2, ox[q])) * wx[q];
-      Dt[tx * 36 + ty + 8 * q] = ok ? -(a + bt) : 0.f;
+      if (MODE == kDsmSparse) {
+        const float a = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[q], k2, oy)) * wy;
+        const float bt = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[q], k2, ox[q])) * wx[q];
+        Dt[tx * 36 + ty + 8 * q] = ok ? -(a + bt) : 0.f;
+      } else {
+        const float ar = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[q], k2, oy)) * isy;       // softmax over the owner's rows
+        const float br = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[q], k2, ox[q])) * isx[q]; // ... over the other image's
+        const float gc = ok ? gq[q] * (ar * br) : 0.f;
+        if (MODE == kDsmStats) { vacc[q] += gc; Dt[tx * 36 + ty + 8 * q] = gc; }
+        else Dt[tx * 36 + ty + 8 * q] = ok ? 2.0f * gc - ar * wy - br * wx[q] : 0.f;
+      }
     }
     __syncthreads();
+    if (MODE == kDsmStats) {
+      // column sums of this tile's G conf: 32 threads add the 32 owner rows of their column in a fixed order
+      if (tid < 32 && l0 + tid < T) {
+        float cs = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) cs += Dt[tid * 36 + rr];
+        atomicAdd(&u_out[(long)b * T + l0 + tid], cs);
+      }
+      continue;
+    }
     if (4 * c4 < C) {
 #pragma unroll 4
       for (int ll = 0; ll < 32; ++ll) {
@@ -171,6 +228,18 @@ __global__ __launch_bounds__(256) void k_dsm_bwd(const float* __restrict__ X, co
         }
       }
     }
+  }
+  if (MODE == kDsmStats) {
+    // row sums: the 32 columns a row's partial sums sit in are the 32 lanes of a half wave
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float t = vacc[q];
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+      const int k = k0 + ty + 8 * q;
+      if (tx == 0 && k < R) atomicAdd(&v_out[(long)b * R + k], t);
+    }
+    return;
   }
   if (c4 < vpr) {
     float* out = part + (((long)z * gridDim.y + b) * R) * c_in;
@@ -279,6 +348,78 @@ extern "C" size_t fm_dual_softmax_backward_workspace_bytes(int N, int L, int S, 
   return align256((size_t)N * (L + S) * 4) + (size_t)4 * N * m * C * 4;      // u, v + up to 4 partial gradients
 }
 
+// the tiled sweep of one side (0: owner = image 0, 1: owner = image 1) in one of its three modes + the combine of its partials
+static int dsm_sweep(int mode, int side, const float* feat0, const float* feat1, int N, int L, int S, int C, float k2, float inv_ct,
+                     const float* ofs_r, const float* sum_r, int pitch_r, const float* ofs_c, const float* sum_c, int pitch_c,
+                     float* v, float* u, float* part, const float* G, float* d_out, hipStream_t st) {
+  const float* X = side ? feat1 : feat0;
+  const float* Y = side ? feat0 : feat1;
+  const int R = side ? S : L, T = side ? L : S;
+  const int Z = dsm_zsplit(N, R);
+  const dim3 grid((R + 31) / 32, N, Z);
+  const int Cp = padded_channels(C);
+  const int smem = (64 * (Cp + 4) + 32 * 36 + 32 * 33) * 4;
+  hipError_t e = hipSuccess;
+#define FM_DSM_LAUNCH(CC, MM)                                                                                              \
+  {                                                                                                                        \
+    static unsigned long long lds_set = 0;                                                                                 \
+    e = ensure_dynamic_lds(&k_dsm_bwd<CC, MM>, (64 * (CC + 4) + 32 * 36 + 32 * 33) * 4, &lds_set);                         \
+    if (e != hipSuccess) return (int)e;                                                                                    \
+    hipLaunchKernelGGL((k_dsm_bwd<CC, MM>), grid, dim3(256), smem, st, X, Y, R, T, C, side ? ofs_c : ofs_r,                \
+                       side ? sum_c : sum_r, side ? pitch_c : pitch_r, side ? ofs_r : ofs_c, side ? sum_r : sum_c,         \
+                       side ? pitch_r : pitch_c, side ? u : v, side ? v : u, k2, part, G, side, v, u);                     \
+  }
+#define FM_DSM_CASE(CC)                                                      \
+  case CC:                                                                   \
+    if (mode == kDsmSparse) FM_DSM_LAUNCH(CC, kDsmSparse)                    \
+    else if (mode == kDsmStats) FM_DSM_LAUNCH(CC, kDsmStats)                 \
+    else FM_DSM_LAUNCH(CC, kDsmDense)                                        \
+    break;
+  switch (Cp) {
+    FM_DSM_CASE(64)
+    FM_DSM_CASE(128)
+    FM_DSM_CASE(256)
+    default: return FM_E_UNSUPPORTED;
+  }
+#undef FM_DSM_CASE
+#undef FM_DSM_LAUNCH
+  if (mode != kDsmStats) {
+    const long n4 = (long)N * R * C / 4;
+    hipLaunchKernelGGL(k_dsm_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n4, Z, inv_ct,
+                       (float4*)d_out);
+  }
+  return (int)hipGetLastError();
+}
+
+// Backward of the dual softmax for a DENSE dL/dconf (losses/loss.py:44-50, 62-65: the loss terms over all negatives):
+// G = dL/dconf [N, L, S] float32 [dev], the softmax statistics as in fm_dual_softmax_backward.  Three tiled sweeps (row /
+// column sums of G conf; the two gradients), no [N, L, S] temporary: the workspace is fm_dual_softmax_backward_workspace_bytes.
+extern "C" int fm_dual_softmax_backward_dense(const float* feat0, const float* feat1, int N, int L, int S, int C,
+                                              float temperature, const float* ofs_r, const float* sum_r, int pitch_r,
+                                              const float* ofs_c, const float* sum_c, int pitch_c, const float* G,
+                                              void* workspace, size_t workspace_bytes, float* d_feat0, float* d_feat1,
+                                              void* stream) {
+  if (!feat0 || !feat1 || !ofs_r || !ofs_c || !sum_r || !sum_c || !G || !workspace || !d_feat0 || !d_feat1) return FM_E_NULL;
+  if (!(N > 0 && L > 0 && S > 0) || pitch_r < L || pitch_c < S) return FM_E_SHAPE;
+  if (!valid_channels(C) || !(temperature > 0.f)) return FM_E_UNSUPPORTED;
+  if (workspace_bytes < fm_dual_softmax_backward_workspace_bytes(N, L, S, C) || ((uintptr_t)workspace & 255)) return FM_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_ct = 1.0f / ((float)C * temperature), k2 = kLog2e * inv_ct;
+  float* v = (float*)workspace;                 // [N][L]  row sums of G conf
+  float* u = v + (size_t)N * L;                 // [N][S]  column sums
+  float* part = (float*)((char*)workspace + align256((size_t)N * (L + S) * 4));
+  hipError_t e = hipMemsetAsync(workspace, 0, (size_t)N * (L + S) * 4, st);
+  if (e != hipSuccess) return (int)e;
+  int r = dsm_sweep(kDsmStats, 0, feat0, feat1, N, L, S, C, k2, inv_ct, ofs_r, sum_r, pitch_r, ofs_c, sum_c, pitch_c, v, u, part, G,
+                    nullptr, st);
+  if (r != FM_OK) return r;
+  r = dsm_sweep(kDsmDense, 0, feat0, feat1, N, L, S, C, k2, inv_ct, ofs_r, sum_r, pitch_r, ofs_c, sum_c, pitch_c, v, u, part, G,
+                d_feat0, st);
+  if (r != FM_OK) return r;
+  return dsm_sweep(kDsmDense, 1, feat0, feat1, N, L, S, C, k2, inv_ct, ofs_r, sum_r, pitch_r, ofs_c, sum_c, pitch_c, v, u, part, G,
+                   d_feat1, st);
+}
+
 extern "C" int fm_dual_softmax_backward(const float* feat0, const float* feat1, int N, int L, int S, int C, float temperature,
                                         const float* ofs_r, const float* sum_r, int pitch_r, const float* ofs_c,
                                         const float* sum_c, int pitch_c,
@@ -298,34 +439,10 @@ extern "C" int fm_dual_softmax_backward(const float* feat0, const float* feat1, 
   hipError_t e = hipMemsetAsync(workspace, 0, (size_t)N * (L + S) * 4, st);
   if (e != hipSuccess) return (int)e;
   if (K > 0) hipLaunchKernelGGL(k_dsm_uv, dim3((K + 255) / 256), dim3(256), 0, st, b_ids, i_ids, j_ids, gc, K, L, S, v, u);
-  const int Cp = padded_channels(C);
   for (int side = 0; side < 2; ++side) {
-    const float* X = side ? feat1 : feat0;
-    const float* Y = side ? feat0 : feat1;
-    const int R = side ? S : L, T = side ? L : S;
-    const int Z = dsm_zsplit(N, R);
-    const dim3 grid((R + 31) / 32, N, Z);
-    const int smem = (64 * (Cp + 4) + 32 * 36) * 4;
-#define FM_DSM_CASE(CC)                                                                                                    \
-  case CC: {                                                                                                               \
-    static unsigned long long lds_set = 0;                                                                                 \
-    e = ensure_dynamic_lds(&k_dsm_bwd<CC>, (64 * (CC + 4) + 32 * 36) * 4, &lds_set);                                       \
-    if (e != hipSuccess) return (int)e;                                                                                    \
-    hipLaunchKernelGGL(k_dsm_bwd<CC>, grid, dim3(256), smem, st, X, Y, R, T, C, side ? ofs_c : ofs_r, side ? sum_c : sum_r, \
-                       side ? pitch_c : pitch_r, side ? ofs_r : ofs_c, side ? sum_r : sum_c, side ? pitch_r : pitch_c,     \
-                       side ? u : v, side ? v : u, k2, part);                                                            \
-    break;                                                                                                                 \
-  }
-    switch (Cp) {
-      FM_DSM_CASE(64)
-      FM_DSM_CASE(128)
-      FM_DSM_CASE(256)
-      default: return FM_E_UNSUPPORTED;
-    }
-#undef FM_DSM_CASE
-    const long n4 = (long)N * R * C / 4;
-    hipLaunchKernelGGL(k_dsm_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)part, n4, Z, inv_ct,
-                       (float4*)(side ? d_feat1 : d_feat0));
+    const int r = dsm_sweep(kDsmSparse, side, feat0, feat1, N, L, S, C, k2, inv_ct, ofs_r, sum_r, pitch_r, ofs_c, sum_c, pitch_c, v,
+                            u, part, nullptr, side ? d_feat1 : d_feat0, st);
+    if (r != FM_OK) return r;
   }
   if (K > 0)
     hipLaunchKernelGGL(k_dsm_entries, dim3((K + 3) / 4), dim3(256), 0, st, feat0, feat1, L, S, C, b_ids, i_ids, j_ids, gc, K,

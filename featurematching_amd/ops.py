@@ -407,6 +407,36 @@ def dual_softmax_at(feat_c0: torch.Tensor, feat_c1: torch.Tensor, b_ids, i_ids, 
     return _DualSoftmaxAt.apply(feat_c0, feat_c1, b_ids, i_ids, j_ids, buffers._temperature, buffers)
 
 
+def _dsm_backward_dense(f0, f1, temperature, buffers, grad):
+    """(dL/df0, dL/df1) for a DENSE dL/dconf (fm_dual_softmax_backward_dense): three tiled sweeps that recompute conf from
+    exact float32 dot products and the forward call's softmax statistics - no [N, L, S] temporary."""
+    lib = _lib.load()
+    x0, x1 = _f32c(f0, "feat_c0"), _f32c(f1, "feat_c1")
+    n, l, c = x0.shape
+    s = x1.shape[1]
+    g = _f32c(grad, "grad")
+    stats = buffers.softmax_stats()
+    need = int(lib.fm_dual_softmax_backward_workspace_bytes(n, l, s, c))
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=x0.device)
+    off = (-ws.data_ptr()) % 256
+    d0, d1 = torch.empty_like(x0), torch.empty_like(x1)
+    _lib.check(lib.fm_dual_softmax_backward_dense(_ptr(x0), _ptr(x1), n, l, s, c, float(temperature), *stats, _ptr(g),
+                                                  C.c_void_p(ws.data_ptr() + off), need, _ptr(d0), _ptr(d1), _stream(x0.device)),
+               "fm_dual_softmax_backward_dense")
+    d0._keep = (ws, g, buffers)
+    return d0.to(f0.dtype), d1.to(f1.dtype)
+
+
+def _count_nonzero_bounded(t: torch.Tensor, chunk_elems: int = 1 << 20) -> int:
+    """number of non-zero entries of a large tensor with temporaries of at most `chunk_elems` bytes (torch.count_nonzero
+    materialises a boolean mask of the whole tensor) and one host sync"""
+    flat = t.reshape(-1)
+    tot = torch.zeros((), dtype=torch.int64, device=t.device)
+    for o in range(0, flat.numel(), chunk_elems):
+        tot += torch.count_nonzero(flat[o:o + chunk_elems])
+    return int(tot)
+
+
 class _ConfMatrixGrad(torch.autograd.Function):
     """Attaches the gradient of the dual softmax to the conf_matrix the HIP forward produced, so that the
     reference's coarse loss (losses/loss.py:27-67 reads data['conf_matrix']) trains the descriptors.
@@ -415,11 +445,13 @@ class _ConfMatrixGrad(torch.autograd.Function):
     (coarse_matching_new.py:64-68).  With G = dL/dconf and c = conf:
         dL/dsim = 2 G c - A u - B v,   u_j = sum_i (G c)_ij,   v_i = sum_j (G c)_ij
         dL/df0  = dL/dsim . f1 / (C T),   dL/df1 = dL/dsim^T . f0 / (C T)
-    The reference's loss reads conf at the supervised entries only (sparse_spvs, its default: loss.py:57-61), so the G
-    autograd hands over is zero almost everywhere: its non-zero entries go to fm_dual_softmax_backward, which recomputes
-    A and B tile by tile from the softmax statistics of the forward call - no [N, L, S] temporary.  A G that is dense
-    (the non-default loss over all negatives: more than 16 entries per row on average) takes the plain torch
-    formula below (three dense temporaries), with a warning."""
+    Both forms of G are served by HIP kernels that recompute A and B tile by tile from the softmax statistics of the
+    forward call - no [N, L, S] temporary:
+      * the reference's default loss reads conf at the supervised entries only (sparse_spvs: loss.py:57-61), so G is zero
+        almost everywhere: its non-zero entries go to fm_dual_softmax_backward;
+      * a G that is dense (the focal / cross-entropy terms over ALL negatives, loss.py:44-50, 62-65: more than 16 entries
+        per row on average) goes to fm_dual_softmax_backward_dense, which streams G through the same tiled sweep.
+    Without the forward call's buffers (no statistics) the plain torch formula is all that is left."""
 
     @staticmethod
     def forward(ctx, feat_c0, feat_c1, conf, temperature, buffers):
@@ -432,13 +464,15 @@ class _ConfMatrixGrad(torch.autograd.Function):
         f0, f1, conf = ctx.saved_tensors
         n, l, s = conf.shape
         if ctx.buffers is not None:
-            nz = torch.nonzero(grad, as_tuple=True)
-            if nz[0].shape[0] <= 16 * n * max(l, s):
+            if _count_nonzero_bounded(grad) <= 16 * n * max(l, s):
+                nz = torch.nonzero(grad, as_tuple=True)
                 gc = grad[nz] * conf[nz]
                 d0, d1 = _dsm_backward(f0, f1, ctx.temperature, ctx.buffers, nz[0], nz[1], nz[2], gc)
-                return d0, d1, None, None, None
-            import warnings
-            warnings.warn("conf_matrix gradient is dense: falling back to the torch formula (three [N,L,S] temporaries)")
+            else:
+                d0, d1 = _dsm_backward_dense(f0, f1, ctx.temperature, ctx.buffers, grad)
+            return d0, d1, None, None, None
+        import warnings
+        warnings.warn("attach_conf_matrix_grad without the forward call's buffers: the torch formula (three [N,L,S] temporaries)")
         k = 1.0 / (f0.shape[-1] * ctx.temperature)
         sim = torch.bmm(f0.float(), f1.float().transpose(1, 2)) * k
         gc = grad * conf

@@ -455,6 +455,14 @@ int fm_dual_softmax_backward(const float* feat0, const float* feat1, int N, int 
                              const float* nm_r, const float* sum_r, int pitch_r, const float* nm_c, const float* sum_c,
                              int pitch_c, const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids, const float* gc,
                              int K, void* workspace, size_t workspace_bytes, float* d_feat0, float* d_feat1, void* stream);
+/* The same for a DENSE dL/dconf: G [dev] float32 [N, L, S] (the reference's loss terms over ALL negatives, losses/loss.py:
+ * 44-50, 62-65, hand back a gradient for every entry).  conf is recomputed tile by tile from exact float32 dot products
+ * and the statistics; three tiled sweeps (the row / column sums of G conf, then the two gradients) read G three times and
+ * write nothing of its size: same workspace as fm_dual_softmax_backward, no [N, L, S] temporary. */
+int fm_dual_softmax_backward_dense(const float* feat0, const float* feat1, int N, int L, int S, int C, float temperature,
+                                   const float* nm_r, const float* sum_r, int pitch_r, const float* nm_c, const float* sum_c,
+                                   int pitch_c, const float* G, void* workspace, size_t workspace_bytes, float* d_feat0,
+                                   float* d_feat1, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1127,6 +1127,90 @@ def test_conf_matrix_carries_the_dual_softmax_gradient():
         assert scale > 0 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
 
 
+def _dense_losses(gt_mask):
+    """the reference's coarse losses over ALL entries (losses/loss.py:44-50 cross entropy, :62-65 focal with dense
+    supervision, alpha 0.25, gamma 2, c_pos_w = c_neg_w = 1)"""
+    def focal(conf):
+        c = torch.clamp(conf, 1e-6, 1 - 1e-6)
+        lp = -0.25 * torch.pow(1 - c[gt_mask], 2.0) * c[gt_mask].log()
+        ln = -0.25 * torch.pow(c[~gt_mask], 2.0) * (1 - c[~gt_mask]).log()
+        return lp.mean() + ln.mean()
+
+    def xent(conf):
+        c = torch.clamp(conf, 1e-6, 1 - 1e-6)
+        return (-torch.log(c[gt_mask])).mean() + (-torch.log(1 - c[~gt_mask])).mean()
+    return {"focal": focal, "cross_entropy": xent}
+
+
+@pytest.mark.parametrize("loss", ["focal", "cross_entropy", "weighted_sum"])
+@pytest.mark.parametrize("hw0,hw1,c", [((12, 16), (12, 16), 64), ((15, 17), (11, 13), 128)])
+def test_dense_conf_matrix_gradient_goes_through_the_hip_backward(hw0, hw1, c, loss):
+    """A loss that reads EVERY entry of data['conf_matrix'] - the reference's terms over all negatives (losses/loss.py:
+    44-50, 62-65; their clamp(conf, 1e-6, ..) zeroes the gradient of most entries, so what autograd hands back is sparse or
+    dense depending on the data) and a plain weighted sum (dL/dconf dense for certain: fm_dual_softmax_backward_dense, three
+    tiled sweeps, conf recomputed from exact dot products) - must give the descriptors the gradient float64 autograd gives
+    through the reference's own expression (coarse_matching_new.py:64-68).  Ragged shapes (L != S, neither a multiple of
+    32); the torch formula (three [N, L, S] temporaries, a warning) must not run."""
+    l, s_ = hw0[0] * hw0[1], hw1[0] * hw1[1]
+    f0, f1 = synth.coarse_descriptors(19, 2, max(l, s_), c, "borderline")
+    f0, f1 = np.ascontiguousarray(f0[:, :l]), np.ascontiguousarray(f1[:, :s_])
+    a0 = torch.as_tensor(f0, device=DEV).requires_grad_(True)
+    a1 = torch.as_tensor(f1, device=DEV).requires_grad_(True)
+    out = ops.coarse_match(a0.detach(), a1.detach(), hw0, hw1, 8.0, conf_matrix=True)
+    # supervision at entries the matcher itself found (conf well inside the losses' clamp) + a few random ones
+    gt_mask = torch.zeros(2, l, s_, dtype=torch.bool, device=DEV)
+    gt_mask[out['b_ids'][::3], out['i_ids'][::3], out['j_ids'][::3]] = True
+    g = torch.Generator(device=DEV).manual_seed(5)
+    wts = torch.randn(2, l, s_, device=DEV, generator=g)
+    fn = _dense_losses(gt_mask).get(loss, lambda conf: (conf * wts.to(conf.dtype)).sum())
+    conf = ops.attach_conf_matrix_grad(a0, a1, out['conf_matrix'], 0.1, out['_coarse_buffers'])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")            # the torch fallback warns: it must not run
+        fn(conf).backward()
+    b0 = torch.as_tensor(f0, device=DEV, dtype=torch.float64).requires_grad_(True)
+    b1 = torch.as_tensor(f1, device=DEV, dtype=torch.float64).requires_grad_(True)
+    sim = torch.einsum("nlc,nsc->nls", b0 / c ** .5, b1 / c ** .5) / 0.1
+    fn(torch.softmax(sim, 1) * torch.softmax(sim, 2)).backward()
+    for got, ref in ((a0.grad, b0.grad), (a1.grad, b1.grad)):
+        scale = ref.abs().max().item()
+        assert scale > 1e-6 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
+
+
+def test_dense_conf_matrix_gradient_at_cfg2_size_without_an_LxS_temporary():
+    """The same at the metric's size - one 640x480 pair, L = S = 4800, C = 256 - with an assert on the allocator: the
+    backward of a dense dL/dconf [1, 4800, 4800] (92 MB) may not allocate anything of that size (the torch formula it
+    replaces holds three such temporaries); against float64 autograd."""
+    cfg = synth.CONFIGS["cfg2"]
+    sh = synth.config_shapes(cfg)
+    l, c = sh['l'], cfg['c']
+    hw_c = (sh['hc'], sh['wc'])
+    f0, f1 = synth.coarse_descriptors(23, 1, l, c, "borderline")
+    a0 = torch.as_tensor(f0, device=DEV).requires_grad_(True)
+    a1 = torch.as_tensor(f1, device=DEV).requires_grad_(True)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    G = torch.randn(1, l, l, device=DEV, generator=g)
+    # float64 autograd first (its temporaries are freed before the measurement)
+    b0 = torch.as_tensor(f0, device=DEV, dtype=torch.float64).requires_grad_(True)
+    b1 = torch.as_tensor(f1, device=DEV, dtype=torch.float64).requires_grad_(True)
+    sim = torch.einsum("nlc,nsc->nls", b0 / c ** .5, b1 / c ** .5) / 0.1
+    ((torch.softmax(sim, 1) * torch.softmax(sim, 2)) * G.double()).sum().backward()
+    del sim
+    out = ops.coarse_match(a0.detach(), a1.detach(), hw_c, hw_c, 8.0, conf_matrix=True)
+    conf = ops.attach_conf_matrix_grad(a0, a1, out['conf_matrix'], 0.1, out['_coarse_buffers'])
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    d0, d1 = torch.autograd.grad(conf, (a0, a1), grad_outputs=G)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 0.5 * G.numel() * 4, f"backward allocated {peak / 1e6:.0f} MB next to a {G.numel() * 4 / 1e6:.0f} MB gradient"
+    for got, ref in ((d0, b0.grad), (d1, b1.grad)):
+        scale = ref.abs().max().item()
+        assert scale > 0 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
+
+
 @pytest.mark.parametrize("dist", ["borderline", "peaky"])
 def test_dual_softmax_at_supervised_entries_and_its_backward_without_an_LxS_array(dist):
     """SURVEY 8(f) row 3 at the metric's size (640x480: L = S = 4800, C = 256): the reference's coarse loss with sparse
