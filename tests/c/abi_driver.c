@@ -45,6 +45,8 @@ static __typeof__(fm_coarse_softmax_stats)* p_fm_coarse_softmax_stats;
 static __typeof__(fm_dual_softmax_conf_at)* p_fm_dual_softmax_conf_at;
 static __typeof__(fm_dual_softmax_backward)* p_fm_dual_softmax_backward;
 static __typeof__(fm_dual_softmax_backward_workspace_bytes)* p_fm_dual_softmax_backward_workspace_bytes;
+static __typeof__(fm_dual_softmax_backward_dense)* p_fm_dual_softmax_backward_dense;
+static __typeof__(fm_gather_windows_dtype)* p_fm_gather_windows_dtype;
 static __typeof__(fm_fine_maps_scratch_bytes_dtype)* p_fm_fine_maps_scratch_bytes_dtype;
 static __typeof__(fm_fine_maps_scratch_bytes)* p_fm_fine_maps_scratch_bytes;
 static __typeof__(fm_debug_reset_counters)* p_fm_debug_reset_counters;
@@ -82,6 +84,7 @@ int main(int argc, char** argv) {
   RESOLVE(fm_coarse_transformer);
   RESOLVE(fm_coarse_match_maps); RESOLVE(fm_read_count_info); RESOLVE(fm_debug_launch_flat); RESOLVE(fm_fine_transformer_start);
   RESOLVE(fm_coarse_match_auto); RESOLVE(fm_coarse_workspace_bytes_auto);
+  RESOLVE(fm_dual_softmax_backward_dense); RESOLVE(fm_gather_windows_dtype);
 
   EXPECT(p_fm_version(), FM_VERSION);
   for (int s = FM_E_INTERNAL; s <= FM_OK; ++s) EXPECT(p_fm_strerror(s) != NULL && p_fm_strerror(s)[0] != 0, 1);
@@ -223,6 +226,9 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_gather_windows(NULL, 1, 64, 8, 8, 0, 7, 4, 2, 2, NULL, NULL, NULL, 0, NULL, NULL), FM_OK);          /* M == 0 */
   EXPECT(p_fm_gather_windows(NULL, 1, 64, 8, 8, 0, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_NULL);
   EXPECT(p_fm_gather_windows(f, 1, 64, 8, 8, 0, 7, 4, 2, 2, ids, ids, NULL, -4, f, NULL), FM_E_SHAPE);
+  EXPECT(p_fm_gather_windows_dtype(f, 5, 1, 64, 8, 8, 0, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_UNSUPPORTED);   /* element type */
+  EXPECT(p_fm_gather_windows_dtype(NULL, FM_F16, 1, 64, 8, 8, 0, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_NULL);
+  EXPECT(p_fm_gather_windows_dtype(f, FM_BF16, 1, 64, 8, 8, 1, 7, 4, 2, 2, ids, ids, NULL, 0, f, NULL), FM_OK);         /* M == 0 */
   EXPECT(p_fm_gather_windows(f, 1, 64, 0, 8, 0, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_SHAPE);
   EXPECT(p_fm_gather_windows(f, 1, 64, 8, 8, 2, 7, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_UNSUPPORTED);      /* layout */
   EXPECT(p_fm_gather_windows(f, 1, 64, 8, 8, 0, 17, 4, 2, 2, ids, ids, NULL, 4, f, NULL), FM_E_UNSUPPORTED);     /* W > 15 */
@@ -277,6 +283,11 @@ int main(int argc, char** argv) {
     EXPECT((int)p_fm_dual_softmax_backward_workspace_bytes(0, 64, 64, 64), 0);
     EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, ids, ids, ids, f, 4, (void*)f, 16, f, f, NULL), FM_E_WORKSPACE);
     EXPECT(p_fm_dual_softmax_backward(f, f, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, NULL, ids, ids, f, 4, (void*)f, 1u << 30, f, f, NULL), FM_E_NULL);
+    /* the dense-gradient form: same workspace, the same refusals */
+    EXPECT(p_fm_dual_softmax_backward_dense(f, f, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, f, (void*)f, 16, f, f, NULL), FM_E_WORKSPACE);
+    EXPECT(p_fm_dual_softmax_backward_dense(f, f, 1, 64, 64, 64, 0.1f, f, f, 256, f, f, 64, NULL, (void*)f, 1u << 30, f, f, NULL), FM_E_NULL);
+    EXPECT(p_fm_dual_softmax_backward_dense(f, f, 1, 64, 64, 64, 0.1f, f, f, 32, f, f, 64, f, (void*)f, 1u << 30, f, f, NULL), FM_E_SHAPE);
+    EXPECT(p_fm_dual_softmax_backward_dense(f, f, 1, 64, 64, 62, 0.1f, f, f, 256, f, f, 64, f, (void*)f, 1u << 30, f, f, NULL), FM_E_UNSUPPORTED);
   }
   /* element type of the maps: an unknown one is refused, half-precision NCHW maps need scratch for both copies */
   EXPECT(p_fm_fine_match_maps_dtype(f, f, 7, 1, 1, 64, 32, 32, 32, 32, 7, 4, 2, 8, 8, ids, ids, ids, NULL, 4, f, f, f, f, 2.f, NULL, f, f, NULL), FM_E_UNSUPPORTED);
