@@ -98,22 +98,16 @@ class Pair:
             self.scratch = torch.empty(self.ff1.numel() * 4, dtype=torch.uint8, device=dev)
         self.last = None
         self.gather = "cells"    # cells | list (see ops.gather_windows)
-        # rows without a peak need the dense sum kernel (FM_MODE_DENSE): all of them in 'borderline' data, the cells whose
-        # partner is a textureless cell in 'mixed' data (the textureless cells themselves - near-zero descriptors - are
-        # certified dead by the sparse sum kernel and cost nothing); 'peaky' takes the common 4 launches
-        self.dense = dist != "peaky"
-        # ... and in 'mixed' data those peakless rows sit next to peaked ones: more candidates than the default 8 slots.  The
-        # general answer is the exact screening pass (FM_MODE_EXACT_SCREENING: a second full sweep, k_dense<C, RESCREEN>, 37 us);
-        # the caller that knows its data gets the same matches with 16 candidate slots and the int8 step from the images'
-        # true maxima (FM_MODE_EXACT_STEP: margins 1.5x narrower, so ~7 instead of ~20 entries of a peakless row pass the
-        # dense kernel's candidate test): 13.8 k against 11.3 k pairs/s (tools/time_flat.py; a row that still
-        # overflows reports FM_E_CANDIDATES - nothing is dropped silently)
-        self.exact = False
-        # ... and the caller that knows ALL its samples are like that (what FM_DEV_ALL_DENSE tells ops.coarse_match's mode
-        # memory after the first call) passes the FM_MODE_FLAT hint: no screening sweep, planes from the prep kernel
-        self.flat = dist != "peaky"
-        self.slots = 16 if dist == "mixed" else None      # candidate slots per row / column (None: fm_default_cand_slots(thr))
-        self.exact_step = dist == "mixed"                 # FM_MODE_EXACT_STEP: the int8 step from the images' true maxima
+        # Which launches the asynchronous coarse call enqueues is NOT hand-picked per distribution: the library's own
+        # one-call entry point (fm_coarse_match_auto through ops.coarse_match) serves this input set twice - the first call
+        # finds out what the data needs (flat similarity: the dense sum kernel; rows without a partner next to peaked ones:
+        # 16 candidate slots + the exact int8 step), the second starts from the hint word the first one left and reports
+        # whether EVERY sample went to the dense kernel (then FM_MODE_FLAT: no screening sweep) - and the step replays the
+        # mode that hint names.  'peaky' data: hint 0, the common path's launches.
+        self.hint = learnt_hint(self)
+        d = ops.HintMemory.decode(self.hint)
+        self.dense, self.exact, self.flat, self.exact_step = d['dense'], d['exact'], d['flat'], d['step']
+        self.slots = d['slots'] or None                   # candidate slots per row / column (None: fm_default_cand_slots(thr))
         # NCHW float32 maps on the maps path: image 1's channels-last copy rides in the assignment kernel's launch
         # (fm_coarse_match_maps) instead of being fm_fine_match_maps' first launch
         self.fuse_maps = layout == "nchw" and fine_path == "maps"
@@ -168,6 +162,29 @@ class Pair:
     def fine(self, buf):
         return ops.fine_match(self.win0, self.win1, self.mix0, self.mix1, buf.mkpts0_c, buf.mkpts1_c,
                               self.hw_i[0] / self.hw_f[0], count=buf.count)
+
+
+_HINTS = {}      # (workload shape, distribution) -> hint word of fm_coarse_match_auto
+
+
+def learnt_hint(pair):
+    """The hint word fm_coarse_match_auto leaves for this kind of data (two calls: learn, then confirm from the hint);
+    learnt once per (shape, distribution) and process."""
+    key = (pair.n, pair.l, pair.c, pair.dist)
+    if key not in _HINTS:
+        mem = ops.MODE_MEMORY.snapshot()
+        ops.MODE_MEMORY.clear()
+        h = 0
+        for _ in range(3):
+            out = ops.coarse_match(pair.f0, pair.f1, pair.hw_c, pair.hw_c, pair.hw_i[0] / pair.hw_c[0])
+            h = out['_coarse_buffers'].hint
+            del out
+        ops.MODE_MEMORY.clear()
+        for k, v in mem.items():
+            ops.MODE_MEMORY.finish(k, v['hint'])
+        torch.cuda.synchronize()
+        _HINTS[key] = h
+    return _HINTS[key]
 
 
 def _events(fn, iters=10, before=None, group=6):
@@ -1065,8 +1082,8 @@ def extras(a, wl, dev, streams, flops):
             rate, rate_nohint = max(rate, r1), max(rate_nohint, r2)
         return {"value": round(rate, 2), "unit": "image-pairs/s", "verified": (ver["ok"] and ver2["ok"]) if ver and ver2 else None,
                 "verification": ver, "matches_per_pair": round(m_pp, 1),
-                "mode": "FM_MODE_DENSE | FM_MODE_FLAT (the hint a caller - or ops.coarse_match's mode memory after its first "
-                        "call, from FM_DEV_ALL_DENSE - passes for data like this: no screening sweep, planes from the prep kernel)",
+                "mode": "what fm_coarse_match_auto's hint word names for this data after two calls on it (bench.learnt_hint: no "
+                        "mode is hand-passed): " + str(ops.HintMemory.decode(_HINTS.get((1, synth.config_shapes(wl)["l"], wl["c"], dist), 0))),
                 "value_without_flat_hint": round(rate_nohint, 2),
                 "corr_avg_ms": round(tcb, 5), "frac": round(flops / (tcb * 1e-3) / 1e12 / PEAK_I8_DENSE_TOPS, 4),
                 "frac_of_f16_peak": round(flops / (tcb * 1e-3) / 1e12 / PEAK_F16_DENSE_TFLOPS, 4),
