@@ -960,7 +960,8 @@ def test_matcher_tail_against_reference_fixture(name, meta):
     same seeded feature maps and weights: two 128x128 pairs, and ONE 640x480 PAIR - the size bench.py times
     forward_features at (L = S = 4800, 1624 matches with conf spread over (0.2, 1]).  The context layers are
     float32-equivalent products in another summation order than the fixture's, which moves the descriptors by ~1e-6
-    relative: the conf tolerance of this chain test is 1e-4 (guard band likewise), fine keypoints 2e-3 px."""
+    relative: the conf tolerance of this chain test is 4e-5 (guard band likewise; measured 1.3e-5 / 2.0e-5), fine
+    keypoints 5e-4 px (measured 6e-5)."""
     from featurematching_amd.matcher import Matcher
     g = load_golden(name)
     inp = net_tail_inputs(meta)
@@ -980,16 +981,16 @@ def test_matcher_tail_against_reference_fixture(name, meta):
     got = _np({k: data[k] for k in ('b_ids', 'i_ids', 'j_ids', 'mconf', 'mkpts0_c', 'mkpts1_c')})
     only_g, only_r, err = compare_match_sets(got, g)
     FLIPS.append((f"test_matcher_tail_against_reference_fixture[{name}]", len(only_g) + len(only_r), len(g['i_ids']), err))
-    assert all(abs(v - 0.2) < 1e-4 for _, v in only_g + only_r), (only_g, only_r)
-    assert err <= 1e-4, err
+    assert all(abs(v - 0.2) < 4e-5 for _, v in only_g + only_r), (only_g, only_r)
+    assert err <= 4e-5, err
     gk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(got['b_ids'], got['i_ids'], got['j_ids']))}
     rk = {(int(b), int(i), int(j)): n for n, (b, i, j) in enumerate(zip(g['b_ids'], g['i_ids'], g['j_ids']))}
     common = [k for k in gk if k in rk]
     gi, ri = np.array([gk[k] for k in common]), np.array([rk[k] for k in common])
     assert len(common) >= len(rk) - 2 and len(rk) > 80
     assert np.array_equal(got['mkpts0_c'][gi], g['mkpts0_c'][ri])
-    assert np.abs(data['mkpts0_f'].cpu().numpy()[gi, :2] - g['mkpts0_f'][ri, :2]).max() <= 2e-3
-    assert np.abs(data['mkpts1_f'].cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= 2e-3
+    assert np.abs(data['mkpts0_f'].cpu().numpy()[gi, :2] - g['mkpts0_f'][ri, :2]).max() <= 5e-4
+    assert np.abs(data['mkpts1_f'].cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= 5e-4
 
 
 def test_matcher_tail_redoes_the_fine_half_when_the_fine_kernel_reports_its_range():
