@@ -8,7 +8,7 @@ match - and the COARSE layers (d_model 256, 8 heads, any self / cross sequence, 
 as fm_coarse_transformer - three launches per encoder layer, hi/lo-split float16 products on the matrix cores (22
 significant bits).  That holds under the reference's own inference call, `matcher.eval()(data)` with grad mode on
 (demo/demo.py:105-108).  The torch ops below are the trainable definition: training mode, inputs that require grad,
-other configurations, CPU tensors.  Parameter names and shapes equal the reference's, so a reference state dict
+other configurations (the reference's 'full' attention among them), padding masks, CPU tensors.  Parameter names and shapes equal the reference's, so a reference state dict
 loads unchanged:
 
     layers.<k>.{q_proj,k_proj,v_proj,merge}.weight [d,d]   layers.<k>.mlp.{0,2}.weight [2d,2d] / [d,2d]
@@ -40,11 +40,26 @@ def linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: flo
     return torch.einsum("nlhd,nhdv,nlh->nlhv", q, kv, z) * s
 
 
-class EncoderLayer(nn.Module):
-    """x <- x + LN2(MLP([x, LN1(merge(attn(q(x), k(src), v(src))))]))   (transformer.py:34-57)"""
+def full_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_mask=None, kv_mask=None) -> torch.Tensor:
+    """Scaled dot-product attention, the reference's other option (attentions.py:54-79, no dropout: its default).
+    q [N,L,H,D], k,v [N,S,H,D] -> [N,L,H,D]: softmax over the source positions of q.k / sqrt(D); with a kv_mask the
+    pairs outside q_mask x kv_mask are filled with -inf first (:71-72: a fully padded query row comes out as NaN there
+    too).  Materialises the [N,L,S,H] scores as the reference does: an option for short sequences."""
+    qk = torch.einsum("nlhd,nshd->nlsh", q, k)
+    if kv_mask is not None:
+        qm = torch.ones(q.shape[:2], dtype=torch.bool, device=q.device) if q_mask is None else q_mask.bool()
+        qk = qk.masked_fill(~(qm[:, :, None, None] & kv_mask.bool()[:, None, :, None]), float('-inf'))
+    a = torch.softmax(qk / q.shape[3] ** .5, dim=2)
+    return torch.einsum("nlsh,nshd->nlhd", a, v)
 
-    def __init__(self, d_model: int, nhead: int):
+
+class EncoderLayer(nn.Module):
+    """x <- x + LN2(MLP([x, LN1(merge(attn(q(x), k(src), v(src))))]))   (transformer.py:34-57); attention = 'linear'
+    (the default) or 'full' (:22)"""
+
+    def __init__(self, d_model: int, nhead: int, attention: str = 'linear'):
         super().__init__()
+        self.attention = attention
         self.nhead, self.dim = nhead, d_model // nhead
         self.q_proj = nn.Linear(d_model, d_model, bias=False)
         self.k_proj = nn.Linear(d_model, d_model, bias=False)
@@ -58,8 +73,9 @@ class EncoderLayer(nn.Module):
     def forward(self, x: torch.Tensor, source: torch.Tensor, x_mask=None, source_mask=None) -> torch.Tensor:
         n, l, _ = x.shape
         heads = lambda t: t.view(n, -1, self.nhead, self.dim)
-        msg = linear_attention(heads(self.q_proj(x)), heads(self.k_proj(source)), heads(self.v_proj(source)),
-                               q_mask=x_mask, kv_mask=source_mask)
+        attn = linear_attention if self.attention == 'linear' else full_attention
+        msg = attn(heads(self.q_proj(x)), heads(self.k_proj(source)), heads(self.v_proj(source)),
+                   q_mask=x_mask, kv_mask=source_mask)
         msg = self.norm1(self.merge(msg.reshape(n, l, -1)))
         msg = self.norm2(self.mlp(torch.cat([x, msg], dim=2)))
         return x + msg
@@ -87,10 +103,11 @@ class LocalFeatureTransformer(nn.Module):
         self.use_hip, self.check_range, self.inference_only = use_hip, check_range, inference_only
         self.range_fallbacks = 0
         self.last_status = None
-        if config.get('attention', 'linear') != 'linear':
-            raise NotImplementedError("only the reference's default linear attention is provided")
+        self.attention = config.get('attention', 'linear')
+        if self.attention not in ('linear', 'full'):
+            raise ValueError(f"attention must be 'linear' or 'full' (transformer.py:22), got {self.attention!r}")
         self.d_model, self.layer_names = config['d_model'], list(config['layer_names'])
-        self.layers = nn.ModuleList(EncoderLayer(config['d_model'], config['nhead']) for _ in self.layer_names)
+        self.layers = nn.ModuleList(EncoderLayer(config['d_model'], config['nhead'], self.attention) for _ in self.layer_names)
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -112,6 +129,8 @@ class LocalFeatureTransformer(nn.Module):
                 import warnings
                 warnings.warn("LocalFeatureTransformer: eval-mode HIP kernels return tensors without a graph through the "
                               "layers' parameters; pass inference_only=False (or call .train()) to fine-tune them")
+        if self.attention != 'linear':               # 'full' attention (attentions.py:54-79): the torch layers
+            return None
         if not self.use_hip or self.training or wants_grad or not feat0.is_cuda or feat0.dtype != torch.float32 \
                 or feat1.dtype != torch.float32 or self.layers[0].nhead != 8 or feat0.shape[0] != feat1.shape[0]:
             return None

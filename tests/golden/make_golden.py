@@ -407,6 +407,25 @@ def kat_cases_round2():
     np.savez_compressed(os.path.join(HERE, "kats_r2.npz"), **cases)
 
 
+def full_attention_case(name="tf_full_small"):
+    """The reference's LocalFeatureTransformer with attention='full' (attentions.py:54-79), with and without padding
+    masks, on the inputs and weights of tf_masked_small (d_model 64, 8 heads, ['self', 'cross'], N = 2, L = 40, S = 36)."""
+    from network.module.transformer import LocalFeatureTransformer
+    seed, n, l, s_, d = 41, 2, 40, 36, 64
+    tf = LocalFeatureTransformer(dict(d_model=d, nhead=8, layer_names=['self', 'cross'], attention='full')).eval()
+    tf.load_state_dict({k: torch.as_tensor(v) for k, v in synth.transformer_weights(seed, d, 2).items()})
+    x0 = torch.as_tensor(synth.normal(seed, 1, (n, l, d)))
+    x1 = torch.as_tensor(synth.normal(seed, 2, (n, s_, d)))
+    m0 = torch.ones(n, l, dtype=torch.bool); m0[0, 33:] = False; m0[1, 25:] = False
+    m1 = torch.ones(n, s_, dtype=torch.bool); m1[0, 30:] = False
+    with torch.no_grad():
+        y0, y1 = tf(x0, x1)
+        z0, z1 = tf(x0, x1, m0, m1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), out0=y0.numpy(), out1=y1.numpy(), mout0=z0.numpy(), mout1=z1.numpy(),
+                        mask0=m0.numpy(), mask1=m1.numpy(), meta=np.array([seed, n, l, s_, d], np.int64))
+    print(f"{name}: out0 {tuple(y0.shape)} |max| {float(y0.abs().max()):.3f}, masked rows NaN: {bool(torch.isnan(z0).any())}")
+
+
 def masked_transformer_case(name="tf_masked_small"):
     """The reference's LocalFeatureTransformer WITH padding masks (network/module/transformer.py:78-96,
     attentions.py:35-40) on a small seeded problem: d_model 64, 8 heads, ['self', 'cross'], N = 2, L = 40, S = 36, the
@@ -444,8 +463,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "net_tail":
         net_tail_case()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "r5":     # the fixture added in round 5 only
+    if len(sys.argv) > 1 and sys.argv[1] == "r5":     # the fixtures added in round 5 only
         net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)
+        full_attention_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epi":
         epipolar_case()
@@ -478,3 +498,4 @@ if __name__ == "__main__":
     full_case("l9600_borderline", "l9600", "borderline", with_fine=False)
     # round 5: the a8 chain (net.py:66-83) at the size the bench times it at
     net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)
+    full_attention_case()
