@@ -78,6 +78,7 @@ SIGNATURES = {
     "fm_coarse_tf_workspace_bytes": (_i, [_i, _i, _i, C.POINTER(C.c_size_t)]),
     "fm_coarse_tf_pack_weights": (_i, [_p, _i, _p, _p]),
     "fm_coarse_transformer": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, C.c_size_t, _p, _p, _p]),
+    "fm_coarse_transformer_masked": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, C.c_size_t, _p, _p, _p]),
     "fm_fine_tf_packed_bytes": (C.c_size_t, []),
     "fm_fine_tf_pack_weights": (_i, [_p, _p, _p, _p]),
     "fm_fine_transformer": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p]),

@@ -73,6 +73,7 @@ struct Seg {
   int L;                 // tokens per sample
   int tiles;             // ceil(L / 32)
   float src_len;         // S of the attention: the source's token count (values / S ... * S)
+  const unsigned char* mask;   // optional padding mask [N, L] of the tokens this launch reads (1 = a real token; attentions.py:35-40)
 };
 struct TfArgs {
   Seg seg[2];
@@ -358,7 +359,9 @@ __global__ __launch_bounds__(256) void k_ctx_kv(TfArgs a) {
   const int b = wg / sg.tiles, tile = wg - b * sg.tiles, tok0 = tile * kTok;
   load_tile(sg.x + (size_t)b * sg.L * kD, tok0, sg.L, xh, kPlane, red8, xinv, xinv + 32, 0.f, tid);
   const float* const hdr = reinterpret_cast<const float*>(a.w + kFragEnd);
-  const bool tok_ok = tok0 + r < sg.L;
+  // padded source tokens (kv_mask, attentions.py:38-40): K = 0 removes their K V^T term and their share of Ksum; their
+  // V needs no mask of its own then
+  const bool tok_ok = tok0 + r < sg.L && (!sg.mask || sg.mask[(size_t)b * sg.L + tok0 + r] != 0);
   const float S = sg.src_len, xi = xinv[r];
   // this wave: heads 2 wv, 2 wv + 1 = output row blocks 2 wv, 2 wv + 1 of both projections, in ONE pass over the source
   // planes (the fragments of Wv follow those of Wk: row blocks 8 .. 15 of the same region)
@@ -524,6 +527,8 @@ __global__ __launch_bounds__(NW * 64) void k_ctx_layer(TfArgs a) {
     gemm_stage<NBQ, 16, kXmLo>(a.w + kFragQ, NBQ * wv, xm, acc, lane);
     CTF_STAMP(1);
     const float f = hdr[kHdrWinv + 0] * xi;
+    // padded query tokens (q_mask, attentions.py:35-36): Q = 0, hence a zero message (0 . KV / (0 + eps))
+    const bool q_ok = !sg.mask || tok0 + r >= sg.L || sg.mask[(size_t)b * sg.L + tok0 + r] != 0;
 #pragma unroll
     for (int i = 0; i < NBQ; ++i) {
       f32x4* p = reinterpret_cast<f32x4*>(qf) + (size_t)(4 * (NBQ * wv + i)) * 64 + r * 2 + h;
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void k_ctx_layer(TfArgs a) {
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = elu1(acc[i][4 * q + e] * f);
+        for (int e = 0; e < 4; ++e) v[e] = q_ok ? elu1(acc[i][4 * q + e] * f) : 0.f;
         p[q * 64] = v;
       }
     }
@@ -714,6 +719,16 @@ extern "C" int fm_coarse_tf_pack_weights(const float* const* const* layers, int 
 extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, int S, int C, int nhead,
                                      const int* layer_kinds, int n_layers, const void* packed, void* workspace,
                                      size_t workspace_bytes, float* out0, float* out1, void* stream) {
+  return fm_coarse_transformer_masked(feat0, feat1, nullptr, nullptr, N, L, S, C, nhead, layer_kinds, n_layers, packed, workspace,
+                                      workspace_bytes, out0, out1, stream);
+}
+
+// The same with the reference's padding masks (transformer.py:78-96 mask0 / mask1, attentions.py:35-40): mask0 [N, L],
+// mask1 [N, S] bytes (1 = a real token, 0 = padding; torch.bool storage), either may be NULL.
+extern "C" int fm_coarse_transformer_masked(const float* feat0, const float* feat1, const unsigned char* mask0,
+                                            const unsigned char* mask1, int N, int L, int S, int C, int nhead,
+                                            const int* layer_kinds, int n_layers, const void* packed, void* workspace,
+                                            size_t workspace_bytes, float* out0, float* out1, void* stream) {
   if (!feat0 || !feat1 || !layer_kinds || !packed || !workspace || !out0 || !out1) return FM_E_NULL;
   if (N <= 0 || L <= 0 || S <= 0) return FM_E_SHAPE;
   if (C != kD || nhead != kH || n_layers <= 0 || n_layers > kMaxLayers) return FM_E_UNSUPPORTED;
@@ -756,6 +771,7 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
 #endif
   const float* cur[2] = {feat0, feat1};
   float* out[2] = {out0, out1};
+  const unsigned char* masks[2] = {mask0, mask1};
 
   // one encoder layer on `nseg` (image, source) pairs: x[img[s]] <- layer(x[img[s]], x[src[s]])
   auto run = [&](const char* w, int nseg, const int* img, const int* src) -> hipError_t {
@@ -771,6 +787,7 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
       Seg& g = a.seg[s];
       g.x = cur[src[s]]; g.out = nullptr; g.part = part[src[s]]; g.kv = kv[src[s]];
       g.L = len[src[s]]; g.tiles = tl[src[s]]; g.src_len = (float)len[src[s]];
+      g.mask = masks[src[s]];
       tiles_kv += N * g.tiles;
     }
     a.tiles0 = N * a.seg[0].tiles;
@@ -782,6 +799,7 @@ extern "C" int fm_coarse_transformer(const float* feat0, const float* feat1, int
       Seg& g = a.seg[s];
       g.x = cur[img[s]]; g.out = out[img[s]]; g.part = nullptr; g.kv = kv[src[s]];
       g.L = len[img[s]]; g.tiles = tl[img[s]]; g.src_len = (float)len[src[s]];
+      g.mask = masks[img[s]];
       tiles_x += N * g.tiles;
     }
     a.tiles0 = N * a.seg[0].tiles;

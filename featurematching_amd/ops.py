@@ -713,9 +713,11 @@ def pack_coarse_transformer(state_dict: dict, n_layers: int, device) -> torch.Te
 
 
 def coarse_transformer(feat0: torch.Tensor, feat1: torch.Tensor, packed: torch.Tensor, layer_names, nhead: int = 8,
-                       workspace: Optional[torch.Tensor] = None):
+                       workspace: Optional[torch.Tensor] = None, mask0: Optional[torch.Tensor] = None,
+                       mask1: Optional[torch.Tensor] = None):
     """The coarse context layers (network/net.py:74) on feat0 [N,L,256], feat1 [N,S,256]; layer_names as in the
-    reference's config (['self', 'cross', ...])."""
+    reference's config (['self', 'cross', ...]).  mask0 [N,L] / mask1 [N,S]: the reference's optional padding masks
+    (transformer.py:78-96; True = a real token), served by the same kernels (fm_coarse_transformer_masked)."""
     lib = _lib.load()
     feat0, feat1 = _f32c(feat0, "feat0"), _f32c(feat1, "feat1")
     n, l, c = feat0.shape
@@ -728,9 +730,18 @@ def coarse_transformer(feat0: torch.Tensor, feat1: torch.Tensor, packed: torch.T
     if workspace is None or workspace.numel() < nbytes.value:
         workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=feat0.device)
     out0, out1 = torch.empty_like(feat0), torch.empty_like(feat1)
-    _lib.check(lib.fm_coarse_transformer(_ptr(feat0), _ptr(feat1), n, l, s, c, nhead, kinds, len(layer_names),
-                                         _ptr(packed), _ptr(workspace), workspace.numel(), _ptr(out0), _ptr(out1),
-                                         _stream(feat0.device)), "fm_coarse_transformer")
+
+    def as_bytes(m, length, name):
+        if m is None:
+            return None
+        if tuple(m.shape) != (n, length):
+            raise ValueError(f"{name} must be [{n}, {length}], got {tuple(m.shape)}")
+        return (m != 0).to(device=feat0.device, dtype=torch.uint8).contiguous()
+    m0, m1 = as_bytes(mask0, l, "mask0"), as_bytes(mask1, s, "mask1")
+    _lib.check(lib.fm_coarse_transformer_masked(_ptr(feat0), _ptr(feat1), _ptr(m0), _ptr(m1), n, l, s, c, nhead, kinds,
+                                                len(layer_names), _ptr(packed), _ptr(workspace), workspace.numel(),
+                                                _ptr(out0), _ptr(out1), _stream(feat0.device)), "fm_coarse_transformer_masked")
+    out0._keep = (m0, m1)
     return out0, out1
 
 

@@ -159,17 +159,17 @@ class LocalFeatureTransformer(nn.Module):
         """network/module/transformer.py:78 (`net.forward` passes mask0 = mask1 = None, net.py:73-74)"""
         assert feat0.shape[2] == self.d_model, "the feature number of src and transformer must be equal"
         self._pending_check = None
-        if mask0 is not None or mask1 is not None:
-            # padding masks (transformer.py:89-95, attentions.py:35-40): `net.forward` passes None (net.py:73-74); a
-            # caller that pads its batches gets the torch layers
-            return self._torch_layers(feat0, feat1, mask0, mask1)
         kind = self._hip_kind(feat0, feat1)
+        if (mask0 is not None or mask1 is not None) and kind != 'coarse':
+            # padding masks (transformer.py:89-95, attentions.py:35-40; `net.forward` passes None, net.py:73-74): the coarse
+            # kernels take them, every other configuration gets the torch layers
+            return self._torch_layers(feat0, feat1, mask0, mask1)
         if kind is not None:
             from . import _lib, ops
             with torch.no_grad():
                 packed = self._packed(feat0.device, kind)
                 if kind == 'coarse':
-                    return ops.coarse_transformer(feat0, feat1, packed, self.layer_names)
+                    return ops.coarse_transformer(feat0, feat1, packed, self.layer_names, mask0=mask0, mask1=mask1)
                 # [0]: FM_DEV_RANGE report; [1]: by how much the matches went below the first attempt's activation scale
                 status = torch.zeros(2, dtype=torch.int32, device=feat0.device)
                 self._fine_calls = getattr(self, '_fine_calls', 0) + 1

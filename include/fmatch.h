@@ -370,6 +370,13 @@ int fm_coarse_tf_pack_weights(const float* const* const* layers, int n_layers, v
 int fm_coarse_transformer(const float* feat0, const float* feat1, int N, int L, int S, int C, int nhead,
                           const int* layer_kinds, int n_layers, const void* packed, void* workspace,
                           size_t workspace_bytes, float* out0, float* out1, void* stream);
+/* The same with the reference's padding masks (transformer.py:78-96 mask0 / mask1; attentions.py:35-40: padded query
+ * positions get Q = 0, padded source positions K = V = 0; values are still divided by the PADDED length): mask0 [N, L],
+ * mask1 [N, S] [dev] bytes (1 = a real token, 0 = padding: torch.bool storage), either may be NULL. */
+int fm_coarse_transformer_masked(const float* feat0, const float* feat1, const unsigned char* mask0,
+                                 const unsigned char* mask1, int N, int L, int S, int C, int nhead,
+                                 const int* layer_kinds, int n_layers, const void* packed, void* workspace,
+                                 size_t workspace_bytes, float* out0, float* out1, void* stream);
 
 /*
  * Fine-level context layers between the window crop and the fine matching (network/net.py:79-80): the reference's

@@ -407,6 +407,26 @@ def kat_cases_round2():
     np.savez_compressed(os.path.join(HERE, "kats_r2.npz"), **cases)
 
 
+def masked_coarse_transformer_case(name="tf_masked_coarse"):
+    """The reference's LocalFeatureTransformer in its COARSE configuration (d_model 256, 8 heads, linear attention) WITH
+    padding masks (transformer.py:78-96, attentions.py:35-40): N = 2, L = 77, S = 130, ['self', 'cross'] x 2, the tails of
+    the samples masked out (one sample of image 1 unmasked).  Inputs and weights from the portable RNG; stored: the outputs."""
+    from network.module.transformer import LocalFeatureTransformer
+    seed, n, l, s_, d = 43, 2, 77, 130, 256
+    names = ['self', 'cross', 'self', 'cross']
+    tf = LocalFeatureTransformer(dict(d_model=d, nhead=8, layer_names=names, attention='linear')).eval()
+    tf.load_state_dict({k: torch.as_tensor(v) for k, v in synth.transformer_weights(seed, d, len(names)).items()})
+    x0 = torch.as_tensor((2.0 * synth.normal(seed, 1, (n, l, d))).astype(np.float32))
+    x1 = torch.as_tensor((2.0 * synth.normal(seed, 2, (n, s_, d))).astype(np.float32))
+    m0 = torch.ones(n, l, dtype=torch.bool); m0[0, 60:] = False; m0[1, 33:] = False
+    m1 = torch.ones(n, s_, dtype=torch.bool); m1[0, 100:] = False
+    with torch.no_grad():
+        y0, y1 = tf(x0, x1, m0, m1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), out0=y0.numpy(), out1=y1.numpy(),
+                        mask0=m0.numpy(), mask1=m1.numpy(), meta=np.array([seed, n, l, s_, d], np.int64))
+    print(f"{name}: out0 {tuple(y0.shape)} |max| {float(y0.abs().max()):.3f}")
+
+
 def full_attention_case(name="tf_full_small"):
     """The reference's LocalFeatureTransformer with attention='full' (attentions.py:54-79), with and without padding
     masks, on the inputs and weights of tf_masked_small (d_model 64, 8 heads, ['self', 'cross'], N = 2, L = 40, S = 36)."""
@@ -466,6 +486,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "r5":     # the fixtures added in round 5 only
         net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)
         full_attention_case()
+        masked_coarse_transformer_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epi":
         epipolar_case()
@@ -499,3 +520,4 @@ if __name__ == "__main__":
     # round 5: the a8 chain (net.py:66-83) at the size the bench times it at
     net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)
     full_attention_case()
+    masked_coarse_transformer_case()

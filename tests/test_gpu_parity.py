@@ -1645,6 +1645,37 @@ def test_fine_transformer_weights_beyond_the_scale_are_reported_and_large_sums_a
 
 
 # ------------------------------------------------------------------ coarse context layers in HIP (8(f) row 1)
+def test_coarse_transformer_padding_masks_against_reference_fixture():
+    """fm_coarse_transformer_masked: the reference's optional padding masks (transformer.py:78-96, attentions.py:35-40) in
+    the HIP context layers - padded query tokens get Q = 0, padded source tokens K = 0 - against the outputs of the
+    REFERENCE's LocalFeatureTransformer(d_model 256, ['self', 'cross'] x 2) with masks, every position (the padded ones
+    too: their message is zero there and here).  The module hands masked calls of its coarse configuration to the kernels."""
+    g = load_golden("tf_masked_coarse")
+    seed, n, l, s_, d = [int(v) for v in g['meta']]
+    layers = ['self', 'cross', 'self', 'cross']
+    tw = {k: torch.as_tensor(v) for k, v in synth.transformer_weights(seed, d, len(layers)).items()}
+    x0 = torch.as_tensor((2.0 * synth.normal(seed, 1, (n, l, d))).astype(np.float32), device=DEV)
+    x1 = torch.as_tensor((2.0 * synth.normal(seed, 2, (n, s_, d))).astype(np.float32), device=DEV)
+    m0, m1 = torch.as_tensor(g['mask0'], device=DEV), torch.as_tensor(g['mask1'], device=DEV)
+    packed = ops.pack_coarse_transformer(tw, len(layers), DEV)
+    y0, y1 = ops.coarse_transformer(x0, x1, packed, layers, mask0=m0, mask1=m1)
+    e0 = np.abs(y0.cpu().numpy() - g['out0']).max()
+    e1 = np.abs(y1.cpu().numpy() - g['out1']).max()
+    assert e0 <= 5e-5 and e1 <= 5e-5, (e0, e1)
+    u0, u1 = ops.coarse_transformer(x0, x1, packed, layers)
+    assert (u0 - y0).abs().max().item() > 1e-2                      # the masks matter
+    z0, z1 = ops.coarse_transformer(x0, x1, packed, layers, mask1=m1)      # one mask only
+    assert (z0 - y0).abs().max().item() > 1e-3 and (z0 - u0).abs().max().item() > 1e-3
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    tf = LocalFeatureTransformer(dict(d_model=d, nhead=8, layer_names=layers, attention='linear')).to(DEV).eval()
+    tf.load_state_dict(tw)
+    with torch.no_grad():
+        a0, a1 = tf(x0, x1, m0, m1)
+        t0, t1 = tf._torch_layers(x0, x1, m0, m1)
+    assert torch.equal(a0, y0) and torch.equal(a1, y1)              # the module took the kernels
+    assert (t0 - y0).abs().max().item() <= 5e-5 and (t1 - y1).abs().max().item() <= 5e-5
+
+
 @pytest.mark.parametrize("n,l,s,layers", [(1, 300, 300, ['self', 'cross'] * 4),      # the reference's 8 layers
                                           (2, 77, 130, ['self', 'cross']),           # ragged tiles, L != S, batch
                                           (1, 32, 5, ['cross', 'self', 'self'])])    # one tile; fewer tokens than a tile

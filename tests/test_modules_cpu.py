@@ -87,6 +87,27 @@ def test_context_layers_with_padding_masks_match_the_reference():
     assert (y0 - z0).abs().max() > 1e-2          # the masks matter
 
 
+def test_masked_coarse_configuration_matches_reference_fixture():
+    """The torch definition of the coarse configuration (d_model 256, four layers) with padding masks against the
+    REFERENCE's outputs (tf_masked_coarse: the fixture the HIP kernels are checked against on the GPU)."""
+    import numpy as np
+    import torch
+    from featurematching_amd import synth
+    from featurematching_amd.transformer import LocalFeatureTransformer
+    from helpers import load_golden
+    g = load_golden("tf_masked_coarse")
+    seed, n, l, s, d = [int(v) for v in g['meta']]
+    layers = ['self', 'cross', 'self', 'cross']
+    tf = LocalFeatureTransformer(dict(d_model=d, nhead=8, layer_names=layers, attention='linear')).eval()
+    tf.load_state_dict({k: torch.as_tensor(v) for k, v in synth.transformer_weights(seed, d, len(layers)).items()})
+    x0 = torch.as_tensor((2.0 * synth.normal(seed, 1, (n, l, d))).astype(np.float32))
+    x1 = torch.as_tensor((2.0 * synth.normal(seed, 2, (n, s, d))).astype(np.float32))
+    with torch.no_grad():
+        y0, y1 = tf(x0, x1, torch.as_tensor(g['mask0']), torch.as_tensor(g['mask1']))
+    np.testing.assert_allclose(y0.numpy(), g['out0'], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(y1.numpy(), g['out1'], rtol=0, atol=3e-5)
+
+
 def test_full_attention_option_matches_reference_fixture():
     """attention='full' (network/module/attentions.py:54-79, transformer.py:22): the torch layers against the outputs of the
     REFERENCE's LocalFeatureTransformer(attention='full') on the same seeded inputs and weights, without masks and with
