@@ -261,6 +261,7 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
   char* base = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
   const float inv_ct = 1.0f / ((float)C * temperature);
+  const float thr_list = conf_matrix ? fminf(thr, 0.1f) : thr;      // candidate threshold of the dense kernels' LISTS
 
   // The common path is four launches: prep -> max pass -> sparse sum kernel -> assignment.
   // one dispatch: clear the per-call counters, quantise both images (one int8 step per image), L1 norms
@@ -292,7 +293,9 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
   if (dense) {
     // dense sum kernel (float32-equivalent hi/lo product on the matrix cores): redoes the samples in which the sparse
     // kernel flagged units (one arithmetic per sample keeps exact conf ties exact); exits at once when there are none
-    e = launch_dense(w, base, inv_ct, thr, st);
+    // (a conf_matrix request: candidates down to min(thr, 0.1) - the lists then name every entry of a dense sample with
+    // conf > 0.1, which k_exact_lists resolves from exact dot products; the assignment applies thr itself)
+    e = launch_dense(w, base, inv_ct, thr_list, st);
     if (e != hipSuccess) return (int)e;
   }
   // The assignment folds the softmax denominators of its candidates from the partial sums itself.  The
@@ -308,7 +311,11 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
     if (e != hipSuccess) return (int)e;
   }
   if (exact) {                 // exits immediately unless the sum kernels' screening overflowed a row's slots
-    e = launch_dense(w, base, inv_ct, thr, st, nullptr, 1);
+    e = launch_dense(w, base, inv_ct, thr_list, st, nullptr, 1);
+    if (e != hipSuccess) return (int)e;
+  }
+  if ((conf_matrix || stats) && dense) {  // every entry is read: the dense kernel's lists and their denominators made exact together
+    e = launch_exact_lists(w, base, inv_ct, feat0, feat1, in_dtype, C, st);
     if (e != hipSuccess) return (int)e;
   }
   if (conf_matrix) {           // dense data['conf_matrix'] on request (one more sweep)
@@ -383,6 +390,7 @@ extern "C" int fm_coarse_match_auto(const void* feat0, const void* feat1, int in
   int cur = mode & kAutoDataModes;
   if (full_stats) cur |= FM_MODE_EXACT_SCREENING;        // (that path runs the denominator reduction the re-screening needs anyway)
   int slots = slots0;
+  if (conf_matrix && slots < 16 && max_cand_slots >= 16) slots = 16;     // (its dense lists go down to conf 0.1: <= 10 + band per row)
   if (hint_io && *hint_io) {                             // what served the previous call of this kind
     cur |= *hint_io & kAutoDataModes;
     const int hs = (*hint_io >> 8) & 0xff;

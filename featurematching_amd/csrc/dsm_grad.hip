@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256) void k_dsm_entries(const float* __restrict__ f
 // with its exact dot product; their conf is rewritten from that number and the same log-softmax offsets.
 // One thread per (row, slot).
 __global__ __launch_bounds__(256) void k_conf_patch(const int* __restrict__ rcount, const int* __restrict__ rlist_j,
-                                                    const float* __restrict__ rlist_x, const float* __restrict__ nm_r,
+                                                    const float* __restrict__ rlist_x, const int* __restrict__ rcount_d,
+                                                    const int* __restrict__ rlist_j_d, const float* __restrict__ rlist_x_d,
+                                                    const float* __restrict__ nm_r,
                                                     const float* __restrict__ sum_r, const float* __restrict__ nm_c,
                                                     const float* __restrict__ sum_c, const int* __restrict__ dense_cnt, int N,
                                                     int L, int S, int Lp, int Sp, int slots, float k2, float* __restrict__ conf) {
@@ -296,19 +298,132 @@ __global__ __launch_bounds__(256) void k_conf_patch(const int* __restrict__ rcou
   const int slot = (int)(gid - grow * slots);
   if (grow >= (long)N * Lp) return;
   const int b = (int)(grow / Lp), i = (int)(grow - (long)b * Lp);
-  if (i >= L || dense_cnt[b] > 0 || slot >= min(rcount[grow], slots)) return;
-  const float x = rlist_x[grow * slots + slot];
+  if (i >= L) return;
+  const bool dense = dense_cnt[b] > 0;         // the dense kernel's lists, made exact by k_exact_lists
+  if (slot >= min((dense ? rcount_d : rcount)[grow], slots)) return;
+  const float x = (dense ? rlist_x_d : rlist_x)[grow * slots + slot];
   if (!(x > -INFINITY)) return;                    // a reserved but empty place
-  const int j = rlist_j[grow * slots + slot];
+  const int j = (dense ? rlist_j_d : rlist_j)[grow * slots + slot];
   const long gcol = (long)b * Sp + j;
   conf[((long)b * L + i) * S + j] = (__builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm_r[grow])) / sum_r[grow]) *
                                     (__builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm_c[gcol])) / sum_c[gcol]);
 }
 
+// The samples the DENSE kernel served (flat similarity somewhere in the sample), when every entry is read (conf_matrix,
+// softmax statistics): the hi/lo-split float16 products carry 22 bits, 2^-22 |sim| ~ 4e-5 at similarities of ~170 - and
+// a peaked row of such a sample (conf ~ 1: the entry IS its row's and its column's denominator) is only right when the
+// entry and the two denominators hold the SAME x.  So the lists of such a sample - with a conf_matrix request they are
+// formed with min(thr, 0.1): every entry whose two softmax factors both exceed 0.1, i.e. every entry with conf > 0.1 -
+// are resolved exactly, entries and denominators together:
+//   k_exact_lists : 16 lanes per (row, slot) and per (column, slot): the exact float32 dot product of the caller's
+//                   descriptors (the arithmetic of k_conf_at) replaces the list's x; the term's change
+//                   exp2(k x + nm) - exp2(k x22 + nm) goes to the screening kernel's list region of the sample (idle)
+//   k_fix_sums    : one thread per row / column: adds the changes in index order (same bits every run) to the
+//                   denominator, refreshes the log-softmax offset
+// The assignment then reads exact x and matching denominators (mconf = the conf_matrix entry), k_conf_patch rewrites the
+// listed entries of the dense matrix.  What stays 22-bit has conf <= 0.1: 2 * 2^-22 |sim| conf <= 8e-6 at |sim| ~ 170.
+__global__ __launch_bounds__(256) void k_exact_lists(const void* __restrict__ f0, const void* __restrict__ f1, int in_dtype, int c_in,
+                                                     const int* __restrict__ rcount, const int* __restrict__ rkey, float* __restrict__ rx,
+                                                     float* __restrict__ rdelta, const int* __restrict__ ccount,
+                                                     const int* __restrict__ ckey, float* __restrict__ cx, float* __restrict__ cdelta,
+                                                     const float* __restrict__ nm_r, const float* __restrict__ nm_c,
+                                                     const int* __restrict__ dense_cnt, int N, int L, int S, int Lp, int Sp,
+                                                     int slots, float k2) {
+  const int side = blockIdx.z;
+  const int len = side ? Sp : Lp;
+  const long grp = (long)blockIdx.x * 16 + (threadIdx.x >> 4);          // one 16-lane group per (list, slot)
+  const int l16 = threadIdx.x & 15;
+  const long gl = grp / slots;
+  const int slot = (int)(grp - gl * slots);
+  if (gl >= (long)N * len) return;
+  const int b = (int)(gl / len), own = (int)(gl - (long)b * len);
+  if (own >= (side ? S : L) || dense_cnt[b] == 0 || slot >= min((side ? ccount : rcount)[gl], slots)) return;   // (uniform over the group)
+  const long at = gl * slots + slot;
+  const int other = (side ? ckey : rkey)[at];
+  const int i = side ? other : own, j = side ? own : other;
+  const long ro = ((long)b * L + i) * c_in, co = ((long)b * S + j) * c_in;
+  const int vpr = c_in >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int v4 = l16 + 16 * q;
+    const bool in = v4 < vpr;
+    const int vc = in ? v4 : 0;
+    float4 a, bb;
+    if (in_dtype == FM_F32) {
+      a = reinterpret_cast<const float4*>((const float*)f0 + ro)[vc];
+      bb = reinterpret_cast<const float4*>((const float*)f1 + co)[vc];
+    } else {
+      a = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)f0 + ro)[vc], in_dtype);
+      bb = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)f1 + co)[vc], in_dtype);
+    }
+    if (!in) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    s = __builtin_fmaf(a.x, bb.x, s);
+    s = __builtin_fmaf(a.y, bb.y, s);
+    s = __builtin_fmaf(a.z, bb.z, s);
+    s = __builtin_fmaf(a.w, bb.w, s);
+  }
+  const float x = row_sum16_g(s);
+  if (l16 == 0) {
+    float* xs = side ? cx : rx;
+    const float nm = (side ? nm_c : nm_r)[gl];
+    (side ? cdelta : rdelta)[at] = __builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm)) - __builtin_amdgcn_exp2f(__builtin_fmaf(xs[at], k2, nm));
+    xs[at] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fix_sums(const int* __restrict__ rcount, const int* __restrict__ rkey,
+                                                  const float* __restrict__ rdelta, const int* __restrict__ ccount,
+                                                  const int* __restrict__ ckey, const float* __restrict__ cdelta,
+                                                  const float* __restrict__ nm_r, const float* __restrict__ nm_c,
+                                                  float* __restrict__ sum_r, float* __restrict__ sum_c, float* __restrict__ nm2_r,
+                                                  float* __restrict__ nm2_c, const int* __restrict__ dense_cnt, int Lp, int Sp,
+                                                  int slots) {
+  const int side = blockIdx.z, b = blockIdx.y;
+  const int len = side ? Sp : Lp;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= len || dense_cnt[b] == 0) return;
+  const long gl = (long)b * len + idx;
+  const int n = min((side ? ccount : rcount)[gl], slots);
+  if (n == 0) return;
+  const int* key = (side ? ckey : rkey) + gl * slots;
+  const float* d = (side ? cdelta : rdelta) + gl * slots;
+  float acc = 0.f;
+  int last = -1;
+  for (int t = 0; t < n; ++t) {           // in index order (the lists are filled in the order the waves arrive)
+    int best = 0x7fffffff, at = 0;
+    for (int q = 0; q < n; ++q) { const int kq = key[q]; if (kq > last && kq < best) { best = kq; at = q; } }
+    acc += d[at];
+    last = best;
+  }
+  float* sum = side ? sum_c : sum_r;
+  const float v = sum[gl] + acc;
+  sum[gl] = v;
+  (side ? nm2_c : nm2_r)[gl] = (side ? nm_c : nm_r)[gl] - __log2f(v);
+}
+
+hipError_t launch_exact_lists(const CoarseWs& w, char* base, float inv_ct, const void* feat0, const void* feat1, int in_dtype,
+                              int c_in, hipStream_t st) {
+  const long groups = (long)w.N * max(w.Lp, w.Sp) * w.slots;
+  hipLaunchKernelGGL(k_exact_lists, dim3((unsigned)((groups + 15) / 16), 1, 2), dim3(256), 0, st, feat0, feat1, in_dtype, c_in,
+                     (const int*)(base + w.cand_count_b), (const int*)(base + w.cand_j_b), (float*)(base + w.cand_x_b),
+                     (float*)(base + w.cand_x), (const int*)(base + w.ccand_count_b), (const int*)(base + w.ccand_i_b),
+                     (float*)(base + w.ccand_x_b), (float*)(base + w.ccand_x), (const float*)(base + w.nmr),
+                     (const float*)(base + w.nmc), (const int*)(base + w.dense_cnt), w.N, w.L, w.S, w.Lp, w.Sp, w.slots,
+                     inv_ct * kLog2e);
+  hipLaunchKernelGGL(k_fix_sums, dim3((max(w.Lp, w.Sp) + 255) / 256, w.N, 2), dim3(256), 0, st,
+                     (const int*)(base + w.cand_count_b), (const int*)(base + w.cand_j_b), (const float*)(base + w.cand_x),
+                     (const int*)(base + w.ccand_count_b), (const int*)(base + w.ccand_i_b), (const float*)(base + w.ccand_x),
+                     (const float*)(base + w.nmr), (const float*)(base + w.nmc), (float*)(base + w.rsum), (float*)(base + w.csum),
+                     (float*)(base + w.nmr2), (float*)(base + w.nmc2), (const int*)(base + w.dense_cnt), w.Lp, w.Sp, w.slots);
+  return hipGetLastError();
+}
+
 hipError_t launch_conf_patch(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st) {
   const long total = (long)w.N * w.Lp * w.slots;
   hipLaunchKernelGGL(k_conf_patch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const int*)(base + w.cand_count),
-                     (const int*)(base + w.cand_j), (const float*)(base + w.cand_x), (const float*)(base + w.nmr),
+                     (const int*)(base + w.cand_j), (const float*)(base + w.cand_x), (const int*)(base + w.cand_count_b),
+                     (const int*)(base + w.cand_j_b), (const float*)(base + w.cand_x_b), (const float*)(base + w.nmr),
                      (const float*)(base + w.rsum), (const float*)(base + w.nmc), (const float*)(base + w.csum),
                      (const int*)(base + w.dense_cnt), w.N, w.L, w.S, w.Lp, w.Sp, w.slots,
                      inv_ct * kLog2e, conf);

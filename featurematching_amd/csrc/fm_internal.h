@@ -112,6 +112,8 @@ hipError_t launch_select(const CoarseWs& w, char* base, int h0c, int w0c, int h1
                          float* mconf, int cap, int32_t* d_count, int mode, hipStream_t st,
                          const MapCopyJob* job = nullptr);
 hipError_t launch_conf_patch(const CoarseWs& w, char* base, float inv_ct, float* conf, hipStream_t st);
+hipError_t launch_exact_lists(const CoarseWs& w, char* base, float inv_ct, const void* feat0, const void* feat1, int in_dtype,
+                              int c_in, hipStream_t st);
 // (the batched form of the screening - k_thresh + k_screen_rows, one wave per (row block, 64 units) - is chosen inside
 // launch_screen when the batch alone fills the chip with waves)
 hipError_t launch_screen(const void* feat0, const void* feat1, int in_dtype, int c_in, const CoarseWs& w, char* base,
