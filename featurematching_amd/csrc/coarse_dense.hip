@@ -233,6 +233,11 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
         conf_base = reinterpret_cast<const char*>(a.conf + ((long)b * a.L + wrow0) * a.S + (long)uc * 32);
         conf_voff = (unsigned)((4 * h * a.S + r) * 4);
         conf_full = !row_edge && uc * 32 + 32 <= a.S;
+#ifdef FM_ABL_CONF_SMALLDST     // timing-only ablation (results are wrong): every store lands in the same 64 KiB
+        conf_pitch = 0;
+        conf_base = reinterpret_cast<const char*>(a.conf) + wv * 8192;
+        conf_voff = (unsigned)(lane * 4);
+#endif
       }
     }
     const unsigned base = ring_a + ((un - u0) % kDenseRing) * UNIT_BYTES + lane * 16;
@@ -291,6 +296,14 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
           // (bit 15 - g).  A filter + rescan of the 16 registers took ~1k cycles whenever ANY of the workgroup's 8 waves
           // entered it - nearly every unit - and the per-unit barrier made all of them wait: 13k of 82k cycles.
           if constexpr (CONF) {
+            // (round 5, in-kernel clock at cfg#3, tools/diag_conf_clock.py: 6140 cycles per unit and workgroup; the same
+            // kernel with the store removed 3160 at one product (FM_ABL_CONF_NOSTORE), with every store aimed at the same
+            // 64 KiB 3350 (FM_ABL_CONF_SMALLDST): what the stores cost is the write path behind the L2, ~160 cycles of
+            // wave time each, while the whole sweep writes at 2.5 TB/s - a store-only kernel of the same shape and
+            // occupancy reaches 5.5 (tools/microbench_store_pattern.hip).  Tried without effect: counting the stores in
+            // the per-unit vmcnt wait instead of draining them, the SIMD's two waves storing in alternate halves of the
+            // k-steps, the conf value formed in the accumulator register (no write-after-read on the store's data),
+            // nontemporal stores (slower: 7070).)
             // conf of register g's entry and its store: rows (g & 3) + 8 (g >> 2) [+ 4 for the upper half], column r
             float t1, t2;
             const char* rowbase = conf_base + (long)((g & 3) + 8 * (g >> 2)) * conf_pitch;      // (wave-uniform: scalar)
@@ -298,11 +311,15 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
               asm volatile(
                   "v_fma_f32 %[t1], %[x], %[kq], %[nm]\n\t"
                   "v_fma_f32 %[t2], %[x], %[kq], %[nmc]\n\t"
+#ifndef FM_ABL_CONF_NOEXP        // timing-only ablations (results are wrong): never defined in the shipped build
                   "v_exp_f32 %[t1], %[t1]\n\t"
                   "v_exp_f32 %[t2], %[t2]\n\t"
                   "s_nop 0\n\t"
+#endif
                   "v_mul_f32 %[t1], %[t1], %[t2]\n\t"
+#ifndef FM_ABL_CONF_NOSTORE
                   "global_store_dword %[vo], %[t1], %[sb]"
+#endif
                   : [t1] "=&v"(t1), [t2] "=&v"(t2)
                   : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [vo] "v"(conf_voff), [sb] "s"(rowbase)
                   : "memory");
@@ -431,6 +448,20 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
 #ifdef FM_DIAG_CLOCK
   dg_loop_end = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef FM_DIAG_CLOCK       // the screening kernel's row-list slots of the padded rows (>= L, never used) carry 64 waves' stamps
+  auto diag_stamp = [&]() {
+  if (split == 0 && panel < 8 && (a.Lp - a.L) * a.slots >= 512 && lane < 8) {
+    const float vals[8] = {(float)(__builtin_amdgcn_s_memtime() - dg0), (float)(__builtin_amdgcn_s_memrealtime() - dgr0),
+                           (float)(u1 - u0), (float)dg_chain, 0.f, (float)dg_bar, (float)dg_pro,
+                           (float)(__builtin_amdgcn_s_memtime() - dg_loop_end)};
+    float vv = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vv = lane == q ? vals[q] : vv;
+    a.diag[((long)b * a.Lp + a.L) * a.slots + (panel * 8 + wv) * 8 + lane] = vv;
+  }
+  };
+  if constexpr (CONF) diag_stamp();
+#endif
   if constexpr (CONF) return;
   // ---- the parked candidates -> the per-row / per-column slot lists: one entry per lane; the slot reservation (a
   // returning atomic: one memory round trip) is issued here and consumed behind the row reduction below ----
@@ -465,16 +496,8 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
     if (q_cpos < a.slots) { a.ccand_i[q_col * a.slots + q_cpos] = wrow0 + (q_key & 31); a.ccand_x[q_col * a.slots + q_cpos] = q_x; }
     if (q_pos >= a.slots || q_cpos >= a.slots) atomicOr(a.flags, RESCREEN ? (unsigned)FM_DEV_CANDIDATES : (unsigned)FM_INT_SCREEN_OVERFLOW);
   }
-#ifdef FM_DIAG_CLOCK       // the screening kernel's row-list slots of the padded rows (>= L, never used) carry 64 waves' stamps
-  if (split == 0 && panel < 8 && (a.Lp - a.L) * a.slots >= 512 && lane < 8) {
-    const float vals[8] = {(float)(__builtin_amdgcn_s_memtime() - dg0), (float)(__builtin_amdgcn_s_memrealtime() - dgr0),
-                           (float)(u1 - u0), (float)dg_chain, 0.f, (float)dg_bar, (float)dg_pro,
-                           (float)(__builtin_amdgcn_s_memtime() - dg_loop_end)};
-    float vv = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) vv = lane == q ? vals[q] : vv;
-    a.diag[((long)b * a.Lp + a.L) * a.slots + (panel * 8 + wv) * 8 + lane] = vv;
-  }
+#ifdef FM_DIAG_CLOCK
+  diag_stamp();
 #endif
 }
 

@@ -13,6 +13,11 @@ import bench  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
+    if '--lib' in sys.argv:            # an experimental build (tools/build_variant.sh), loaded explicitly
+        at = sys.argv.index('--lib')
+        from featurematching_amd import _lib
+        _lib.load(os.path.abspath(sys.argv[at + 1]))
+        del sys.argv[at:at + 2]
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     wl = dict(bench.WORKLOADS["cfg3"], n=n)
     p = bench.Pair(wl, 4242, 5, dev, "peaky", device_data=True)
