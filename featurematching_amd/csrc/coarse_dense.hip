@@ -82,14 +82,23 @@ __device__ __forceinline__ unsigned lds_addr_d(T* p) { return (unsigned)(size_t)
 // product again, the candidate test with the now-known softmax denominators (log2 P_row > log2 thr and log2 P_col >
 // log2 thr: at most 1/thr entries of a row can pass), no sums; the lists of the samples the sum sweep served are
 // refilled from scratch (k_reduce_sums cleared their counters).  Enqueued always, exits at once when not needed.
-enum { kDenseSums = 0, kDenseConf = 1, kDenseRescreen = 2 };
+// CONF_LITE (round 5): the conf sweep of the samples the SCREENING kernel served.  There every entry that is not on its
+// row's list of significant entries has exp2(k x + nm) < 2^-32 of its row's largest term - conf < 2.4e-10 whatever a few
+// per cent of relative error do to it - and every entry that is on a list is rewritten from its exact float32 dot product
+// by k_conf_patch: ONE float16 product (hi x hi, 11 bits) is enough.  A third of the MFMAs and, more to the point, half
+// of the plane bytes per unit: the sweep is bound by its memory stream (tools/microbench_store_pattern.hip: the same
+// stores with 32 KiB of plane reads per unit and NO arithmetic take 1.6-1.9 ms at cfg#3, with reads that always hit 0.93).
+// The samples the dense kernel served (flat similarity: entries of every size) keep the hi/lo-split product (CONF).
+enum { kDenseSums = 0, kDenseConf = 1, kDenseRescreen = 2, kDenseConfLite = 3 };
 template <int C, int VAR = kDenseSums>
 __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
-  constexpr bool CONF = VAR == kDenseConf, RESCREEN = VAR == kDenseRescreen, SUMS = VAR == kDenseSums;
+  constexpr bool LITE = VAR == kDenseConfLite;
+  constexpr bool CONF = VAR == kDenseConf || LITE, RESCREEN = VAR == kDenseRescreen, SUMS = VAR == kDenseSums;
   constexpr int KSTEPS = C / 16;
   constexpr int PLANE = KSTEPS * 1024;              // bytes of one plane (hi or lo) of a unit
   constexpr int UNIT_BYTES = 2 * PLANE;             // hi then lo
-  constexpr int PW = 2 * KSTEPS / 8;                // LDS-DMA pieces (1 KiB) per wave and unit
+  constexpr int NPIECE = LITE ? KSTEPS : 2 * KSTEPS;      // LDS-DMA pieces (1 KiB) per unit: (plane, k-step)
+  constexpr int PW = (NPIECE + 7) / 8;              // ... per wave (LITE at C = 64: 4 pieces - waves 4 .. 7 bring none)
   constexpr int SPK = 16 / KSTEPS;                  // epilogue slices (accumulator registers) per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];      // the unit ring
   __shared__ float s_meta[kDenseRing * 64];         // per ring slot: the unit's 32 column stabilisers (twice)
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   const int panel = pg * a.pgroup + (kk - split * pcount);
   const int u0 = split * a.units_per_split, u1 = min(u0 + a.units_per_split, a.units);
   if (!CONF && a.dense_cnt[b] == 0) return;         // uniform: this sample was served by the screening kernel
+  if (CONF && LITE != (a.dense_cnt[b] == 0)) return;        // uniform: the conf sweep of this sample is the other variant's
   const float inv_sc = a.f16inv[b];                 // the planes carry exact power-of-two scales (k_prep_f16)
   const float kq = a.k * inv_sc;                    // accumulator -> log2-domain similarity
   const char* plane_hi = reinterpret_cast<const char*>(a.hi1 + (long)b * a.Sp * C);
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
 #pragma unroll
     for (int n = 0; n < PW; ++n) {
       const int p = wv * PW + n;                    // 0 .. 2 KSTEPS - 1: hi pieces first, then lo
+      if (NPIECE < 8 * PW && p >= NPIECE) break;
       const char* src = (p < KSTEPS ? plane_hi : plane_lo) + ((long)u * KSTEPS + (p < KSTEPS ? p : p - KSTEPS)) * 1024 + lane * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(smem + slot * UNIT_BYTES + p * 1024), 16, 0, 0);
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       ahi[ks] = *reinterpret_cast<const half8d*>(a.hi0 + off + ks * 512);
-      alo[ks] = *reinterpret_cast<const half8d*>(a.lo0 + off + ks * 512);
+      if constexpr (!LITE) alo[ks] = *reinterpret_cast<const half8d*>(a.lo0 + off + ks * 512);
     }
   }
   float nmsel[16];                                  // ... of this lane's 16 rows (accumulator register g: row (g&3) + 8 (g>>2) + 4 h)
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
   // barrier; the first chain then takes each A fragment as it arrives (the compiler's own counted waits), instead of
   // the whole prologue - ~350 KB per workgroup through one CU's 64 B/clk - in front of the first MFMA (12k cycles).
   {
-    constexpr int YOUNGER = 2 * KSTEPS;             // the A fragments (the other units' pieces only make it safer)
+    constexpr int YOUNGER = LITE ? KSTEPS : 2 * KSTEPS;      // the A fragments (the other units' pieces only make it safer)
     static_assert(YOUNGER <= 63, "vmcnt immediate");
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(YOUNGER) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
     auto issue_ = [](auto ksc, half8d (&bh_)[RING], half8d (&bl_)[RING], unsigned base_) {
       constexpr int ks = decltype(ksc)::value;
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bh_[ks % RING]) : "v"(base_), "i"(ks * 1024));
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl_[ks % RING]) : "v"(base_), "i"(PLANE + ks * 1024));
+      if constexpr (!LITE) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl_[ks % RING]) : "v"(base_), "i"(PLANE + ks * 1024));
     };
 #define issue(...) issue_(__VA_ARGS__, bh, bl, base)
     if (DN) {
@@ -262,7 +273,8 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
       if (DN) {
         if constexpr (ks + PF < KSTEPS) issue(std::integral_constant<int, ks + PF>{});
         constexpr int ahead = (KSTEPS - 1 - ks) < PF ? (KSTEPS - 1 - ks) : PF;     // k-steps issued beyond ks
-        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(bh[ks % RING]), "+v"(bl[ks % RING]), "+v"(nmc_n) : "n"(2 * ahead));
+        if constexpr (LITE) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[ks % RING]), "+v"(nmc_n) : "n"(ahead));
+        else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(bh[ks % RING]), "+v"(bl[ks % RING]), "+v"(nmc_n) : "n"(2 * ahead));
         if (ks == 0) {
           // The accumulator starts at 0, or at -inf for padded rows (>= L) / padded columns (>= S): such entries stay
           // -inf through the whole chain, so the epilogue needs no masks (exp2 gives 0, the candidate test fails)
@@ -279,8 +291,10 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
           accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bh[ks % RING], accN, 0, 0, 0);
         }
 #ifndef FM_ABL_DENSE_ONEMFMA    // timing-only ablation: one product instead of three
-        accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bh[ks % RING], accN, 0, 0, 0);
-        accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl[ks % RING], accN, 0, 0, 0);
+        if constexpr (!LITE) {
+          accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bh[ks % RING], accN, 0, 0, 0);
+          accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl[ks % RING], accN, 0, 0, 0);
+        }
 #endif
       }
 #ifndef FM_ABL_DENSE_NOEPI      // timing-only ablation (results are wrong): never defined in the shipped build
@@ -318,7 +332,15 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
 #endif
                   "v_mul_f32 %[t1], %[t1], %[t2]\n\t"
 #ifndef FM_ABL_CONF_NOSTORE
+#if defined(FM_CONF_STORE_SC01)   // experiments (round 5): cache-policy bits on the store
+                  "global_store_dword %[vo], %[t1], %[sb] sc0 sc1"
+#elif defined(FM_CONF_STORE_SC1)
+                  "global_store_dword %[vo], %[t1], %[sb] sc1"
+#elif defined(FM_CONF_STORE_NT)
+                  "global_store_dword %[vo], %[t1], %[sb] nt"
+#else
                   "global_store_dword %[vo], %[t1], %[sb]"
+#endif
 #endif
                   : [t1] "=&v"(t1), [t2] "=&v"(t2)
                   : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [vo] "v"(conf_voff), [sb] "s"(rowbase)
@@ -536,7 +558,11 @@ hipError_t launch_dense(const CoarseWs& w, char* base, float inv_ct, float thr, 
 #define FM_DENSE_CASE(CC)                                                                        \
   case CC: {                                                                                     \
     static unsigned long long lds_set = 0, lds_set_c = 0, lds_set_r = 0;                         \
-    if (conf) {                                                                                  \
+    if (conf) {      /* the samples the screening kernel served, then (exits at once without any) the dense kernel's */ \
+      static unsigned long long lds_set_l = 0;                                                   \
+      e = ensure_dynamic_lds(&k_dense<CC, kDenseConfLite>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set_l); \
+      if (e != hipSuccess) return e;                                                             \
+      hipLaunchKernelGGL((k_dense<CC, kDenseConfLite>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);   \
       e = ensure_dynamic_lds(&k_dense<CC, kDenseConf>, kDenseRing * 2 * (CC / 16) * 1024, &lds_set_c); \
       if (e != hipSuccess) return e;                                                             \
       hipLaunchKernelGGL((k_dense<CC, kDenseConf>), dim3(blocks), dim3(512), kDenseRing * 2 * (CC / 16) * 1024, st, a);   \

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_conf_patch(const int* __restrict__ rcou
 // entry and the two denominators hold the SAME x.  So the lists of such a sample - with a conf_matrix request they are
 // formed with min(thr, 0.1): every entry whose two softmax factors both exceed 0.1, i.e. every entry with conf > 0.1 -
 // are resolved exactly, entries and denominators together:
-//   k_exact_lists : 16 lanes per (row, slot) and per (column, slot): the exact float32 dot product of the caller's
+//   k_exact_lists : 16 lanes per row list and per column list, its entries in turn: the exact float32 dot product of the caller's
 //                   descriptors (the arithmetic of k_conf_at) replaces the list's x; the term's change
 //                   exp2(k x + nm) - exp2(k x22 + nm) goes to the screening kernel's list region of the sample (idle)
 //   k_fix_sums    : one thread per row / column: adds the changes in index order (same bits every run) to the
@@ -331,44 +331,45 @@ __global__ __launch_bounds__(256) void k_exact_lists(const void* __restrict__ f0
                                                      int slots, float k2) {
   const int side = blockIdx.z;
   const int len = side ? Sp : Lp;
-  const long grp = (long)blockIdx.x * 16 + (threadIdx.x >> 4);          // one 16-lane group per (list, slot)
+  const long gl = (long)blockIdx.x * 16 + (threadIdx.x >> 4);           // one 16-lane group per list, its slots in turn
   const int l16 = threadIdx.x & 15;
-  const long gl = grp / slots;
-  const int slot = (int)(grp - gl * slots);
   if (gl >= (long)N * len) return;
   const int b = (int)(gl / len), own = (int)(gl - (long)b * len);
-  if (own >= (side ? S : L) || dense_cnt[b] == 0 || slot >= min((side ? ccount : rcount)[gl], slots)) return;   // (uniform over the group)
-  const long at = gl * slots + slot;
-  const int other = (side ? ckey : rkey)[at];
-  const int i = side ? other : own, j = side ? own : other;
-  const long ro = ((long)b * L + i) * c_in, co = ((long)b * S + j) * c_in;
+  if (own >= (side ? S : L) || dense_cnt[b] == 0) return;              // (uniform over the group)
+  const int n = min((side ? ccount : rcount)[gl], slots);
   const int vpr = c_in >> 2;
-  float s = 0.f;
+  for (int slot = 0; slot < n; ++slot) {
+    const long at = gl * slots + slot;
+    const int other = (side ? ckey : rkey)[at];
+    const int i = side ? other : own, j = side ? own : other;
+    const long ro = ((long)b * L + i) * c_in, co = ((long)b * S + j) * c_in;
+    float s = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int v4 = l16 + 16 * q;
-    const bool in = v4 < vpr;
-    const int vc = in ? v4 : 0;
-    float4 a, bb;
-    if (in_dtype == FM_F32) {
-      a = reinterpret_cast<const float4*>((const float*)f0 + ro)[vc];
-      bb = reinterpret_cast<const float4*>((const float*)f1 + co)[vc];
-    } else {
-      a = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)f0 + ro)[vc], in_dtype);
-      bb = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)f1 + co)[vc], in_dtype);
+    for (int q = 0; q < 4; ++q) {
+      const int v4 = l16 + 16 * q;
+      const bool in = v4 < vpr;
+      const int vc = in ? v4 : 0;
+      float4 a, bb;
+      if (in_dtype == FM_F32) {
+        a = reinterpret_cast<const float4*>((const float*)f0 + ro)[vc];
+        bb = reinterpret_cast<const float4*>((const float*)f1 + co)[vc];
+      } else {
+        a = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)f0 + ro)[vc], in_dtype);
+        bb = half4_to_float4(reinterpret_cast<const uint2*>((const unsigned short*)f1 + co)[vc], in_dtype);
+      }
+      if (!in) a = make_float4(0.f, 0.f, 0.f, 0.f);
+      s = __builtin_fmaf(a.x, bb.x, s);
+      s = __builtin_fmaf(a.y, bb.y, s);
+      s = __builtin_fmaf(a.z, bb.z, s);
+      s = __builtin_fmaf(a.w, bb.w, s);
     }
-    if (!in) a = make_float4(0.f, 0.f, 0.f, 0.f);
-    s = __builtin_fmaf(a.x, bb.x, s);
-    s = __builtin_fmaf(a.y, bb.y, s);
-    s = __builtin_fmaf(a.z, bb.z, s);
-    s = __builtin_fmaf(a.w, bb.w, s);
-  }
-  const float x = row_sum16_g(s);
-  if (l16 == 0) {
-    float* xs = side ? cx : rx;
-    const float nm = (side ? nm_c : nm_r)[gl];
-    (side ? cdelta : rdelta)[at] = __builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm)) - __builtin_amdgcn_exp2f(__builtin_fmaf(xs[at], k2, nm));
-    xs[at] = x;
+    const float x = row_sum16_g(s);
+    if (l16 == 0) {
+      float* xs = side ? cx : rx;
+      const float nm = (side ? nm_c : nm_r)[gl];
+      (side ? cdelta : rdelta)[at] = __builtin_amdgcn_exp2f(__builtin_fmaf(x, k2, nm)) - __builtin_amdgcn_exp2f(__builtin_fmaf(xs[at], k2, nm));
+      xs[at] = x;
+    }
   }
 }
 
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void k_fix_sums(const int* __restrict__ rcount
 
 hipError_t launch_exact_lists(const CoarseWs& w, char* base, float inv_ct, const void* feat0, const void* feat1, int in_dtype,
                               int c_in, hipStream_t st) {
-  const long groups = (long)w.N * max(w.Lp, w.Sp) * w.slots;
+  const long groups = (long)w.N * max(w.Lp, w.Sp);
   hipLaunchKernelGGL(k_exact_lists, dim3((unsigned)((groups + 15) / 16), 1, 2), dim3(256), 0, st, feat0, feat1, in_dtype, c_in,
                      (const int*)(base + w.cand_count_b), (const int*)(base + w.cand_j_b), (float*)(base + w.cand_x_b),
                      (float*)(base + w.cand_x), (const int*)(base + w.ccand_count_b), (const int*)(base + w.ccand_i_b),

@@ -63,6 +63,45 @@ __global__ __launch_bounds__(512) void k_tile_x4(float* conf, int L, int S, int 
   }
 }
 
+// the sweep's whole memory stream: per unit the workgroup also READS 32 KiB of its sample's planes (4.9 MB per sample,
+// shared by the sample's 19 workgroups, which sit on one XCD: L2 hits) - 16 bytes per lane, 4 loads per wave
+__global__ __launch_bounds__(512) void k_tile_rw(float* conf, const float4* __restrict__ planes, int L, int S, float* sink, int lds_dma, int src, int nq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // all workgroups of a sample on one XCD: workgroup k of the grid runs on XCD k % 8
+  const int per_s = (L + 255) / 256, nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int lin = src == 2 ? (int)blockIdx.x : xcd * (nblk / 8) + idx;                // (nblk is a multiple of 8 here: 64 samples x 19)
+  const int b = lin / per_s, panel = lin - b * per_s;
+  const int row0 = (panel * 8 + wv) * 32;
+  float* base = conf + ((long)b * L + row0) * S;
+  // src 0: the sample's planes (shared by its 19 workgroups); 1: the same 32 KiB for everybody, every unit (always an L2
+  // hit); 2: the sample's planes, but the workgroups of a sample spread over all XCDs (lin = blockIdx.x)
+  const float4* pl = planes + (long)b * (S / 32) * 2048;          // 32 KiB per unit = 2048 float4
+  const long ustride = src == 1 ? 0 : 2048;
+  if (src == 1) pl = planes;
+  const int lr = lane >> 5, lc = lane & 31;
+  float acc = 0.f;
+  for (int u = 0; u < S / 32; ++u) {
+    if (lds_dma) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < nq) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl + (long)u * ustride + (wv * 4 + q) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(smem + ((u & 3) * 32768) + (wv * 4 + q) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (q < nq) { const float4 v = pl[(long)u * ustride + (wv * 4 + q) * 64 + lane]; acc += v.x + v.w; }
+    }
+    if (row0 < L) {
+      const float v = (float)u + acc;
+#pragma unroll 4
+      for (int r = 0; r < 32; r += 2)
+        if (row0 + r + lr < L) base[(long)(r + lr) * S + u * 32 + lc] = v;
+    }
+  }
+  if (acc == 12345.f) *sink = acc;
+}
+
 template <int W, int CW, bool NT>
 static void run(const char* name, float* conf, int N, int L, int S, int splits, int delay, hipEvent_t e0, hipEvent_t e1) {
   constexpr int RW = 8 / CW;
@@ -142,6 +181,37 @@ int main(int argc, char** argv) {
       if (rep && ms < best) best = ms;
     }
     printf("one workgroup per compute unit, delay %d: %.3f ms  %.2f TB/s\n", delay, best, 4.0 * n / best / 1e9);
+  }
+  {
+    float4* planes; hipMalloc(&planes, (size_t)N * (S / 32) * 32768); hipMemset(planes, 0, (size_t)N * (S / 32) * 32768);
+    float* sink; hipMalloc(&sink, 4);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_rw), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    for (int src = 0; src < 3; ++src)
+    for (int mode = 0; mode < 2; ++mode) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_tile_rw, dim3(N * ((L + 255) / 256)), dim3(512), 128 * 1024, 0, conf, planes, L, S, sink, mode, src, 4);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+      }
+      printf("stores + 32 KiB of plane reads per unit (%s; %s), one workgroup per compute unit: %.3f ms  %.2f TB/s of stores\n",
+             mode ? "LDS-DMA" : "register loads", src == 0 ? "sample's planes, sample on one XCD" : (src == 1 ? "the same 32 KiB always" : "sample's planes, sample spread over XCDs"),
+             best, 4.0 * n / best / 1e9);
+    }
+    for (int nq : {2, 1}) {                      // fewer plane bytes per unit: 16 KiB (one plane), 8 KiB (one plane, 512-row workgroups)
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_tile_rw, dim3(N * ((L + 255) / 256)), dim3(512), 128 * 1024, 0, conf, planes, L, S, sink, 1, 0, nq);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+      }
+      printf("stores + %d KiB of plane reads per unit (LDS-DMA; sample on one XCD): %.3f ms  %.2f TB/s of stores\n", 8 * nq, best, 4.0 * n / best / 1e9);
+    }
+    hipFree(planes); hipFree(sink);
   }
   // paced like the sweep (a unit of the real kernel takes ~1.5 us per wave): does the shape matter less when the stores trickle?
   run<32, 1, false>("tile, paced", conf, N, L, S, 3, 4, e0, e1);
