@@ -287,7 +287,7 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
   if (dense && !flat) {
     // float16 hi / lo planes for the samples that go on to the dense kernel (all of them when the exact screening or
     // the conf_matrix sweep will run); exits at once otherwise
-    e = launch_prep_f16(feat0, feat1, in_dtype, C, w, base, (exact || conf_matrix) ? 1 : 0, st);
+    e = launch_prep_f16(feat0, feat1, in_dtype, C, w, base, exact ? 1 : (conf_matrix ? 2 : 0), st);
     if (e != hipSuccess) return (int)e;
   }
   if (dense) {

@@ -330,6 +330,9 @@ __global__ __launch_bounds__(256) void k_prep_f16(PrepArgs a) {
   const int rows = img1 ? a.S : a.L, rows_pad = img1 ? a.Sp : a.Lp;
   const int b = (int)(rb * 32 / rows_pad);
   if (!a.force && a.dense_cnt[b] == 0) return;                 // uniform
+  // (force 2 - the conf sweep alone wants the planes: a sample the screening kernel served gets the hi plane only, its
+  // sweep is k_dense<C, CONF_LITE>)
+  const bool want_lo = a.force != 2 || a.dense_cnt[b] > 0;
   // largest |x| of both images of this sample (block maxima of k_prep_split)
   __shared__ float wred[2][4];
   float m0 = 0.f, m1 = 0.f;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void k_prep_f16(PrepArgs a) {
     const int h = q / KSTEPS, ks = q - h * KSTEPS;
     const long off = (((rb * KSTEPS + ks) * 2 + h) * 32 + r) * 8;
     *reinterpret_cast<half8*>(hi + off) = hh;
-    *reinterpret_cast<half8*>(lo + off) = ll;
+    if (want_lo) *reinterpret_cast<half8*>(lo + off) = ll;
   }
 }
 
