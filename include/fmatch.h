@@ -130,7 +130,11 @@ int fm_coarse_workspace_bytes_mode(int N, int L, int S, int C, int cand_slots, i
  *   FM_MODE_DENSE adds the float16 planes and the dense sum kernel for flagged samples, FM_MODE_EXACT_SCREENING
  *   (implies FM_MODE_DENSE) two more kernels that repeat the screening with the exact softmax denominators, after
  *   which at most 1/thr entries of a row can be candidates; all of them are decided on the device and exit at once
- *   when not needed.  A conf_matrix request implies both.
+ *   when not needed.  A conf_matrix request implies FM_MODE_DENSE (the sweep reads the float16 planes).  Every entry
+ *   of the matrix is within 1e-5 of the float32 reference: entries on a screened sample's lists of significant entries,
+ *   and the entries with conf > 0.1 of a sample with flat similarity together with the denominators that contain them,
+ *   come from exact float32 dot products; for that the candidate lists of such a sample go down to min(thr, 0.1) - up
+ *   to ~10 candidates per row: pass cand_slots >= 16 on flat data (fm_coarse_match_auto does).
  */
 int fm_coarse_match(const float* feat0, const float* feat1, int N, int L, int S, int C,
                     int h0c, int w0c, int h1c, int w1c,
