@@ -1071,6 +1071,29 @@ def test_dense_conf_matrix_keeps_the_rows_of_textureless_cells():
     assert float(tiny.max()) < 1e-4 and ((got[0, 0] - tiny).abs() <= 1e-3 * tiny.abs() + 1e-12).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conf_matrix_of_a_batch_with_a_screened_and_a_flat_sample(dtype):
+    """One call, two samples: sample 0 is served by the screening kernel (its conf sweep is the one-product CONF_LITE
+    variant, its listed entries are rewritten from exact dot products), sample 1 has textureless cells and goes through
+    the dense kernel (hi/lo-split sweep; k_exact_lists + k_fix_sums make its listed entries and their denominators exact
+    together).  Both against the oracle on the same (for bfloat16: up-cast) descriptors at 1e-5, at similarities of ~200."""
+    f0, f1 = synth.coarse_descriptors(53, 2, 20 * 30, 128, "peaky")
+    f0[1, ::3] *= 1e-4
+    f1[1, 1::3] *= 1e-4
+    t0, t1 = torch.as_tensor(f0, device=DEV).to(dtype), torch.as_tensor(f1, device=DEV).to(dtype)
+    g0, g1 = t0.float().cpu().numpy(), t1.float().cpu().numpy()
+    ref = orc.coarse_match(g0, g1, (160, 240), (20, 30), (20, 30), 0.2, 2, 0.1, return_conf=True)
+    out = ops.coarse_match(t0, t1, (20, 30), (20, 30), 8.0, conf_matrix=True)
+    _assert_coarse(out, ref)
+    got = out['conf_matrix'].cpu()
+    smax = float(np.abs(g0[0].astype(np.float64) @ g1[0].astype(np.float64).T).max()) / (128 * 0.1)
+    assert smax > 100
+    for b in range(2):
+        assert (got[b] - ref['conf_matrix'][b]).abs().max().item() <= 1e-5, b
+    pick = got[out['b_ids'].cpu(), out['i_ids'].cpu(), out['j_ids'].cpu()]
+    assert (pick - out['mconf'].cpu()).abs().max().item() <= 2e-6
+
+
 def test_dense_conf_matrix_and_training_ids():
     f0, f1 = synth.coarse_descriptors(91, 2, 23 * 31, 256, "borderline")       # ragged L = S = 713
     hw_c, hw_i = (23, 31), (184, 248)
