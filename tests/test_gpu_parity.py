@@ -1307,6 +1307,27 @@ def test_dense_conf_matrix_entries_that_matter_take_the_exact_route():
     assert smax > 100            # (where the 22-bit route alone would be ~2^-22 * 160 = 4e-5 off)
 
 
+def test_conf_matrix_at_the_bench_size_one_product_sweep():
+    """The conf sweep of a sample the screening kernel served is ONE float16 product (k_dense<C, CONF_LITE>): everything
+    that matters is on a row's list and rewritten exactly, the rest is below 2^-32 of its row's largest term.  At the
+    bench's size (one 640x480 pair, L = S = 4800, C = 256, |sim| ~ 200) against the oracle's float32 matrix: 1e-5 in
+    every entry; the listed entries (conf > 1e-6 here) also RELATIVE to 1e-4; no entry that the reference has below
+    1e-9 comes out above 1e-8."""
+    cfg = dict(synth.CONFIGS["cfg2"], n=1)
+    sh = synth.config_shapes(cfg)
+    f0, f1 = synth.coarse_descriptors(4711, 1, sh['l'], cfg['c'], "peaky")
+    hw_c, hw_i = (sh['hc'], sh['wc']), (cfg['h'], cfg['w'])
+    ref = orc.coarse_match(f0, f1, hw_i, hw_c, hw_c, 0.2, 2, 0.1, return_conf=True)
+    out = ops.coarse_match(torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV), hw_c, hw_c, 8.0, conf_matrix=True)
+    _assert_coarse(out, ref)
+    got, want = out['conf_matrix'].cpu(), ref['conf_matrix']
+    assert (got - want).abs().max().item() <= 1e-5
+    big = want > 1e-6
+    assert int(big.sum()) >= ref['mconf'].shape[0]
+    assert ((got[big] - want[big]).abs() <= 1e-4 * want[big] + 1e-7).all()
+    assert float(got[want < 1e-9].max()) < 1e-8
+
+
 def test_gt_padding_sampler():
     """The older training sampler (network/utils/coarse_matching.py:114-141): predicted matches (sub-sampled when
     there are too many) followed by randomly drawn ground-truth matches with mconf = 0; gt_mask marks them and
