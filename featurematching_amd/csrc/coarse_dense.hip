@@ -317,34 +317,35 @@ __global__ __launch_bounds__(512) void k_dense(DenseArgs a) {
             // occupancy reaches 5.5 (tools/microbench_store_pattern.hip).  Tried without effect: counting the stores in
             // the per-unit vmcnt wait instead of draining them, the SIMD's two waves storing in alternate halves of the
             // k-steps, the conf value formed in the accumulator register (no write-after-read on the store's data),
-            // nontemporal stores (slower: 7070).)
+            // nontemporal stores (slower there: 7070).)
             // conf of register g's entry and its store: rows (g & 3) + 8 (g >> 2) [+ 4 for the upper half], column r
             float t1, t2;
             const char* rowbase = conf_base + (long)((g & 3) + 8 * (g >> 2)) * conf_pitch;      // (wave-uniform: scalar)
             if (conf_full) {
-              asm volatile(
-                  "v_fma_f32 %[t1], %[x], %[kq], %[nm]\n\t"
-                  "v_fma_f32 %[t2], %[x], %[kq], %[nmc]\n\t"
-#ifndef FM_ABL_CONF_NOEXP        // timing-only ablations (results are wrong): never defined in the shipped build
-                  "v_exp_f32 %[t1], %[t1]\n\t"
-                  "v_exp_f32 %[t2], %[t2]\n\t"
-                  "s_nop 0\n\t"
-#endif
-                  "v_mul_f32 %[t1], %[t1], %[t2]\n\t"
-#ifndef FM_ABL_CONF_NOSTORE
-#if defined(FM_CONF_STORE_SC01)   // experiments (round 5): cache-policy bits on the store
-                  "global_store_dword %[vo], %[t1], %[sb] sc0 sc1"
-#elif defined(FM_CONF_STORE_SC1)
-                  "global_store_dword %[vo], %[t1], %[sb] sc1"
-#elif defined(FM_CONF_STORE_NT)
-                  "global_store_dword %[vo], %[t1], %[sb] nt"
+              // (nontemporal stores in the one-product sweep, whose limit is the memory stream: 3.05 -> 2.84 ms for the whole
+              // conf stage at cfg#3; in the hi/lo-split sweep, which the matrix cores' power budget clocks down, they cost time:
+              // 7070 against 6410 cycles per unit)
+#if defined(FM_ABL_CONF_NOEXP)           // timing-only ablations (results are wrong): never defined in the shipped build
+#define FM_CONF_EXP ""
 #else
-                  "global_store_dword %[vo], %[t1], %[sb]"
+#define FM_CONF_EXP "v_exp_f32 %[t1], %[t1]\n\tv_exp_f32 %[t2], %[t2]\n\ts_nop 0\n\t"
 #endif
+#if defined(FM_ABL_CONF_NOSTORE)
+#define FM_CONF_STORE(POLICY) ""
+#else
+#define FM_CONF_STORE(POLICY) "global_store_dword %[vo], %[t1], %[sb]" POLICY
 #endif
-                  : [t1] "=&v"(t1), [t2] "=&v"(t2)
-                  : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [vo] "v"(conf_voff), [sb] "s"(rowbase)
-                  : "memory");
+#define FM_CONF_SLICE(POLICY)                                                                                              \
+  asm volatile("v_fma_f32 %[t1], %[x], %[kq], %[nm]\n\t"                                                                   \
+               "v_fma_f32 %[t2], %[x], %[kq], %[nmc]\n\t" FM_CONF_EXP "v_mul_f32 %[t1], %[t1], %[t2]\n\t" FM_CONF_STORE(POLICY) \
+               : [t1] "=&v"(t1), [t2] "=&v"(t2)                                                                            \
+               : [x] "v"(accC[g]), [kq] "v"(kqv), [nm] "v"(nmsel[g]), [nmc] "v"(nmc_c), [vo] "v"(conf_voff), [sb] "s"(rowbase) \
+               : "memory")
+              if constexpr (LITE) FM_CONF_SLICE(" nt");
+              else FM_CONF_SLICE("");
+#undef FM_CONF_SLICE
+#undef FM_CONF_STORE
+#undef FM_CONF_EXP
             }
           } else if constexpr (RESCREEN) {
             // log2 P_row and log2 P_col of register g's entry against log2 thr: the hit goes into the lane's bit mask
