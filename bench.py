@@ -1165,7 +1165,7 @@ def extras(a, wl, dev, streams, flops):
                 "conf_matrix_max_abs_err_sample0": cerr, "error_bar": cbar, "largest_abs_similarity": round(smax, 1),
                 "verified": bool(cerr <= cbar),
                 "note": "coarse stage with data['conf_matrix'] requested (FM_MODE_DENSE | exact screening off): prep, max "
-                        "pass, screening, float16 planes, denominator reduction, dense conf sweep (k_dense<256, CONF>: the "
+                        "pass, screening, float16 planes, denominator reduction, dense conf sweep (k_dense<256, CONF_LITE> - one float16 product for screened samples, hi/lo-split k_dense<256, CONF> for flat ones: the "
                         "5.9 GB write) + exact rewrite of the entries that matter (k_conf_patch), assignment; GB/s = conf_matrix bytes over the WHOLE stage's time"}
             return res
         guarded("cfg3", cfg3_line)
