@@ -18,9 +18,16 @@ def main():
         from featurematching_amd import _lib
         _lib.load(os.path.abspath(sys.argv[at + 1]))
         del sys.argv[at:at + 2]
+    dist = 'peaky'
+    if '--dist' in sys.argv:           # 'borderline': every sample goes through the dense kernel and the hi/lo-split sweep
+        at = sys.argv.index('--dist')
+        dist = sys.argv[at + 1]
+        del sys.argv[at:at + 2]
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     wl = dict(bench.WORKLOADS["cfg3"], n=n)
-    p = bench.Pair(wl, 4242, 5, dev, "peaky", device_data=True)
+    p = bench.Pair(wl, 4242, 5, dev, dist, device_data=True)
+    if dist != "peaky":
+        p.slots = 16
     p.conf_matrix, p.dense, p.stages, p.fuse_maps = True, True, "coarse", False
     p.step()
     p.step()
