@@ -942,7 +942,8 @@ def main():
     traffic, traffic_src = committed_traffic(a.workload)
     copy_gbs = copy_rate(crop_bytes, dev)
     maps_path = pairs[0].fine_path == "maps"
-    launches = 4 + (2 if pairs[0].dense and not pairs[0].flat else 0) + \
+    # (the common path's five: prep, max pass, thresholds, screening, assignment)
+    launches = 5 + (2 if pairs[0].dense and not pairs[0].flat else 0) + \
         ((2 if a.layout == "nchw" and not pairs[0].fuse_maps else 1) if maps_path else (3 if a.layout == "nhwc" else 2))
     map_bytes = 2.0 * wl["n"] * cf * 4 * sh0["hf"] * sh0["wf"]           # both fine maps
     out = {
@@ -1211,9 +1212,9 @@ def extras(a, wl, dev, streams, flops):
                 del p
             rate, ver, m_pp = stream_rate(wl, a.window, dev, "peaky", 1, 4, steps=600, nsets=8, layout="nhwc", fine_path="maps")
             res.update({"value": round(rate, 2), "unit": "image-pairs/s", "verified": ver["ok"] if ver else None,
-                        "verification": ver, "launches_per_step": 5,
+                        "verification": ver, "launches_per_step": 6,
                         "note": "the metric's step with channels-last fine maps (what a backbone that keeps its [B,H,W,C] "
-                                "activations hands over): coarse stage (4 launches) + k_fine_maps; 4 streams"})
+                                "activations hands over): coarse stage (5 launches) + k_fine_maps; 4 streams"})
             return res
         guarded("channels_last_maps", cl_line)
 
