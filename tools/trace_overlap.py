@@ -27,8 +27,15 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n.split("fm::")[-1].split("(")[0],
                          r.get("Queue_Id", "0"), r.get("Stream_Id", "0")))
     rows.sort()
-    # the timed part: the last 60 % of the launches
-    rows = rows[int(len(rows) * 0.4):]
+    # the densest 10 ms of the trace (a bench run is mostly host-side pauses between its timed regions)
+    starts = np.array([r[0] for r in rows])
+    win = 10_000_000
+    best, at = 0, 0
+    for i in range(0, len(rows), 50):
+        n = int(np.searchsorted(starts, starts[i] + win)) - i
+        if n > best:
+            best, at = n, i
+    rows = [r for r in rows[at:at + best]]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     print(f"{len(rows)} launches over {(t1 - t0) / 1e3:.0f} us")
     dur = defaultdict(list)
@@ -57,6 +64,9 @@ def main():
     for q, v in byq.items():
         for (s0, e0, n0), (s1, e1, n1) in zip(v, v[1:]):
             gaps[f"{n0} -> {n1}"].append((s1 - e0) / 1e3)
+    for q, v in sorted(byq.items()):
+        span = v[-1][1] - v[0][0]
+        print(f"  queue {q}: {len(v)} kernels, busy {sum(e - s for s, e, _ in v) / span:.3f} of its span")
     print(f"  {len(byq)} queues/streams; gaps between consecutive kernels of a queue:")
     for k, v in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:12]:
         print(f"    {k:60s} n {len(v):5d}  median {np.median(v):6.2f} us  mean {np.mean(v):6.2f}")
