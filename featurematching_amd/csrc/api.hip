@@ -391,6 +391,7 @@ extern "C" int fm_coarse_match_auto(const void* feat0, const void* feat1, int in
   if (full_stats) cur |= FM_MODE_EXACT_SCREENING;        // (that path runs the denominator reduction the re-screening needs anyway)
   int slots = slots0;
   if (conf_matrix && slots < 16 && max_cand_slots >= 16) slots = 16;     // (its dense lists go down to conf 0.1: <= 10 + band per row)
+  const int slots_start = slots;                         // what this REQUEST starts with: not something the data taught
   if (hint_io && *hint_io) {                             // what served the previous call of this kind
     cur |= *hint_io & kAutoDataModes;
     const int hs = (*hint_io >> 8) & 0xff;
@@ -451,7 +452,11 @@ extern "C" int fm_coarse_match_auto(const void* feat0, const void* feat1, int in
     if ((learnt & FM_MODE_DENSE) && !full_stats) {
       if (info & FM_DEV_ALL_DENSE) learnt |= FM_MODE_FLAT; else learnt &= ~FM_MODE_FLAT;
     }
-    *hint_io = learnt | (slots != slots0 ? slots << 8 : 0) | (attempts << 24);
+    // second byte: the slots the DATA asked for beyond this request's own starting point (0 = none: a conf_matrix
+    // call's 16 are implied by the request and must not follow plain calls of the shape); third byte: the slot count
+    // the serving attempt ran with - ALWAYS written (the workspace layout fm_coarse_cell_maps / fm_coarse_softmax_stats
+    // must be asked for), ignored on input
+    *hint_io = learnt | (slots != slots_start ? slots << 8 : 0) | (slots << 16) | (attempts << 24);
   }
   return st;
 }

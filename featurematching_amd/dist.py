@@ -40,25 +40,30 @@ def pack_records(b_ids: torch.Tensor, kpts0: torch.Tensor, kpts1: torch.Tensor, 
     return rec
 
 
-def gather_match_lists(records: torch.Tensor, group=None) -> torch.Tensor:
+def gather_match_lists(records: torch.Tensor, group=None, always_exchange: bool = False) -> torch.Tensor:
     """All ranks receive the concatenation (rank-major, each rank's order preserved) of every
-    rank's records - identical to a single process run on the concatenated batch."""
+    rank's records - identical to a single process run on the concatenated batch.
+
+    Two collectives on the records' device (RCCL for device tensors, gloo for CPU ones): the per-rank counts into one
+    [world] tensor - read back with ONE host copy, the sync the padding needs - and the records padded to the largest
+    count into one [world * cap, 6] tensor (utils/comm.py:113-176's pad-to-largest scheme).  A world of one returns its
+    records as they are unless `always_exchange` (the single-GPU rehearsal of the N-rank path: both collectives run)."""
     if not (dist.is_available() and dist.is_initialized()):
         return records
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not always_exchange:
         return records
     dev = records.device
     count = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(count) for _ in range(world)]
-    dist.all_gather(counts, count, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts_t = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, count, group=group)
+    counts = counts_t.tolist()                       # one device -> host copy for all ranks' counts
     cap = max(counts)
     padded = torch.zeros(cap, RECORD, dtype=torch.int32, device=dev)
     padded[:records.shape[0]] = records
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    bufs = torch.empty(world * cap, RECORD, dtype=torch.int32, device=dev)       # rank r's block = rows [r cap, (r+1) cap)
+    dist.all_gather_into_tensor(bufs, padded, group=group)
+    return torch.cat([bufs[r * cap:r * cap + c] for r, c in enumerate(counts)], dim=0)
 
 
 def unpack_records(rec: torch.Tensor):

@@ -265,7 +265,17 @@ class HintMemory:
             return {k: dict(self.decode(v[0]), calls=v[1], hint=v[0]) for k, v in self._d.items()}
 
 
+def hint_key(shape0, shape1, thr=0.2, temperature=0.1, dtype=torch.float32, conf_matrix=False, stats=False):
+    """The problem kind MODE_MEMORY keys a hint word by: shapes, thr, temperature, descriptor dtype, and whether the call
+    asks for the conf_matrix / the softmax statistics (such a call starts at 16 slots and runs the denominator
+    reduction whatever the data: its word must not follow plain inference calls of the same shape, nor the reverse)."""
+    return (tuple(shape0), tuple(shape1), float(thr), float(temperature), dtype, bool(conf_matrix), bool(stats))
+
+
 MODE_MEMORY = HintMemory()
+# how often a correct-but-slow route served a call in this process (bench.py prints them in `extra.slow_paths`, so a
+# silent detour shows in the record): the torch formula of the conf_matrix backward (three [N,L,S] temporaries)
+SLOW_PATHS = {"conf_matrix_grad_torch_formula": 0}
 _AUTO_WS_BYTES = {}
 
 
@@ -290,7 +300,7 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
     if f1.shape[0] != n or f1.shape[2] != c:
         raise ValueError(f"feat_c0 {tuple(f0.shape)} and feat_c1 {tuple(f1.shape)} disagree")
     dev = f0.device
-    key = (tuple(feat_c0.shape), tuple(feat_c1.shape), float(thr), float(temperature))
+    key = hint_key(feat_c0.shape, feat_c1.shape, thr, temperature, f0.dtype, conf_matrix, stats)
     managed = exact_screening is None and dense is None and exact_step is None and flat is None
     mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
            (_lib.FM_MODE_EXACT_STEP if exact_step else 0) | (_lib.FM_MODE_FLAT if flat else 0) | \
@@ -335,7 +345,7 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
         if managed:
             MODE_MEMORY.finish(key, int(hint.value))
         h = int(hint.value)
-        slots_used = ((h >> 8) & 0xff) or int(lib.fm_default_cand_slots(float(thr)))
+        slots_used = (h >> 16) & 0xff          # the slot count the serving attempt ran with (always written)
         out.info, out.hint, out.attempts = int(info.value), h & 0xffff, (h >> 24) & 0xff
         out._keep = (f0, f1, sc0, sc1)
         out._shape = (n, l, s, c, slots_used)
@@ -472,6 +482,7 @@ class _ConfMatrixGrad(torch.autograd.Function):
                 d0, d1 = _dsm_backward_dense(f0, f1, ctx.temperature, ctx.buffers, grad)
             return d0, d1, None, None, None
         import warnings
+        SLOW_PATHS["conf_matrix_grad_torch_formula"] += 1
         warnings.warn("attach_conf_matrix_grad without the forward call's buffers: the torch formula (three [N,L,S] temporaries)")
         k = 1.0 / (f0.shape[-1] * ctx.temperature)
         sim = torch.bmm(f0.float(), f1.float().transpose(1, 2)) * k

@@ -205,8 +205,10 @@ int fm_coarse_match_maps(const void* feat0, const void* feat1, int in_dtype, int
  *   conf_matrix: optional [dev] float32 [N,L,S] or NULL, as in fm_coarse_match.
  *   hint_io: optional HOST int32.  In: 0, or the value a previous call on data of this kind left there - the call
  *            then starts where that one ended (flat data: FM_MODE_FLAT, no screening sweep; ...).  Out: the mode bits
- *            (low byte) and cand_slots (second byte, 0 = default) that served this call, and the number of coarse
- *            launches sequences it took (fourth byte, informational).  A hint is never wrong, only possibly slower
+ *            (low byte) and the cand_slots the data asked for beyond the request's own default (second byte, 0 = none)
+ *            that served this call, the slot count the serving attempt actually ran with (third byte, always set,
+ *            ignored on input: the `cand_slots` to pass to fm_coarse_cell_maps / fm_coarse_softmax_stats for this
+ *            workspace), and the number of coarse launch sequences it took (fourth byte, informational).  A hint is never wrong, only possibly slower
  *            than the common path: pass 0 every so often to find out whether the data has changed (the Python layer
  *            does, every 64th call of a shape).
  *   info_out: optional, the raw FM_DEV_* status bits of the attempt that served the call.

@@ -103,6 +103,81 @@ def ref_fine(win0, win1, data, mix, hw0_f):
     return d['mkpts0_f'], d['mkpts1_f']
 
 
+def ref_fine_w(win0, win1, data, mix, hw0_f, ww):
+    """The reference's FineMatching at another window size: fine_matching_new.py:22-79 derives W from the windows'
+    WW (:34); only the two nn.Linear(49, 1) of :18-19 fix 49.  Construct the module as the reference does, swap the
+    two layers for nn.Linear(ww, 1) holding the seeded weights, run its UNMODIFIED forward."""
+    fm = FineMatching({'d_model': win0.shape[-1] if win0.shape[0] else 64}).eval()
+    fm.mix_feat_0 = torch.nn.Linear(ww, 1, bias=True)
+    fm.mix_feat_1 = torch.nn.Linear(ww, 1, bias=True)
+    with torch.no_grad():
+        fm.mix_feat_0.weight.copy_(torch.as_tensor(mix[0]).view(1, -1)); fm.mix_feat_0.bias.fill_(float(mix[1]))
+        fm.mix_feat_1.weight.copy_(torch.as_tensor(mix[2]).view(1, -1)); fm.mix_feat_1.bias.fill_(float(mix[3]))
+        d = dict(data, hw0_f=hw0_f)
+        fm(win0, win1, d)
+    return d['mkpts0_f'], d['mkpts1_f']
+
+
+def w5_case(name, cfgname, dist, w=5):
+    """What the metric times (BASELINE.json config 2: 640x480, C = 256, 5x5 fine window) through the reference: its
+    CoarseMatching, its FinePreprocess unfold + select at W = 5 (fine_preprocess.py:43-50) and its FineMatching.forward
+    with Linear(25, 1) position mixes.  Stored: the coarse outputs, the fine keypoints [M,3], per-window checksums."""
+    cfg = dict(synth.CONFIGS[cfgname])
+    sh = synth.config_shapes(cfg)
+    f0, f1 = synth.coarse_descriptors(cfg['seed'], cfg['n'], sh['l'], cfg['c'], dist)
+    hw_i, hw_c = (cfg['h'], cfg['w']), (sh['hc'], sh['wc'])
+    data = ref_coarse(f0, f1, hw_i, hw_i, hw_c, hw_c)
+    out = pack_coarse(data)
+    ff0, ff1 = synth.fine_maps(cfg['seed'], cfg['n'], cfg['cf'], sh['hf'], sh['wf'])
+    mix = synth.mix_weights(cfg['seed'], w * w)
+    w0, w1 = ref_windows(ff0, ff1, data, w)
+    assert w0.shape[1] == w * w
+    k0, k1 = ref_fine_w(w0, w1, data, mix, (sh['hf'], sh['wf']), w * w)
+    pos = torch.arange(1, w * w + 1, dtype=torch.float64).view(1, w * w, 1)
+    ch = torch.arange(1, cfg['cf'] + 1, dtype=torch.float64).view(1, 1, -1)
+    out.update(mkpts0_f=k0.numpy(), mkpts1_f=k1.numpy(),
+               win0_sum=(w0.double() * pos * ch).sum((1, 2)).numpy(), win1_sum=(w1.double() * pos * ch).sum((1, 2)).numpy(),
+               meta=np.array([cfg['n'], cfg['h'], cfg['w'], cfg['c'], cfg['cf'], cfg['seed'], w], np.int64))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: M={out['i_ids'].shape[0]} fine offsets in [{float((k0[:, :2] - data['mkpts0_c']).min()):.2f}, "
+          f"{float((k0[:, :2] - data['mkpts0_c']).max()):.2f}] px")
+
+
+def batch_summary_case(name, cfgname, dist):
+    """cfg#3 at its size: ALL samples of the batch through the reference's CoarseMatching, one sample at a time
+    (coarse_matching_new.py:43-143 has no cross-sample term), and only a summary per sample stored: M, SHA-256 of the
+    (i, j) ids as little-endian int32 pairs in the reference's order, min / max / float64 sum of mconf, float64 sums
+    of the coarse keypoints.  Matches whose conf lies within 1e-4 of thr (where float32 re-orderings may flip the
+    decision: the tests' guard band) are listed explicitly (`band`: b, i, j + conf) and left OUT of the hashes.  The GPU
+    test regenerates the inputs from synth and compares its batch call with it."""
+    import hashlib
+    cfg = dict(synth.CONFIGS[cfgname])
+    sh = synth.config_shapes(cfg)
+    hw_i, hw_c = (cfg['h'], cfg['w']), (sh['hc'], sh['wc'])
+    ms, shas, cmin, cmax, csum, ksum = [], [], [], [], [], []
+    band, band_conf = [], []
+    for b in range(cfg['n']):
+        f0, f1 = synth.coarse_descriptors(cfg['seed'] + b, 1, sh['l'], cfg['c'], dist)
+        d = ref_coarse(f0, f1, hw_i, hw_i, hw_c, hw_c)
+        ij = np.stack([d['i_ids'].numpy(), d['j_ids'].numpy()], 1).astype('<i4')
+        mc = d['mconf'].numpy()
+        inb = np.abs(mc - 0.2) < 1e-4
+        for (i, j), cval in zip(ij[inb], mc[inb]):
+            band.append((b, int(i), int(j))); band_conf.append(cval)
+        ij, mc = ij[~inb], mc[~inb]
+        kp0, kp1 = d['mkpts0_c'].numpy()[~inb], d['mkpts1_c'].numpy()[~inb]
+        ms.append(ij.shape[0]); shas.append(hashlib.sha256(ij.tobytes()).hexdigest())
+        cmin.append(mc.min() if len(mc) else 0.0); cmax.append(mc.max() if len(mc) else 0.0)
+        csum.append(mc.astype(np.float64).sum())
+        ksum.append([kp0.astype(np.float64).sum(), kp1.astype(np.float64).sum()])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), m=np.array(ms, np.int64), sha256=np.array(shas),
+                        mconf_min=np.array(cmin, np.float32), mconf_max=np.array(cmax, np.float32),
+                        mconf_sum=np.array(csum, np.float64), kpts_sum=np.array(ksum, np.float64),
+                        band=np.array(band, np.int32).reshape(-1, 3), band_conf=np.array(band_conf, np.float32),
+                        meta=np.array([cfg['n'], cfg['h'], cfg['w'], cfg['c'], cfg['cf'], cfg['seed']], np.int64))
+    print(f"{name}: {cfg['n']} samples, M in [{min(ms)}, {max(ms)}] outside the band, total {sum(ms)}; within 1e-4 of thr: {len(band)}")
+
+
 def pack_coarse(data):
     return dict(b_ids=data['b_ids'].numpy().astype(np.int32), i_ids=data['i_ids'].numpy().astype(np.int32),
                 j_ids=data['j_ids'].numpy().astype(np.int32), mconf=data['mconf'].numpy(),
@@ -483,6 +558,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "net_tail":
         net_tail_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r6":     # the fixtures added in round 6 only
+        w5_case("cfg2_peaky_w5", "cfg2", "peaky")
+        w5_case("cfg2_borderline_w5", "cfg2", "borderline")
+        batch_summary_case("cfg3_all64_peaky", "cfg3", "peaky")
+        batch_summary_case("cfg3_all64_borderline", "cfg3", "borderline")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r5":     # the fixtures added in round 5 only
         net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)
         full_attention_case()
@@ -521,3 +602,8 @@ if __name__ == "__main__":
     net_tail_case("net_tail_cfg2", NET_TAIL_CFG2)
     full_attention_case()
     masked_coarse_transformer_case()
+    # round 6: the metric's own fine configuration (W = 5) and cfg#3 at its size (all 64 samples) through the reference
+    w5_case("cfg2_peaky_w5", "cfg2", "peaky")
+    w5_case("cfg2_borderline_w5", "cfg2", "borderline")
+    batch_summary_case("cfg3_all64_peaky", "cfg3", "peaky")
+    batch_summary_case("cfg3_all64_borderline", "cfg3", "borderline")

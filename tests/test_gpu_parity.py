@@ -137,6 +137,87 @@ def test_bench_path_against_reference_fixture(name, dist, layout):
 
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("name,dist", [("cfg2_peaky_w5", "peaky"), ("cfg2_borderline_w5", "borderline")])
+def test_headline_step_w5_at_cfg2_against_reference_fixture(name, dist, layout):
+    """What the metric times, pinned to the REFERENCE: one 640x480 pair, 5x5 fine window (BASELINE.json configs[1]).
+    fine_matching_new.py:22-79 derives W from WW (:34); only the nn.Linear(49, 1) of :18-19 fix 49 - make_golden.py swaps
+    them for Linear(25, 1) after construction and runs the reference's unmodified forward on its own W = 5 unfold
+    (fine_preprocess.py:43-50).  fm_coarse_match + fm_fine_match_maps (NCHW and channels-last) against those outputs;
+    the crops through fm_gather_windows against the per-window checksums."""
+    g = load_golden(name)
+    assert int(g['meta'][6]) == 5
+    inp = case_inputs(g['meta'][:6], dist, ww=25)
+    out = _run_coarse(inp['f0'], inp['f1'], inp['hw_i'], inp['hw_c'], inp['hw_c'])
+    ndiff = _assert_coarse(out, g)
+    assert ndiff <= 4, f"{ndiff} guard-band flips"
+    gi, ri, nref = _common_rows(out, g)
+    assert len(gi) >= nref - 4 and nref > 3000
+    ff0, ff1 = _maps(inp, layout)
+    mix0, mix1 = _mix_tensors(inp['mix'])
+    wc = inp['hw_c'][1]
+    k0, k1 = ops.fine_match_maps(ff0, ff1, out['b_ids'], out['i_ids'], out['j_ids'], 5, 4, wc, wc, mix0, mix1,
+                                 out['mkpts0_c'], out['mkpts1_c'], inp['hw_i'][0] / inp['hw_f'][0])
+    assert k0.shape[1] == 3
+    assert np.abs(k0.cpu().numpy()[gi, :2] - g['mkpts0_f'][ri, :2]).max() <= FINE_TOL_PX
+    assert np.abs(k1.cpu().numpy()[gi, :2] - g['mkpts1_f'][ri, :2]).max() <= FINE_TOL_PX
+    np.testing.assert_allclose(k0.cpu().numpy()[gi, 2], g['mkpts0_f'][ri, 2], atol=1e-4)
+    np.testing.assert_allclose(k1.cpu().numpy()[gi, 2], g['mkpts1_f'][ri, 2], atol=1e-4)
+    win0 = ops.gather_windows(ff0, out['b_ids'], out['i_ids'], 5, 4, wc)
+    win1 = ops.gather_windows(ff1, out['b_ids'], out['j_ids'], 5, 4, wc)
+    pos = torch.arange(1, 26, dtype=torch.float64, device=DEV).view(1, 25, 1)
+    ch = torch.arange(1, 65, dtype=torch.float64, device=DEV).view(1, 1, -1)
+    np.testing.assert_allclose((win0.double() * pos * ch).sum((1, 2)).cpu().numpy()[gi], g['win0_sum'][ri], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose((win1.double() * pos * ch).sum((1, 2)).cpu().numpy()[gi], g['win1_sum'][ri], rtol=1e-12, atol=1e-9)
+    # ... and the two-call form on window tensors gives the fused call's numbers
+    q0, q1 = ops.fine_match(win0, win1, mix0, mix1, out['mkpts0_c'], out['mkpts1_c'], inp['hw_i'][0] / inp['hw_f'][0])
+    assert torch.equal(q0, k0) and torch.equal(q1, k1)
+
+
+@pytest.mark.parametrize("name,dist", [("cfg3_all64_peaky", "peaky"), ("cfg3_all64_borderline", "borderline")])
+def test_cfg3_all_64_samples_against_the_reference_summary(name, dist):
+    """BASELINE config #3 AT ITS SIZE against the reference: all 64 samples went through coarse_matching_new.py:43-143
+    one at a time (make_golden.py:batch_summary_case) and left per-sample M, SHA-256 of the (i, j) ids in the
+    reference's order, min / max / sum of mconf, sums of the coarse keypoints; matches within 1e-4 of thr are listed
+    explicitly and excluded from the hashes (the guard band).  ONE batched fm_coarse_match_auto call is compared."""
+    import hashlib
+    g = load_golden(name)
+    n, h, w, c, cf, seed = [int(v) for v in g['meta']]
+    assert n == 64
+    sh = synth.config_shapes(dict(h=h, w=w))
+    hw_c = (sh['hc'], sh['wc'])
+    f0 = torch.empty(n, sh['l'], c, device=DEV)
+    f1 = torch.empty_like(f0)
+    for b in range(n):                 # (sample b of the batch = seed + b: what coarse_descriptors(seed, 64, ...) returns)
+        a0, a1 = synth.coarse_descriptors(seed + b, 1, sh['l'], c, dist)
+        f0[b], f1[b] = torch.as_tensor(a0[0]), torch.as_tensor(a1[0])
+    out = _np(ops.coarse_match(f0, f1, hw_c, hw_c, h / sh['hc']))
+    band = {(int(b), int(i), int(j)): float(cv) for (b, i, j), cv in zip(g['band'], g['band_conf'])}
+    flips = 0
+    for b in range(n):
+        sel = out['b_ids'] == b
+        ij = np.stack([out['i_ids'][sel], out['j_ids'][sel]], 1)
+        mc, kp0, kp1 = out['mconf'][sel], out['mkpts0_c'][sel], out['mkpts1_c'][sel]
+        listed = np.array([(b, int(i), int(j)) in band for i, j in ij], bool)
+        inside = (np.abs(mc - 0.2) < GUARD) & ~listed       # a flip INTO the set is only legal inside the guard band
+        flips += int(inside.sum())
+        for (i, j), cv in zip(ij[listed], mc[listed]):
+            assert abs(cv - band[(b, int(i), int(j))]) <= CONF_TOL
+        missing = [k for k in band if k[0] == b and not ((ij[:, 0] == k[1]) & (ij[:, 1] == k[2])).any()]
+        for k in missing:                                   # a flip OUT of the set likewise
+            assert abs(band[k] - 0.2) < GUARD, f"reference match {k} (conf {band[k]}) is missing"
+        flips += len(missing)
+        keep = ~(listed | inside)
+        assert int(keep.sum()) == int(g['m'][b]), f"sample {b}: M {int(keep.sum())} vs reference {int(g['m'][b])}"
+        assert hashlib.sha256(ij[keep].astype('<i4').tobytes()).hexdigest() == str(g['sha256'][b]), f"sample {b}: ids differ"
+        assert abs(float(mc[keep].min()) - float(g['mconf_min'][b])) <= CONF_TOL
+        assert abs(float(mc[keep].max()) - float(g['mconf_max'][b])) <= CONF_TOL
+        assert abs(mc[keep].astype(np.float64).sum() - g['mconf_sum'][b]) <= CONF_TOL * max(1, int(keep.sum()))
+        assert kp0[keep].astype(np.float64).sum() == g['kpts_sum'][b, 0] and kp1[keep].astype(np.float64).sum() == g['kpts_sum'][b, 1]
+    FLIPS.append((f"test_cfg3_all_64_samples[{name}]", flips, int(g['m'].sum()) + len(band), 0.0))
+    assert flips <= 4
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
 def test_headline_step_w5_at_cfg2_against_oracle(layout):
     """The metric's own configuration - one 640x480 pair, 5x5 fine window (BASELINE.json configs[1]) - through the
     calls bench.py times.  The reference's fine_matching_new.py cannot run W = 5 (nn.Linear(49, 1)); the oracle (pinned
@@ -196,7 +277,7 @@ def test_mode_memory_learns_the_wider_lists_on_mixed_data():
     inp = case_inputs(g['meta'], "mixed", with_fine=False)
     t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
     ops.MODE_MEMORY.clear()
-    key = (tuple(t0.shape), tuple(t1.shape), 0.2, 0.1)
+    key = ops.hint_key(t0.shape, t1.shape)
     outs = [ops.coarse_match(t0, t1, inp['hw_c'], inp['hw_c'], 8.0) for _ in range(3)]
     snap = ops.MODE_MEMORY.snapshot()[key]
     assert snap['dense'] and snap['flat'] and (snap['wide'] or snap['exact'])
@@ -214,7 +295,7 @@ def test_mode_memory_learns_the_flat_hint():
     inp = case_inputs(g['meta'], "borderline", with_fine=False)
     t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
     ops.MODE_MEMORY.clear()
-    key = (tuple(t0.shape), tuple(t1.shape), 0.2, 0.1)
+    key = ops.hint_key(t0.shape, t1.shape)
     outs = [ops.coarse_match(t0, t1, inp['hw_c'], inp['hw_c'], 8.0) for _ in range(3)]
     snap = ops.MODE_MEMORY.snapshot()[key]
     assert snap['dense'] and snap['flat']
@@ -1201,6 +1282,45 @@ def test_dense_conf_matrix_gradient_goes_through_the_hip_backward(hw0, hw1, c, l
     for got, ref in ((a0.grad, b0.grad), (a1.grad, b1.grad)):
         scale = ref.abs().max().item()
         assert scale > 1e-6 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("what", ["stats", "conf_matrix"])
+def test_softmax_statistics_at_a_low_threshold_use_the_slot_count_the_call_ran_with(what):
+    """thr = 0.05: fm_default_cand_slots is 32, ops.coarse_match caps the auto call at 16 slots - the workspace layout the
+    statistics are read from (CoarseBuffers.softmax_stats -> fm_coarse_softmax_stats) must be the 16-slot one the serving
+    attempt ran with (third byte of the hint word), not the default's; the gradient against float64 autograd through
+    coarse_matching_new.py:64-68 (a layout for the wrong slot count reads past the workspace)."""
+    hw = (12, 16)
+    l, c = hw[0] * hw[1], 64
+    f0, f1 = synth.coarse_descriptors(29, 2, l, c, "borderline")
+    a0 = torch.as_tensor(f0, device=DEV).requires_grad_(True)
+    a1 = torch.as_tensor(f1, device=DEV).requires_grad_(True)
+    lib = _lib.load()
+    assert lib.fm_default_cand_slots(0.05) > 16
+    out = ops.coarse_match(a0.detach(), a1.detach(), hw, hw, 8.0, thr=0.05, stats=(what == "stats"),
+                           conf_matrix=(what == "conf_matrix"))
+    assert out['_coarse_buffers']._shape[4] == 16
+    g = torch.Generator(device="cpu").manual_seed(11)
+    gt = torch.stack([torch.randint(2, (80,), generator=g), torch.randint(l, (80,), generator=g),
+                      torch.randint(l, (80,), generator=g)], 1).to(DEV)
+    wts = torch.randn(80, generator=g).to(DEV)
+    if what == "stats":
+        conf = ops.dual_softmax_at(a0, a1, gt[:, 0], gt[:, 1], gt[:, 2], out['_coarse_buffers'])
+    else:
+        conf = ops.attach_conf_matrix_grad(a0, a1, out['conf_matrix'], 0.1, out['_coarse_buffers'])[gt[:, 0], gt[:, 1], gt[:, 2]]
+    (conf * wts).sum().backward()
+    b0 = torch.as_tensor(f0, device=DEV, dtype=torch.float64).requires_grad_(True)
+    b1 = torch.as_tensor(f1, device=DEV, dtype=torch.float64).requires_grad_(True)
+    sim = torch.einsum("nlc,nsc->nls", b0 / c ** .5, b1 / c ** .5) / 0.1
+    conf64 = (torch.softmax(sim, 1) * torch.softmax(sim, 2))[gt[:, 0], gt[:, 1], gt[:, 2]]
+    (conf64 * wts.double()).sum().backward()
+    assert (conf.detach().double() - conf64.detach()).abs().max().item() <= 1e-5
+    for got, ref in ((a0.grad, b0.grad), (a1.grad, b1.grad)):
+        scale = ref.abs().max().item()
+        assert scale > 0 and (got.double() - ref).abs().max().item() <= 2e-4 * scale
+    # the oracle's matches at this threshold too
+    ref = orc.coarse_match(torch.as_tensor(f0), torch.as_tensor(f1), (96, 128), hw, hw, thr=0.05)
+    _assert_coarse(out, ref, thr=0.05)
 
 
 def test_dense_conf_matrix_gradient_at_cfg2_size_without_an_LxS_temporary():

@@ -35,6 +35,44 @@ def test_full_path_matches_reference(name, dist):
     np.testing.assert_allclose((w0.double() * pos * ch).sum((1, 2)).numpy(), g['win0_sum'], rtol=1e-12, atol=1e-9)
 
 
+@pytest.mark.parametrize("name,dist", [("cfg2_peaky_w5", "peaky"), ("cfg2_borderline_w5", "borderline")])
+def test_oracle_at_the_metric_s_window_size_matches_reference(name, dist):
+    """Round 6: the oracle at W = 5 (BASELINE.json configs[1]) against the reference's own FineMatching.forward run with
+    Linear(25, 1) position mixes on its own W = 5 unfold (make_golden.py:w5_case) - the oracle's W parameter is no
+    longer pinned at 7 only."""
+    g = load_golden(name)
+    inp = case_inputs(g['meta'][:6], dist, ww=25)
+    torch.set_num_threads(8)
+    out = orc.match_features(inp['f0'], inp['f1'], inp['ff0'], inp['ff1'], inp['hw_i'], inp['mix'], w=5)
+    _check_coarse(out, g)
+    np.testing.assert_allclose(out['mkpts0_f'].numpy(), g['mkpts0_f'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out['mkpts1_f'].numpy(), g['mkpts1_f'], rtol=0, atol=2e-5)
+    for key, ff, ids in (('win0_sum', inp['ff0'], out['i_ids']), ('win1_sum', inp['ff1'], out['j_ids'])):
+        wv = orc.crop_windows(ff, out['b_ids'], ids, 5, 4, inp['hw_c'][1])
+        pos = torch.arange(1, 26, dtype=torch.float64).view(1, 25, 1)
+        ch = torch.arange(1, 65, dtype=torch.float64).view(1, 1, -1)
+        np.testing.assert_allclose((wv.double() * pos * ch).sum((1, 2)).numpy(), g[key], rtol=1e-12, atol=1e-9)
+
+
+def test_oracle_on_samples_of_the_full_batch_summary():
+    """cfg3_all64_*: three samples of the 64 through the oracle against the reference's per-sample summary (the GPU test
+    checks all 64 through one batched call)."""
+    import hashlib
+    for name, dist in (("cfg3_all64_peaky", "peaky"), ("cfg3_all64_borderline", "borderline")):
+        g = load_golden(name)
+        n, h, w, c, cf, seed = [int(v) for v in g['meta']]
+        sh = synth.config_shapes(dict(h=h, w=w))
+        band = {(int(b), int(i), int(j)) for b, i, j in g['band']}
+        for b in (0, 63) if dist == "peaky" else (17,):
+            f0, f1 = synth.coarse_descriptors(seed + b, 1, sh['l'], c, dist)
+            out = orc.coarse_match(f0, f1, (h, w), (sh['hc'], sh['wc']), (sh['hc'], sh['wc']))
+            ij = np.stack([out['i_ids'].numpy(), out['j_ids'].numpy()], 1)
+            keep = np.array([(b, int(i), int(j)) not in band for i, j in ij], bool)
+            assert int(keep.sum()) == int(g['m'][b])
+            assert hashlib.sha256(ij[keep].astype('<i4').tobytes()).hexdigest() == str(g['sha256'][b])
+            assert abs(out['mconf'].numpy()[keep].astype(np.float64).sum() - g['mconf_sum'][b]) <= 1e-6 * keep.sum()
+
+
 def test_batch_case_matches_reference():
     g = load_golden("cfg3_first2_peaky")
     inp = case_inputs(g['meta'], "peaky")

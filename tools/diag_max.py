@@ -45,7 +45,8 @@ def main():
         v.fm_debug_launch_corr(ptr, p.n, p.l, p.l, p.c, slots, 0.1, 0.2, 0, st)
     torch.cuda.synchronize()
     tiles = lay["Sp"] // 64                                   # the max pass' own grid (api.hip: kMaxPassTarget)
-    s0 = min(max(512 // (p.n * lay["panels"]), 1), max(tiles // 2, 1), 32)
+    wg = p.n * lay["panels"]                                  # (api.hip: choose_splits with kMaxPassTarget / kMaxPassSlots)
+    s0 = min(max((5120 if wg >= 512 else 256) // wg, 1), max(tiles // 2, 1), 32)
     tps = -(-tiles // s0)
     msplits = -(-tiles // tps)
     nwg = p.n * lay["panels"] * msplits
