@@ -24,6 +24,7 @@ FM_DEV_RANGE = 4                                    # device status bit
 FM_DEV_ALL_DENSE = 256                              # informational device status bit (fm_read_count_info)
 FM_MODE_EXACT_SCREENING, FM_MODE_DENSE, FM_MODE_NO_CELL_MAPS, FM_MODE_EXACT_STEP, FM_MODE_STATS = 1, 2, 4, 8, 16   # `mode` bits
 FM_MODE_FLAT = 32
+FM_MODE_ALONE = 64      # hint about the device: this call has the GPU to itself (grids sized for the kernel alone)
 FM_LAYOUT_NCHW_PREPARED = 2                         # fm_fine_match_maps*: image 1's channels-last copy is already in `scratch`
 
 _lib = None
@@ -92,6 +93,9 @@ SIGNATURES = {
                                       _p, _p, _f, _p, _p, _p, _p]),
     "fm_fine_match_maps": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p,
                                 _p, _p, _f, _p, _p, _p, _p]),
+    "fm_fine_maps_cells_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
+    "fm_fine_match_maps_cells": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p,
+                                      _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p]),
 }
 
 

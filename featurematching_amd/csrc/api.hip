@@ -27,9 +27,10 @@ int choose_splits(int N, int panels, int tiles, int target) {
 // launch holds thousands of items anyway (a batch, a 1024x1024 pair); 32 - shorter waves, more of them - for a pair or two
 // (one 640x480 pair on 4 streams: 27.0 / 28.0 / 27.3 / 26.1 k pairs/s at 64 / 32 / 16 / 8 units; 64 pairs: 286 / 309 /
 // 375 us at 64 / 32 / 16)
-static int choose_screen_chunks(int N, int Lp, int nunits, int* units_per_chunk) {
+static int choose_screen_chunks(int N, int Lp, int nunits, int* units_per_chunk, bool alone) {
   const long nrb = (long)N * (Lp / 32);
-  const int cu = nrb * ((nunits + 63) / 64) >= 4096 ? 64 : 32;
+  // (FM_MODE_ALONE, a pair or two: 8-unit chunks - 3.5 us faster alone at one 640x480 pair, 7 % slower on four streams)
+  const int cu = nrb * ((nunits + 63) / 64) >= 4096 ? 64 : (alone && nrb * ((nunits + 7) / 8) <= 8192 ? 8 : 32);
   *units_per_chunk = cu;
   return (nunits + cu - 1) / cu;
 }
@@ -43,7 +44,7 @@ static int choose_screen_chunks(int N, int Lp, int nunits, int* units_per_chunk)
 constexpr int kMaxPassTarget = 256;
 constexpr int kMaxPassSlots = 512;
 
-CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
+CoarseWs coarse_layout(int N, int L, int S, int C, int slots, bool alone) {
   CoarseWs w;
   memset(&w, 0, sizeof(w));
   C = padded_channels(C);
@@ -56,11 +57,11 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots) {
   // (a batch that fills the resident slots by itself gets ~10 rounds of workgroups, so that the last round's tail is a
   // small share of the launch: 1216 workgroups on 512 slots were "2.4 of 3 rounds"; 64 pairs of 640x480: 351 -> 333 us
   // with 4 splits; 2 / 3 / 4 / 5 / 8 splits: 335 / 340 / 333 / 348 / 363 us)
-  w.splits0 = choose_splits(N, w.panels, w.tiles, N * w.panels >= kMaxPassSlots ? 10 * kMaxPassSlots : kMaxPassTarget);
+  w.splits0 = choose_splits(N, w.panels, w.tiles, N * w.panels >= kMaxPassSlots ? 10 * kMaxPassSlots : (alone ? kMaxPassSlots : kMaxPassTarget));
 #ifdef FM_TUNE_ENV
   if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : kMaxPassTarget);
 #endif
-  w.splits_s = choose_screen_chunks(N, w.Lp, w.Sp / 32, &w.units_s);
+  w.splits_s = choose_screen_chunks(N, w.Lp, w.Sp / 32, &w.units_s, alone);
   const size_t rows = (size_t)N * w.Lp, cols = (size_t)N * w.Sp;
   const size_t nblk = (rows * slots + 255) / 256;
   size_t o = 0;
@@ -143,7 +144,7 @@ extern "C" int fm_default_cand_slots(float thr) {
 static bool valid_slots(int s) { return s >= 4 && s <= 64 && (s & (s - 1)) == 0; }
 
 constexpr int kKnownModes = FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_NO_CELL_MAPS | FM_MODE_EXACT_STEP | FM_MODE_STATS |
-                            FM_MODE_FLAT;
+                            FM_MODE_FLAT | FM_MODE_ALONE;
 
 static bool needs_dense_region(int mode, bool want_conf) {
   return want_conf || (mode & (FM_MODE_DENSE | FM_MODE_EXACT_SCREENING | FM_MODE_STATS | FM_MODE_FLAT)) != 0;
@@ -256,7 +257,7 @@ static int coarse_match_impl(const void* feat0, const void* feat1, int in_dtype,
   if (mode & ~kKnownModes) return FM_E_UNSUPPORTED;
   const bool exact = (mode & FM_MODE_EXACT_SCREENING) != 0;
   const bool dense = needs_dense_region(mode, conf_matrix != nullptr);      // exact screening and conf_matrix read the planes too
-  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots);
+  const CoarseWs w = coarse_layout(N, L, S, C, cand_slots, (mode & FM_MODE_ALONE) != 0);
   if (workspace_bytes < (dense ? w.total : w.common_total) || ((uintptr_t)workspace & 255)) return FM_E_WORKSPACE;
   char* base = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;

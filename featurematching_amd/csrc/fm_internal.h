@@ -80,7 +80,8 @@ struct CoarseWs {
 
 // splits of the column sweep so that panels*splits*N fills the chip once
 int choose_splits(int N, int panels, int tiles, int target = 256);
-CoarseWs coarse_layout(int N, int L, int S, int C, int slots);
+// (alone: FM_MODE_ALONE - launch geometry only, the offsets and sizes do not depend on it)
+CoarseWs coarse_layout(int N, int L, int S, int C, int slots, bool alone = false);
 
 struct Scalars {          // lives at ws.scalars (zeroed per call)
   unsigned flags;         // FM_DEV_* bits

@@ -115,7 +115,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
                        conf_matrix: bool = False, exact_screening: bool = False, dense: bool = False,
                        cell_maps: bool = True, exact_step: bool = False, stats: bool = False,
                        flat: bool = False, side_map: Optional[torch.Tensor] = None,
-                       side_scratch: Optional[torch.Tensor] = None) -> CoarseBuffers:
+                       side_scratch: Optional[torch.Tensor] = None, alone: bool = False) -> CoarseBuffers:
     """Enqueue the coarse stage (coarse_matching_new.py:43-143, eval) and return the
     capacity-sized device buffers without synchronising.  feat_c0 / feat_c1 may be float32, float16 or bfloat16
     (fm_coarse_match_dtype: half-precision values are exact in float32, so the result equals the float32 call on
@@ -133,7 +133,9 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
     prep kernel and all samples go to the dense sum kernel (two launches fewer); the result does not depend on it.
     `side_map` (fm_coarse_match_maps): image 1's NCHW float32 fine map [N, 64, Hf, Wf] - its channels-last copy, which
     fine_match_maps would make as its first launch, rides in the assignment kernel's launch instead and lands in
-    `side_scratch` (allocated when not given; CoarseBuffers.side_scratch) - pass that to fine_match_maps(prepared=...)."""
+    `side_scratch` (allocated when not given; CoarseBuffers.side_scratch) - pass that to fine_match_maps(prepared=...).
+    `alone` (FM_MODE_ALONE): this call has the GPU to itself - launches that cannot fill the chip take the grid that is
+    fastest for the kernel alone instead of the small footprint that leaves room for other streams' kernels."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -150,7 +152,7 @@ def coarse_match_async(feat_c0: torch.Tensor, feat_c1: torch.Tensor, hw0_c, hw1_
         cand_slots = lib.fm_default_cand_slots(float(thr))
     mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
            (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_EXACT_STEP if exact_step else 0) | \
-           (_lib.FM_MODE_STATS if stats else 0) | (_lib.FM_MODE_FLAT if flat else 0)
+           (_lib.FM_MODE_STATS if stats else 0) | (_lib.FM_MODE_FLAT if flat else 0) | (_lib.FM_MODE_ALONE if alone else 0)
     wkey = (n, l, s, c, cand_slots, mode, bool(conf_matrix))
     ws_bytes = _WS_BYTES.get(wkey)
     if ws_bytes is None:                       # (a pure function of the shapes: asked once per shape)
@@ -282,14 +284,17 @@ _AUTO_WS_BYTES = {}
 def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2, temperature=0.1,
                  scale0=None, scale1=None, conf_matrix: bool = False, exact_screening: Optional[bool] = None,
                  dense: Optional[bool] = None, exact_step: Optional[bool] = None, stats: bool = False,
-                 flat: Optional[bool] = None, cell_maps: bool = True) -> dict:
+                 flat: Optional[bool] = None, cell_maps: bool = True, alone: bool = True) -> dict:
     """Synchronous form: sliced outputs.  A thin caller of fm_coarse_match_auto - the ONE C entry point that serves any
     data (flat similarity, candidate overflow, a clipped int8 step and the assignment's bounded wait are answered inside
     it, behind the host sync the reference's torch.where has at coarse_matching_new.py:109).  What is left here: the
     allocations, FM_E_CAPACITY (exact ties can exceed N*min(L,S): larger output buffers, once more) and the optional
     hint word per problem kind (MODE_MEMORY: flat data starts its second call where the first ended).
     exact_screening / dense / exact_step / flat: None = left to the library (and the hint); True = the mode to START
-    with (a caller that knows its data).  conf_matrix / stats as in coarse_match_async."""
+    with (a caller that knows its data).  conf_matrix / stats as in coarse_match_async.  `alone` (FM_MODE_ALONE, default
+    on HERE): the synchronous form waits for its result on the host - the reference's single-pair caller,
+    demo/demo.py:95-116 - so its launches take the grids that are fastest for a kernel alone on the device; a process
+    that runs several such calls side by side (threads, streams) passes alone=False."""
     lib = _lib.load()
     f0 = _desc(feat_c0, "feat_c0")
     f1 = _desc(feat_c1, "feat_c1")
@@ -304,7 +309,8 @@ def coarse_match(feat_c0, feat_c1, hw0_c, hw1_c, scale_px, thr=0.2, border_rm=2,
     managed = exact_screening is None and dense is None and exact_step is None and flat is None
     mode = (_lib.FM_MODE_EXACT_SCREENING if exact_screening else 0) | (_lib.FM_MODE_DENSE if dense else 0) | \
            (_lib.FM_MODE_EXACT_STEP if exact_step else 0) | (_lib.FM_MODE_FLAT if flat else 0) | \
-           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_STATS if stats else 0)
+           (0 if cell_maps else _lib.FM_MODE_NO_CELL_MAPS) | (_lib.FM_MODE_STATS if stats else 0) | \
+           (_lib.FM_MODE_ALONE if alone else 0)
     hint0, probing = MODE_MEMORY.start(key) if managed else (0, False)
     sc0 = None if scale0 is None else _f32c(scale0.to(dev), "scale0")
     sc1 = None if scale1 is None else _f32c(scale1.to(dev), "scale1")
@@ -692,6 +698,44 @@ def fine_match_maps(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, 
                                       _ptr(out0), _ptr(out1), _stream(dev))
     _lib.check(st, "fm_fine_match_maps_dtype")
     out0._keep = (f0, f1, scratch)
+    return out0, out1
+
+
+def fine_match_maps_cells(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, j_ids, w: int, hw0_c, hw1_c,
+                          mix0: torch.Tensor, mix1: torch.Tensor, mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor,
+                          scale_f: float, cells, count: Optional[torch.Tensor] = None,
+                          scratch: Optional[torch.Tensor] = None):
+    """Window crop + fine stage from NCHW float32 maps WITHOUT the channels-last copy of image 1 (fm_fine_match_maps_cells:
+    fine_preprocess.py:43-50 + fine_matching_new.py:50-79): every map is read in strips of 8 coarse cells, image 0 twice
+    and image 1 once, each in its own cell order - the form for BATCHES (60 MB of map reads per 640x480 pair instead of
+    80 MB, and no 20-byte runs).  `cells` = CoarseBuffers.cell_maps() of the coarse call that produced the ids (the
+    cell -> match maps in its workspace; run it with cell_maps=True).  Stride 4, pad 2, even map widths.  Results equal
+    fine_match_maps bit for bit.  Returns (mkpts0_f, mkpts1_f)."""
+    lib = _lib.load()
+    if not (feat_f0.is_cuda and feat_f0.dtype == torch.float32 and feat_f0.is_contiguous() and feat_f1.is_contiguous()
+            and feat_f1.dtype == torch.float32):
+        raise RuntimeError("fine_match_maps_cells: contiguous NCHW float32 maps on the GPU (the HIP path has no CPU fallback)")
+    n, cf, hf0, wf0 = feat_f0.shape
+    hf1, wf1 = feat_f1.shape[2:]
+    dev = feat_f0.device
+    m_max = int(b_ids.shape[0])
+    out0 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
+    out1 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
+    if m_max == 0:
+        return out0, out1
+    (c0, p0, t0), (c1, p1, t1) = cells
+    need = int(lib.fm_fine_maps_cells_scratch_bytes(n, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]), int(hw1_c[1])))
+    if scratch is None or scratch.numel() * scratch.element_size() < need + 256:
+        scratch = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    sp = scratch.data_ptr() + ((-scratch.data_ptr()) % 256)
+    st = lib.fm_fine_match_maps_cells(_ptr(feat_f0), _ptr(feat_f1), n, cf, hf0, wf0, hf1, wf1, w, 4, 2, int(hw0_c[0]),
+                                      int(hw0_c[1]), int(hw1_c[0]), int(hw1_c[1]), C.c_void_p(c0), p0, C.c_void_p(t0),
+                                      C.c_void_p(c1), p1, C.c_void_p(t1), _ptr(b_ids), _ptr(i_ids), _ptr(j_ids),
+                                      _ptr(count), m_max, _ptr(_f32c(mix0, "mix0")), _ptr(_f32c(mix1, "mix1")),
+                                      _ptr(_f32c(mkpts0_c, "mkpts0_c")), _ptr(_f32c(mkpts1_c, "mkpts1_c")), float(scale_f),
+                                      C.c_void_p(sp), _ptr(out0), _ptr(out1), _stream(dev))
+    _lib.check(st, "fm_fine_match_maps_cells")
+    out0._keep = (feat_f0, feat_f1, scratch)
     return out0, out1
 
 

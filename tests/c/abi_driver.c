@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
   EXPECT(bytes == full, 1);
   EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 1, &bytes), FM_OK);
   EXPECT(bytes == full, 1);
-  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 64, 0, &bytes), FM_E_UNSUPPORTED);
+  EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 128, 0, &bytes), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, FM_MODE_EXACT_STEP, 0, &bytes), FM_OK);
   EXPECT(p_fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, NULL), FM_E_NULL);
   EXPECT(p_fm_coarse_workspace_bytes(0, 4800, 4800, 256, 8, &bytes), FM_E_SHAPE);
@@ -144,7 +144,7 @@ int main(int argc, char** argv) {
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.0f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 5, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);
   EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 16, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_WORKSPACE);
-  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 64, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);   /* unknown mode bit */
+  EXPECT(p_fm_coarse_match(one, one, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 128, one, one, one, one, one, one, 64, cnt, NULL, NULL), FM_E_UNSUPPORTED);   /* unknown mode bit */
   /* fm_coarse_match_maps: the side job's arguments are checked before anything is enqueued */
   EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, NULL, 1, 64, 32, 32, one, NULL), FM_E_NULL);
   EXPECT(p_fm_coarse_match_maps(one, one, FM_F32, 1, 64, 64, 64, 8, 8, 8, 8, 0.1f, 0.2f, 2, 8.f, NULL, NULL, one, 1u << 30, 8, 0, one, one, one, one, one, one, 64, cnt, NULL, (const float*)one, 1, 64, 32, 32, NULL, NULL), FM_E_NULL);
@@ -190,7 +190,7 @@ int main(int argc, char** argv) {
     EXPECT(AUTO(one, NULL, 1u << 30, 0, 0, 0.2f, cnt, &am), FM_E_NULL);
     EXPECT(AUTO(one, one, 1u << 30, 0, 0, 0.2f, NULL, &am), FM_E_NULL);
     EXPECT(AUTO(one, one, 1u << 30, 24, 0, 0.2f, cnt, &am), FM_E_UNSUPPORTED);               /* slots not a power of two */
-    EXPECT(AUTO(one, one, 1u << 30, 0, 64, 0.2f, cnt, &am), FM_E_UNSUPPORTED);               /* unknown mode bit */
+    EXPECT(AUTO(one, one, 1u << 30, 0, 128, 0.2f, cnt, &am), FM_E_UNSUPPORTED);               /* unknown mode bit */
     EXPECT(AUTO(one, one, 1u << 30, 0, 0, 1.0f, cnt, &am), FM_E_UNSUPPORTED);                /* thr */
     EXPECT(AUTO(one, one, 16, 0, 0, 0.2f, cnt, &am), FM_E_WORKSPACE);
     EXPECT(AUTO(one, odd, 1u << 30, 0, 0, 0.2f, cnt, &am), FM_E_WORKSPACE);

@@ -59,7 +59,8 @@ def test_workspace_query_and_argument_checks():
     for mode, conf in ((1, 0), (2, 0), (3, 0), (0, 1)):
         assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, mode, conf, C.byref(n)) == 0
         assert n.value == per_pair > common
-    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 64, 0, C.byref(n)) == -3     # unknown mode bit
+    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 128, 0, C.byref(n)) == -3    # unknown mode bit
+    assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 64, 0, C.byref(n)) == 0 and n.value == common   # FM_MODE_ALONE: geometry only
     assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 8, 0, C.byref(n)) == 0 and n.value == common   # FM_MODE_EXACT_STEP
     assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 4, 0, C.byref(n)) == 0 and n.value == common   # FM_MODE_NO_CELL_MAPS
     assert lib.fm_coarse_workspace_bytes_mode(1, 4800, 4800, 256, 8, 0, 0, None) == -1
