@@ -110,10 +110,7 @@ class Pair:
         self.slots = d['slots'] or None                   # candidate slots per row / column (None: fm_default_cand_slots(thr))
         # NCHW float32 maps on the maps path: image 1's channels-last copy rides in the assignment kernel's launch
         # (fm_coarse_match_maps) instead of being fm_fine_match_maps' first launch
-        # a BATCH of NCHW maps takes the strip form of the fine stage (fm_fine_match_maps_cells: no channels-last copy of
-        # image 1, every map read in strips of 8 cells; three dependent launches that only pay when a launch fills the chip)
-        self.strips = layout == "nchw" and fine_path == "maps" and self.n >= 8
-        self.fuse_maps = layout == "nchw" and fine_path == "maps" and not self.strips
+        self.fuse_maps = layout == "nchw" and fine_path == "maps"
         self.conf_matrix = False         # materialise data['conf_matrix'] (cfg#3's HBM-bound mode)
         self.alone = False               # FM_MODE_ALONE: only the ONE-stream line sets it (that step does have the GPU to itself)
         self.stages = "all"      # diagnostic only (--stages): "coarse" or "fine" time a part of the step
@@ -131,8 +128,7 @@ class Pair:
                                          conf_matrix=self.conf_matrix, flat=(self.flat and self.dense and not self.conf_matrix),
                                          side_map=(self.ff1 if self.fuse_maps else None),
                                          side_scratch=(self.scratch if self.fuse_maps else None),
-                                         cell_maps=((self.fine_path == "windows" and self.layout == "nchw") or self.strips),
-                                         alone=self.alone)
+                                         cell_maps=(self.fine_path == "windows" and self.layout == "nchw"), alone=self.alone)
         if self.stages == "coarse" and self.last is not None:
             self.last = (buf,) + self.last[1:]
             return self.last
@@ -147,10 +143,6 @@ class Pair:
     def fine_maps(self, buf, standalone=False):
         """window crop + fine stage from the maps in one call (no window tensors); standalone: with its own transpose of
         image 1 even when the step lets the coarse call carry it"""
-        if self.strips:
-            return ops.fine_match_maps_cells(self.ff0, self.ff1, buf.b_ids, buf.i_ids, buf.j_ids, self.window, self.hw_c,
-                                             self.hw_c, self.mix0, self.mix1, buf.mkpts0_c, buf.mkpts1_c,
-                                             self.hw_i[0] / self.hw_f[0], buf.cell_maps(), count=buf.count, scratch=self.scratch)
         prepared = self.scratch if (self.fuse_maps and not standalone) else None
         return ops.fine_match_maps(self.ff0, self.ff1, buf.b_ids, buf.i_ids, buf.j_ids, self.window, 4, self.hw_c[1],
                                    self.hw_c[1], self.mix0, self.mix1, buf.mkpts0_c, buf.mkpts1_c,

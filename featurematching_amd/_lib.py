@@ -93,9 +93,6 @@ SIGNATURES = {
                                       _p, _p, _f, _p, _p, _p, _p]),
     "fm_fine_match_maps": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p,
                                 _p, _p, _f, _p, _p, _p, _p]),
-    "fm_fine_maps_cells_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
-    "fm_fine_match_maps_cells": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p,
-                                      _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p]),
 }
 
 

@@ -536,7 +536,6 @@ __device__ __forceinline__ void soft_argmax2(float sim0, float sim1, int pos, bo
     const float kx[2] = {k0x, k1x}, ky[2] = {k0y, k1y};
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      if (outs[d] == nullptr) continue;              // (k_fine_strip: one direction per pass; the other's sums are unused)
       const float inv = 1.0f / sum_k(5 * d);
       const float cx = sum_k(5 * d + 1) * inv, cy = sum_k(5 * d + 2) * inv;
       const float vx = sum_k(5 * d + 3) * inv - cx * cx, vy = sum_k(5 * d + 4) * inv - cy * cy;
@@ -727,221 +726,6 @@ __global__ __launch_bounds__(256) void k_fine_maps(const float* __restrict__ map
   }
 }
 
-
-// ----------------------------------------------------------------------------------------
-// k_fine_strip (round 6): crop + fine stage for NCHW maps WITHOUT the channels-last copy of image 1 - the form for
-// batches (fm_fine_match_maps_cells).  What the copy route moves per 640x480 pair: the copy itself (19.7 MB read +
-// 19.7 MB written), image 0's windows in place and image 1's from the copy: 80 MB for 39 MB of maps - and its in-place
-// loader touches every window as 320 runs of 20 bytes (64 channels x 5 rows), ten cache lines per wave load, so at a batch
-// the kernel is bound by the address path, not by HBM.  Here every map is read in STRIPS: a workgroup takes 8 consecutive
-// cells of one coarse row and loads the strip's footprint - 64 channels x W rows x (4*8 + W - 4) pixels - as runs of
-// 132 / 140 contiguous bytes (8-byte loads) into an LDS tile [channel][row][x] with an odd channel pitch (lane = channel
-// reads are conflict free); the 8 windows are read back from the tile, two cells per wave.  Neither direction of
-// fine_matching_new.py:50-57 needs both windows at once: sim0[m, r] = sum_c q0[m, c] F1[m, r, c] needs the 64 numbers
-// q0[m] = mix_0(F0 window) and image 1's window.  Three passes, each walking ONE map in its own cell order:
-//   pass 1 (ROLE_Q,   image 0): q0 of EVERY cell                                  -> Q0 [N, cells0, 64]
-//   pass 2 (ROLE_SIMQ, image 1): q1 of every cell -> Q1; for the cell's match m (cell -> match map of the coarse stage):
-//                                 sim0 = Q0[i_m] . window, soft-argmax            -> out0[m]
-//   pass 3 (ROLE_SIM,  image 0): sim1 = Q1[j_m] . window, soft-argmax             -> out1[m]
-// 60 MB of map reads + 5 MB of tables per pair instead of 80 MB.  The arithmetic per match is fine_core's, instruction
-// for instruction (the mix in position order, transpose_reduce, soft_argmax2 with the other direction idle), so the
-// results equal fm_fine_match_maps bit for bit.  Matches that lost their cell to an exactly tied match (the coarse
-// stage's tie lists) are served by the first waves of the grid through the per-window loader.
-// ----------------------------------------------------------------------------------------
-constexpr int kStripCells = 8;
-constexpr int kStripGrid = 1024;       // persistent workgroups of a strip pass
-template <int W> struct StripGeom {
-  static constexpr int NX2 = (4 * kStripCells + W - 4 + 1) / 2;     // 8-byte pairs per tile row: 17 (W = 5) / 18 (W = 7)
-  static constexpr int RP = 2 * NX2;                                 // row pitch in floats
-  static constexpr int P = W * RP + 1;                               // channel pitch (odd: lane = channel reads hit 32 banks)
-  static constexpr int TILE = 64 * P;                                // floats: 10944 (W = 5) / 16192 (W = 7)
-};
-enum { ROLE_Q = 0, ROLE_SIMQ = 1, ROLE_SIM = 2 };
-
-struct StripArgs {
-  const float* map; int Hf, Wf, h_c, w_c;            // the map this pass walks [N, 64, Hf, Wf] and its cell grid
-  const float* mix;                                  // [WW + 1] position mix of THIS image (ROLE_Q / ROLE_SIMQ)
-  float* qout;                                       // [N, cells, 64] q-vectors of this image's cells (ROLE_Q / ROLE_SIMQ)
-  const float* qin; int cells_other;                 // [N, cells_other, 64] q-vectors of the OTHER image (ROLE_SIMQ / ROLE_SIM)
-  const int32_t* cell_to_match; int cell_pitch; const int32_t* ties;     // this image's cell -> match index + 1 map, tie list
-  const int32_t* partner; int partner_pitch;         // this image's cell -> the OTHER image's cell of the match that owns it
-  const int64_t* b_ids; const int64_t* ids; const int64_t* ids_other;    // match list: this image's cell, the other image's
-  const int32_t* d_count; int m_max;
-  const float* kc; float scale_f; float* out;        // coarse keypoints of the image this direction refines, its output [M, 3]
-  int dir;                                           // which direction of soft_argmax2 this pass is (0: out0, 1: out1)
-  int N, strips_per_row;
-};
-
-// cell -> partner cell of the match that OWNS the cell (the one the cell -> match map names): lets a strip pass fetch a
-// cell's match index and its partner's q-vector address in ONE round trip instead of map -> ids[m] -> q-vector.
-__global__ __launch_bounds__(256) void k_strip_partners(const int64_t* __restrict__ b_ids, const int64_t* __restrict__ i_ids,
-                                                        const int64_t* __restrict__ j_ids, const int32_t* __restrict__ d_count,
-                                                        int m_max, const int32_t* __restrict__ cell0, int pitch0,
-                                                        const int32_t* __restrict__ cell1, int pitch1, int32_t* __restrict__ p0,
-                                                        int ppitch0, int32_t* __restrict__ p1, int ppitch1) {
-  const int M = d_count ? min(d_count[0], m_max) : m_max;
-  for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
-    const int b = (int)b_ids[m], i = (int)i_ids[m], j = (int)j_ids[m];
-    if (cell0[(long)b * pitch0 + i] == m + 1) p0[(long)b * ppitch0 + i] = j;
-    if (cell1[(long)b * pitch1 + j] == m + 1) p1[(long)b * ppitch1 + j] = i;
-  }
-}
-
-template <int W, int ROLE>
-__global__ __launch_bounds__(256) void k_fine_strip(StripArgs a) {
-  using G = StripGeom<W>;
-  constexpr int WW = W * W, NP = WW > 32 ? 64 : 32;
-  constexpr int CPW = kStripCells / 4;                // cells per wave
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = a.d_count ? min(a.d_count[0], a.m_max) : a.m_max;
-  const int cells = a.h_c * a.w_c;
-  const long nstrips = (long)a.N * a.h_c * a.strips_per_row;
-  const float inv_sqrt_c = 1.0f / sqrtf(64.f);
-  const int pos = tr_index<NP>(lane);
-  const bool on = pos < WW && (NP == 64 || !(lane & 1));
-
-  // one match from its window in registers (f[r]: position r, this lane's channel) and its partner's q-vector
-  auto sim_and_store = [&](const float (&f)[WW], float qo, int m, float kx, float ky) {
-    float p[NP];
-#pragma unroll
-    for (int r = 0; r < NP; ++r) p[r] = r < WW ? qo * f[r] : 0.f;
-    const float sim = transpose_reduce<NP>(p, lane);
-    float* o = a.out + (long)m * 3;
-    if (a.dir == 0) soft_argmax2<W>(sim, 0.f, pos, on, lane, inv_sqrt_c, a.scale_f, kx, ky, 0.f, 0.f, o, nullptr);
-    else soft_argmax2<W>(0.f, sim, pos, on, lane, inv_sqrt_c, a.scale_f, 0.f, 0.f, kx, ky, nullptr, o);
-  };
-
-  constexpr int TOTAL2 = 64 * W * G::NX2;
-  constexpr int NIT = (TOTAL2 + 255) / 256;
-  struct Strip { int b, cy, cx0; };
-  auto decode = [&](long sidx) {
-    Strip s;
-    s.cx0 = (int)(sidx % a.strips_per_row) * kStripCells;
-    s.cy = (int)((sidx / a.strips_per_row) % a.h_c);
-    s.b = (int)(sidx / ((long)a.strips_per_row * a.h_c));
-    return s;
-  };
-  // the strip's footprint - (channel, row) runs of NX2 pairs, consecutive threads along x - and, ahead of it, what this
-  // wave's cells need from the match list: the cell's match and its partner's cell (one round trip, in flight with the tile)
-  auto issue = [&](const Strip& s, float2 (&v)[NIT], int (&pm)[CPW], int (&po)[CPW]) {
-    if (ROLE != ROLE_Q) {
-#pragma unroll
-      for (int kk = 0; kk < CPW; ++kk) {
-        const int cx = min(s.cx0 + wv + 4 * kk, a.w_c - 1);
-        const int cell = s.cy * a.w_c + cx;
-        pm[kk] = a.cell_to_match[(long)s.b * a.cell_pitch + cell];
-        po[kk] = a.partner[(long)s.b * a.partner_pitch + cell];
-      }
-    }
-    const int oy = s.cy * 4 - 2, ox = s.cx0 * 4 - 2;                   // stride 4, the reference's literal pad 2
-    const float* src = a.map + (long)s.b * 64 * a.Hf * a.Wf;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = it * 256 + tid;
-      const int c = idx / (W * G::NX2), rem = idx - c * (W * G::NX2);
-      const int y = rem / G::NX2, k = rem - y * G::NX2;
-      const int gy = oy + y, gx = ox + 2 * k;
-      const bool ok = idx < TOTAL2 && gy >= 0 && gy < a.Hf && gx >= 0 && gx < a.Wf;       // (Wf even, gx even: a pair never straddles an edge)
-      const float2 t = *reinterpret_cast<const float2*>(src + ((long)c * a.Hf + (ok ? gy : 0)) * a.Wf + (ok ? gx : 0));
-      v[it] = ok ? t : make_float2(0.f, 0.f);
-    }
-  };
-
-  // Persistent loop over the strips, software-pipelined through registers: while a strip is worked on out of LDS the next
-  // one's footprint (and its cells' match records) is in flight into registers - a workgroup's memory time and its
-  // arithmetic (about as long: ~450 vector instructions per match and direction) overlap instead of adding up.
-  float2 v[NIT];
-  int pm[CPW], po[CPW];
-  long sidx = xcd_contiguous(blockIdx.x, gridDim.x);
-  if (sidx < nstrips) issue(decode(sidx), v, pm, po);
-  while (sidx < nstrips) {
-    const Strip s = decode(sidx);
-    // this strip's matches: partner q-vector and coarse keypoint (their round trip runs under the LDS phase)
-    int mm[CPW];
-    float qo[CPW], kx[CPW], ky[CPW];
-#pragma unroll
-    for (int kk = 0; kk < CPW; ++kk) {
-      mm[kk] = -1; qo[kk] = kx[kk] = ky[kk] = 0.f;
-      if (ROLE != ROLE_Q) {
-        int m = pm[kk] - 1;
-        if (m >= M || s.cx0 + wv + 4 * kk >= a.w_c) m = -1;
-        mm[kk] = __builtin_amdgcn_readfirstlane(m);
-        if (mm[kk] >= 0) {
-          const int oc = __builtin_amdgcn_readfirstlane(po[kk]);
-          qo[kk] = a.qin[((long)s.b * a.cells_other + oc) * 64 + lane];
-          kx[kk] = a.kc[mm[kk] * 2]; ky[kk] = a.kc[mm[kk] * 2 + 1];
-        }
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = it * 256 + tid;
-      if (idx < TOTAL2) {
-        const int c = idx / (W * G::NX2), rem = idx - c * (W * G::NX2);
-        float* d = tile + c * G::P + 2 * rem;            // (rem = y * NX2 + k: row pitch 2 * NX2)
-        d[0] = v[it].x; d[1] = v[it].y;
-      }
-    }
-    __syncthreads();
-    const long next = sidx + gridDim.x;
-    if (next < nstrips) issue(decode(next), v, pm, po);
-    // ---- two cells per wave ----
-#pragma unroll
-    for (int kk = 0; kk < CPW; ++kk) {
-      const int k = wv + 4 * kk, cx = s.cx0 + k;
-      if (cx >= a.w_c) continue;                          // (wave-uniform)
-      if (ROLE == ROLE_SIM && mm[kk] < 0) continue;
-      const int cell = s.cy * a.w_c + cx;
-      float f[WW];
-#pragma unroll
-      for (int r = 0; r < WW; ++r) f[r] = tile[lane * G::P + (r / W) * G::RP + 4 * k + (r % W)];
-      if (ROLE != ROLE_SIM) {
-        float q = a.mix[WW];
-#pragma unroll
-        for (int r = 0; r < WW; ++r) q = __builtin_fmaf(a.mix[r], f[r], q);
-        a.qout[((long)s.b * cells + cell) * 64 + lane] = q;
-      }
-      if (ROLE != ROLE_Q && mm[kk] >= 0) sim_and_store(f, qo[kk], mm[kk], kx[kk], ky[kk]);
-    }
-    __syncthreads();                                      // the tile is refilled by the next strip
-    sidx = next;
-  }
-
-  // ---- matches that lost their cell to an exactly tied match: per-window loader, first waves of the grid ----
-  if (ROLE != ROLE_Q) {
-    const int nties = a.ties[0];
-    if (nties != 0) {
-      float* wt = tile + wv * kGatherTileFloats(W);       // (4 x 6.8 / 13.3 KB: inside the strip tile)
-      const int gwave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
-      auto serve = [&](int m) {
-        m = __builtin_amdgcn_readfirstlane(m);
-        const int b = __builtin_amdgcn_readfirstlane((int)a.b_ids[m]);
-        const int cell = __builtin_amdgcn_readfirstlane((int)a.ids[m]);
-        const int oc = __builtin_amdgcn_readfirstlane((int)a.ids_other[m]);
-        const int cy = cell / a.w_c;
-        wave_load_window64<W>(a.map + (long)b * 64 * a.Hf * a.Wf, a.Hf, a.Wf, cy * 4 - 2, (cell - cy * a.w_c) * 4 - 2, wt, lane);
-        float f[WW];
-#pragma unroll
-        for (int r = 0; r < WW; ++r) f[r] = wt[r * 68 + lane];
-        sim_and_store(f, a.qin[((long)b * a.cells_other + oc) * 64 + lane], m, a.kc[m * 2], a.kc[m * 2 + 1]);
-        __builtin_amdgcn_wave_barrier();
-      };
-      if (nties <= kTieCap) {
-        for (int q = gwave; q < nties; q += nwaves) {
-          const int m = a.ties[1 + q];
-          if (m >= 0 && m < M) serve(m);
-        }
-      } else {                                            // the list overflowed: every wave scans its slice of the matches
-        const int chunk = (M + nwaves - 1) / nwaves;
-        for (int m = gwave * chunk; m < min(M, (gwave + 1) * chunk); ++m) {
-          const int mb = (int)a.b_ids[m], id = (int)a.ids[m];
-          if (a.cell_to_match[(long)mb * a.cell_pitch + id] != m + 1) serve(m);
-        }
-      }
-    }
-  }
-}
 
 // [N, 64, Hf, Wf] -> [N, Hf, Wf, 64]: one workgroup per (sample, row y, 64 pixels of the row); reads 64 channel
 // segments of 256 bytes (16-byte loads along x), writes one contiguous 16 KiB block; the transpose goes through an
@@ -1249,78 +1033,4 @@ extern "C" int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, in
   return fm_fine_match_maps_dtype(feat_f0, feat_f1, FM_F32, layout, N, Cf, Hf0, Wf0, Hf1, Wf1, W, stride, pad, w0c, w1c,
                                   b_ids, i_ids, j_ids, d_count, m_max, mix0, mix1, mkpts0_c, mkpts1_c, scale_f, scratch,
                                   out0, out1, stream);
-}
-
-// the two tables of q-vectors (every cell of image 0, every cell of image 1), 256-byte aligned
-extern "C" size_t fm_fine_maps_cells_scratch_bytes(int N, int h0c, int w0c, int h1c, int w1c) {
-  if (N <= 0 || h0c <= 0 || w0c <= 0 || h1c <= 0 || w1c <= 0) return 0;
-  // the q tables of both images + the cell -> partner cell arrays (k_strip_partners)
-  return align256((size_t)N * h0c * w0c * 256) + align256((size_t)N * h1c * w1c * 256) +
-         align256((size_t)N * h0c * w0c * 4) + align256((size_t)N * h1c * w1c * 4);
-}
-
-extern "C" int fm_fine_match_maps_cells(const float* feat_f0, const float* feat_f1, int N, int Cf, int Hf0, int Wf0, int Hf1,
-                                        int Wf1, int W, int stride, int pad, int h0c, int w0c, int h1c, int w1c,
-                                        const int32_t* cell0, int pitch0, const int32_t* ties0, const int32_t* cell1,
-                                        int pitch1, const int32_t* ties1, const int64_t* b_ids, const int64_t* i_ids,
-                                        const int64_t* j_ids, const int32_t* d_count, int m_max, const float* mix0,
-                                        const float* mix1, const float* mkpts0_c, const float* mkpts1_c, float scale_f,
-                                        void* scratch, float* out0, float* out1, void* stream) {
-  if (m_max == 0) return FM_OK;
-  if (!feat_f0 || !feat_f1 || !cell0 || !ties0 || !cell1 || !ties1 || !b_ids || !i_ids || !j_ids || !mix0 || !mix1 ||
-      !mkpts0_c || !mkpts1_c || !scratch || !out0 || !out1)
-    return FM_E_NULL;
-  if (N <= 0 || Hf0 <= 0 || Wf0 <= 0 || Hf1 <= 0 || Wf1 <= 0 || h0c <= 0 || w0c <= 0 || h1c <= 0 || w1c <= 0 || m_max < 0 ||
-      pitch0 < h0c * w0c || pitch1 < h1c * w1c)
-    return FM_E_SHAPE;
-  // the strip loader: stride 4 and the reference's pad 2 (fine_preprocess.py:43-46), rows of an even number of pixels
-  if (!maps64_ok(Cf, Hf0, Wf0, W) || !maps64_ok(Cf, Hf1, Wf1, W) || stride != 4 || pad != 2 || (Wf0 & 1) || (Wf1 & 1))
-    return FM_E_UNSUPPORTED;
-  if (((uintptr_t)scratch & 255) || ((uintptr_t)feat_f0 & 7) || ((uintptr_t)feat_f1 & 7)) return FM_E_WORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  float* q0 = (float*)scratch;
-  float* q1 = (float*)((char*)q0 + align256((size_t)N * h0c * w0c * 256));
-  int32_t* part0 = (int32_t*)((char*)q1 + align256((size_t)N * h1c * w1c * 256));
-  int32_t* part1 = (int32_t*)((char*)part0 + align256((size_t)N * h0c * w0c * 4));
-  {
-    const int blocks = (m_max + 255) / 256 < 1024 ? (m_max + 255) / 256 : 1024;
-    hipLaunchKernelGGL(k_strip_partners, dim3(blocks), dim3(256), 0, st, b_ids, i_ids, j_ids, d_count, m_max, cell0, pitch0, cell1,
-                       pitch1, part0, h0c * w0c, part1, h1c * w1c);
-  }
-  auto pass = [&](int role, const float* map, int Hf, int Wf, int hc, int wc, const float* mix, float* qout, const float* qin,
-                  int cells_other, const int32_t* cmap, int pitch, const int32_t* ties, const int32_t* partner, const int64_t* ids,
-                  const int64_t* ids_other, const float* kc, float* out, int dir) {
-    StripArgs a;
-    a.partner = partner; a.partner_pitch = hc * wc;
-    a.map = map; a.Hf = Hf; a.Wf = Wf; a.h_c = hc; a.w_c = wc; a.mix = mix; a.qout = qout; a.qin = qin; a.cells_other = cells_other;
-    a.cell_to_match = cmap; a.cell_pitch = pitch; a.ties = ties; a.b_ids = b_ids; a.ids = ids; a.ids_other = ids_other;
-    a.d_count = d_count; a.m_max = m_max; a.kc = kc; a.scale_f = scale_f; a.out = out; a.dir = dir; a.N = N;
-    a.strips_per_row = (wc + kStripCells - 1) / kStripCells;
-    const long nstrips = (long)N * hc * a.strips_per_row;
-    // persistent workgroups: 4 per compute unit (two are resident; the rest even out the tail), a multiple of 8
-    const int blocks = (int)((nstrips < kStripGrid ? nstrips : kStripGrid) + 7) / 8 * 8;
-#define FM_STRIP_LAUNCH(WQ, R)                                                                                      \
-  do {                                                                                                              \
-    static unsigned long long lds_set = 0;                                                                          \
-    const int lds = StripGeom<WQ>::TILE * 4;                                                                        \
-    hipError_t e = ensure_dynamic_lds(&k_fine_strip<WQ, R>, lds, &lds_set);                                         \
-    if (e != hipSuccess) return e;                                                                                  \
-    hipLaunchKernelGGL((k_fine_strip<WQ, R>), dim3(blocks), dim3(256), lds, st, a);                                 \
-  } while (0)
-    if (W == 5) {
-      if (role == ROLE_Q) FM_STRIP_LAUNCH(5, ROLE_Q); else if (role == ROLE_SIMQ) FM_STRIP_LAUNCH(5, ROLE_SIMQ); else FM_STRIP_LAUNCH(5, ROLE_SIM);
-    } else {
-      if (role == ROLE_Q) FM_STRIP_LAUNCH(7, ROLE_Q); else if (role == ROLE_SIMQ) FM_STRIP_LAUNCH(7, ROLE_SIMQ); else FM_STRIP_LAUNCH(7, ROLE_SIM);
-    }
-#undef FM_STRIP_LAUNCH
-    return hipGetLastError();
-  };
-  hipError_t e = pass(ROLE_Q, feat_f0, Hf0, Wf0, h0c, w0c, mix0, q0, nullptr, 0, cell0, pitch0, ties0, part0, i_ids, j_ids, mkpts0_c, out0, 0);
-  if (e != hipSuccess) return (int)e;
-  // image 1 in its own cell order: q1 of every cell, and direction 0 (q0 of the partner . image 1's window -> keypoint 0)
-  e = pass(ROLE_SIMQ, feat_f1, Hf1, Wf1, h1c, w1c, mix1, q1, q0, h0c * w0c, cell1, pitch1, ties1, part1, j_ids, i_ids, mkpts0_c, out0, 0);
-  if (e != hipSuccess) return (int)e;
-  // image 0 again: direction 1 (q1 of the partner . image 0's window -> keypoint 1)
-  e = pass(ROLE_SIM, feat_f0, Hf0, Wf0, h0c, w0c, mix0, nullptr, q1, h1c * w1c, cell0, pitch0, ties0, part0, i_ids, j_ids, mkpts1_c, out1, 1);
-  return (int)e;
 }

@@ -701,44 +701,6 @@ def fine_match_maps(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, 
     return out0, out1
 
 
-def fine_match_maps_cells(feat_f0: torch.Tensor, feat_f1: torch.Tensor, b_ids, i_ids, j_ids, w: int, hw0_c, hw1_c,
-                          mix0: torch.Tensor, mix1: torch.Tensor, mkpts0_c: torch.Tensor, mkpts1_c: torch.Tensor,
-                          scale_f: float, cells, count: Optional[torch.Tensor] = None,
-                          scratch: Optional[torch.Tensor] = None):
-    """Window crop + fine stage from NCHW float32 maps WITHOUT the channels-last copy of image 1 (fm_fine_match_maps_cells:
-    fine_preprocess.py:43-50 + fine_matching_new.py:50-79): every map is read in strips of 8 coarse cells, image 0 twice
-    and image 1 once, each in its own cell order - the form for BATCHES (60 MB of map reads per 640x480 pair instead of
-    80 MB, and no 20-byte runs).  `cells` = CoarseBuffers.cell_maps() of the coarse call that produced the ids (the
-    cell -> match maps in its workspace; run it with cell_maps=True).  Stride 4, pad 2, even map widths.  Results equal
-    fine_match_maps bit for bit.  Returns (mkpts0_f, mkpts1_f)."""
-    lib = _lib.load()
-    if not (feat_f0.is_cuda and feat_f0.dtype == torch.float32 and feat_f0.is_contiguous() and feat_f1.is_contiguous()
-            and feat_f1.dtype == torch.float32):
-        raise RuntimeError("fine_match_maps_cells: contiguous NCHW float32 maps on the GPU (the HIP path has no CPU fallback)")
-    n, cf, hf0, wf0 = feat_f0.shape
-    hf1, wf1 = feat_f1.shape[2:]
-    dev = feat_f0.device
-    m_max = int(b_ids.shape[0])
-    out0 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
-    out1 = torch.empty(m_max, 3, dtype=torch.float32, device=dev)
-    if m_max == 0:
-        return out0, out1
-    (c0, p0, t0), (c1, p1, t1) = cells
-    need = int(lib.fm_fine_maps_cells_scratch_bytes(n, int(hw0_c[0]), int(hw0_c[1]), int(hw1_c[0]), int(hw1_c[1])))
-    if scratch is None or scratch.numel() * scratch.element_size() < need + 256:
-        scratch = torch.empty(need + 256, dtype=torch.uint8, device=dev)
-    sp = scratch.data_ptr() + ((-scratch.data_ptr()) % 256)
-    st = lib.fm_fine_match_maps_cells(_ptr(feat_f0), _ptr(feat_f1), n, cf, hf0, wf0, hf1, wf1, w, 4, 2, int(hw0_c[0]),
-                                      int(hw0_c[1]), int(hw1_c[0]), int(hw1_c[1]), C.c_void_p(c0), p0, C.c_void_p(t0),
-                                      C.c_void_p(c1), p1, C.c_void_p(t1), _ptr(b_ids), _ptr(i_ids), _ptr(j_ids),
-                                      _ptr(count), m_max, _ptr(_f32c(mix0, "mix0")), _ptr(_f32c(mix1, "mix1")),
-                                      _ptr(_f32c(mkpts0_c, "mkpts0_c")), _ptr(_f32c(mkpts1_c, "mkpts1_c")), float(scale_f),
-                                      C.c_void_p(sp), _ptr(out0), _ptr(out1), _stream(dev))
-    _lib.check(st, "fm_fine_match_maps_cells")
-    out0._keep = (feat_f0, feat_f1, scratch)
-    return out0, out1
-
-
 _TF_NAMES = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight",
              "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
 

@@ -349,30 +349,6 @@ int fm_fine_match_maps(const float* feat_f0, const float* feat_f1, int layout, i
                        void* scratch, float* out0, float* out1, void* stream);
 
 /*
- * The same for BATCHES of NCHW float32 maps, without the channels-last copy of image 1 (round 6): every map is read in
- * strips of 8 consecutive coarse cells (runs of 132 / 140 contiguous bytes instead of the 20-byte runs of single windows),
- * image 0 twice and image 1 once, each in its own cell order - neither direction of fine_matching_new.py:50-57 needs both
- * windows at once (sim0 = q0 . window1 with q0 = mix_0(window0): 64 numbers per cell):
- *   pass 1 q0 of every cell of image 0 | pass 2 (image 1's cells) q1 of every cell, out0 of the cell's match |
- *   pass 3 (image 0's cells) out1 of the cell's match.
- * 60 MB of map reads + 5 MB of q tables per 640x480 pair instead of 80 MB.  cell0 / cell1, pitch, ties: the cell -> match
- * maps and tie lists of the coarse call that produced the ids (fm_coarse_cell_maps; not with FM_MODE_NO_CELL_MAPS).
- * scratch: fm_fine_maps_cells_scratch_bytes(N, h0c, w0c, h1c, w1c) bytes [dev], 256-byte aligned (the q tables).
- * stride 4, pad 2 (fine_preprocess.py:43-46 with resolution (8, 2)), even Wf0 / Wf1, Cf = 64, W in {5,7}; other
- * configurations: FM_E_UNSUPPORTED (fm_fine_match_maps serves them).  Results equal fm_fine_match_maps bit for bit.  Three
- * dependent launches: for ONE pair per call fm_fine_match_maps (one launch behind fm_coarse_match_maps) is faster.
- */
-size_t fm_fine_maps_cells_scratch_bytes(int N, int h0c, int w0c, int h1c, int w1c);
-int fm_fine_match_maps_cells(const float* feat_f0, const float* feat_f1, int N, int Cf, int Hf0, int Wf0, int Hf1, int Wf1,
-                             int W, int stride, int pad, int h0c, int w0c, int h1c, int w1c,
-                             const int32_t* cell0, int pitch0, const int32_t* ties0,
-                             const int32_t* cell1, int pitch1, const int32_t* ties1,
-                             const int64_t* b_ids, const int64_t* i_ids, const int64_t* j_ids,
-                             const int32_t* d_count, int m_max, const float* mix0, const float* mix1,
-                             const float* mkpts0_c, const float* mkpts1_c, float scale_f,
-                             void* scratch, float* out0, float* out1, void* stream);
-
-/*
  * The same with the element type of the maps as an argument (enum fm_dtype): FM_F16 / FM_BF16 maps - what a backbone
  * under autocast hands over (network/net.py:56-57) - are read as they are, no up-cast pass.  Every float16 /
  * bfloat16 value is exact in float32 and the arithmetic is the float32 call's, so the result equals

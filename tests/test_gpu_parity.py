@@ -874,80 +874,6 @@ def test_fine_match_from_the_maps(w, channels_last):
     assert torch.equal(g0[:m - 7], h0[:m - 7]) and torch.equal(g1[:m - 7], h1[:m - 7])
 
 
-@pytest.mark.parametrize("w", [5, 7])
-@pytest.mark.parametrize("n,hc,wc,dist", [(2, 60, 80, "peaky"), (3, 13, 19, "borderline"), (1, 16, 16, "peaky"), (9, 9, 7, "peaky")])
-def test_strip_form_of_the_fine_stage_equals_the_copy_form(n, hc, wc, dist, w):
-    """fm_fine_match_maps_cells (round 6: the batch form - every NCHW map read in strips of 8 cells, image 0 twice and image
-    1 once in their own cell order, no channels-last copy; fine_preprocess.py:43-50 + fine_matching_new.py:50-79) against
-    fm_fine_match_maps on the same maps: bit for bit.  Cell grids that are no multiple of 8 (partial strips), maps whose
-    windows hang over every edge, several samples, M spread over all of them."""
-    l = hc * wc
-    f0, f1 = synth.coarse_descriptors(301 + n, n, l, 64, dist)
-    ff0, ff1 = synth.fine_maps(301 + n, n, 64, 4 * hc, 4 * wc)
-    mix = synth.mix_weights(7, w * w)
-    mix0, mix1 = _mix_tensors(mix)
-    t0, t1 = torch.as_tensor(ff0, device=DEV), torch.as_tensor(ff1, device=DEV)
-    # (border_rm = 0 on the small grids: matched cells on the border ring, whose windows hang over the maps' edges)
-    out = ops.coarse_match(torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV), (hc, wc), (hc, wc), 8.0,
-                           border_rm=(2 if hc >= 60 else 0))
-    m = out['i_ids'].shape[0]
-    assert m > 0.3 * n * (hc - 4) * (wc - 4)
-    if hc < 60:
-        y = (out['i_ids'] // wc).cpu().numpy()
-        assert y.min() == 0 and y.max() == hc - 1
-    k0, k1 = ops.fine_match_maps(t0, t1, out['b_ids'], out['i_ids'], out['j_ids'], w, 4, wc, wc, mix0, mix1,
-                                 out['mkpts0_c'], out['mkpts1_c'], 2.0)
-    s0, s1 = ops.fine_match_maps_cells(t0, t1, out['b_ids'], out['i_ids'], out['j_ids'], w, (hc, wc), (hc, wc), mix0, mix1,
-                                       out['mkpts0_c'], out['mkpts1_c'], 2.0, out['_coarse_buffers'].cell_maps())
-    torch.cuda.synchronize()
-    assert torch.equal(s0, k0) and torch.equal(s1, k1)
-
-
-def test_strip_form_serves_exactly_tied_matches_and_rectangular_pairs():
-    """Exact ties (two matches share an image-0 cell: one of them is not in the cell -> match map and comes from the tie
-    list) and L != S through the strip form, against the copy form bit for bit; then against the reference fixture."""
-    kats = load_kats()
-    for name in ("tie", "rect_scale"):
-        k = kats[name]
-        f0, f1 = k['f0'], k['f1']
-        hw = [int(v) for v in k['hw']]
-        hw0_c, hw1_c = (hw[4], hw[5]), (hw[6], hw[7])
-        kw = {}
-        if 'scale0' in k:
-            kw = dict(scale0=torch.as_tensor(k['scale0'], device=DEV), scale1=torch.as_tensor(k['scale1'], device=DEV))
-        out = ops.coarse_match(torch.as_tensor(f0, device=DEV), torch.as_tensor(f1, device=DEV), hw0_c, hw1_c, hw[0] / hw0_c[0], **kw)
-        n = f0.shape[0]
-        ff0, _ = synth.fine_maps(11, n, 64, 4 * hw0_c[0], 4 * hw0_c[1])
-        _, ff1 = synth.fine_maps(11, n, 64, 4 * hw1_c[0], 4 * hw1_c[1])
-        t0, t1 = torch.as_tensor(ff0, device=DEV), torch.as_tensor(ff1, device=DEV)
-        mix0, mix1 = _mix_tensors(synth.mix_weights(11, 49))
-        k0, k1 = ops.fine_match_maps(t0, t1, out['b_ids'], out['i_ids'], out['j_ids'], 7, 4, hw0_c[1], hw1_c[1], mix0, mix1,
-                                     out['mkpts0_c'], out['mkpts1_c'], 2.0)
-        s0, s1 = ops.fine_match_maps_cells(t0, t1, out['b_ids'], out['i_ids'], out['j_ids'], 7, hw0_c, hw1_c, mix0, mix1,
-                                           out['mkpts0_c'], out['mkpts1_c'], 2.0, out['_coarse_buffers'].cell_maps())
-        torch.cuda.synchronize()
-        assert out['i_ids'].shape[0] > 0
-        assert torch.equal(s0, k0) and torch.equal(s1, k1), name
-        if name == "tie":
-            ids = out['i_ids'].cpu().numpy()
-            assert len(ids) != len(set(ids.tolist())), "the tie case holds two matches of one image-0 cell"
-            assert np.abs(s0.cpu().numpy()[:, :2] - k['mkpts0_f'][:, :2]).max() <= FINE_TOL_PX
-            assert np.abs(s1.cpu().numpy()[:, :2] - k['mkpts1_f'][:, :2]).max() <= FINE_TOL_PX
-
-
-def test_strip_form_argument_checks_and_empty_list():
-    lib = _lib.load()
-    one = ctypes.c_void_p(256)
-    args = lambda stride, pad, wf: (one, one, 1, 64, 64, wf, 64, wf, 5, stride, pad, 16, 16, 16, 16, one, 256, one, one, 256, one,
-                                    one, one, one, None, 10, one, one, one, one, 2.0, one, one, one, None)
-    assert lib.fm_fine_match_maps_cells(*args(8, 2, 64)) == -3      # FM_E_UNSUPPORTED: stride
-    assert lib.fm_fine_match_maps_cells(*args(4, 3, 64)) == -3      # pad
-    assert lib.fm_fine_match_maps_cells(*args(4, 2, 63)) == -3      # odd row length
-    a = list(args(4, 2, 64)); a[25] = 0
-    assert lib.fm_fine_match_maps_cells(*a) == 0                                       # m_max == 0: nothing to do
-    assert lib.fm_fine_maps_cells_scratch_bytes(2, 60, 80, 60, 80) == 2 * (2 * 4800 * 256 + 2 * 4800 * 4)
-
-
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("channels_last", [False, True])
 @pytest.mark.parametrize("w", [5, 7])
