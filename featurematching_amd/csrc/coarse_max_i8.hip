@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void k_max_i8(MaxArgs a) {
       if (DC) slot(2 * ks + 1);
       // the ring refill rides in the gaps of this pipe (an LDS-DMA instruction issued between MFMAs costs a fraction of
       // one issued in a burst in front of them): piece n behind k-step (n + 1) KS8 / PER_WAVE - 1
+#ifndef FM_ABL_MAX_NODMA    // (timing-only ablation build: the ring is not refilled - wrong maxima; profiles/r06_ab_max_ablations.txt)
       if (DN && DC && ((ks + 1) * PER_WAVE) % KS8 == 0 && ts >= 0) stage_piece(ts, tsbuf, (ks + 1) * PER_WAVE / KS8 - 1);
+#endif
       if (DN && DC) __builtin_amdgcn_sched_barrier(0);
       if constexpr (ks + 1 < KS8) self(self, std::integral_constant<int, ks + 1>{});
     };
