@@ -415,7 +415,9 @@ extern "C" int fm_coarse_match_auto(const void* feat0, const void* feat1, int in
       // the common path's own results are still in the workspace: add the dense kernels' part and assign again
       cur |= FM_MODE_DENSE;
       const CoarseWs w = coarse_layout(N, L, S, C, slots);
-      if (workspace_bytes >= w.total) {
+      // (the resume clears the WHOLE status word: only when "flat similarity" is all it holds - anything else the device
+      // reported with it would be dropped, so such a call is repeated from the start instead)
+      if (workspace_bytes >= w.total && (info & ~FM_DEV_ALL_DENSE) == FM_DEV_DENSE) {
         st = resume_with_dense(feat0, feat1, in_dtype, C, w, (char*)workspace, h0c, w0c, h1c, w1c,
                                1.0f / ((float)C * temperature), thr, border_rm, scale_px, scale0, scale1, b_ids, i_ids, j_ids,
                                mkpts0_c, mkpts1_c, mconf, cap, d_count, fixed | cur, (hipStream_t)stream);

@@ -89,8 +89,11 @@ __global__ __launch_bounds__(256) void k_dsm_uv(const int64_t* __restrict__ b_id
 // 62-65 - without any [N, L, S] temporary):
 //   kDsmSparse : as above (G lives in w_x / w_y and the entries' own kernel).
 //   kDsmStats  : v_k = sum_l G_kl conf_kl and u_l = sum_k G_kl conf_kl with conf recomputed tile by tile from exact float32
-//                dot products (conf = A B); no gradient phase.  Launched on side 0 only; v and u by float atomics
-//                (<= 4 adds per row, one per row tile and column).
+//                dot products (conf = A B); no gradient phase.  Launched on side 0 only; v and u by float atomics: a row's
+//                v takes one add per z slice (<= 4), a COLUMN's u one add per 32-row tile of the owner image (150 at
+//                640x480) in arrival order - the dense backward's gradients are therefore reproducible to float32
+//                rounding of those sums (~1e-7 relative), not bit for bit; every other reduction of this file is
+//                order-fixed (k_fix_sums, k_dsm_combine).
 //   kDsmDense  : D_kl = 2 G_kl conf_kl - A_kl u_l - B_kl v_k, the whole of dL/dsim, accumulated into the rows' gradient.
 // G is read through a transposing LDS tile when the owner image is image 1 (g_t: element (owner row, other row) lives at
 // G[other][owner]): both sides read 128-byte row segments of G.  G is read three times in all (92 MB per 640x480 pair
