@@ -57,7 +57,15 @@ CoarseWs coarse_layout(int N, int L, int S, int C, int slots, bool alone) {
   // (a batch that fills the resident slots by itself gets ~10 rounds of workgroups, so that the last round's tail is a
   // small share of the launch: 1216 workgroups on 512 slots were "2.4 of 3 rounds"; 64 pairs of 640x480: 351 -> 333 us
   // with 4 splits; 2 / 3 / 4 / 5 / 8 splits: 335 / 340 / 333 / 348 / 363 us)
-  w.splits0 = choose_splits(N, w.panels, w.tiles, N * w.panels >= kMaxPassSlots ? 10 * kMaxPassSlots : (alone ? kMaxPassSlots : kMaxPassTarget));
+  {
+    int target = N * w.panels >= kMaxPassSlots ? 10 * kMaxPassSlots : (alone ? kMaxPassSlots : kMaxPassTarget);
+    // (round 6: a launch whose workgroups would each sweep >= 32 tiles at one workgroup per CU - a 1024x1024 pair: 64 -
+    // is long enough for the matrix cores to decide, and one wave per SIMD runs them at 40 %: two workgroups per CU there.
+    // 1024x1024 on four streams, 256 / 384 / 512 / 768 workgroups: 6228 / 6307 / 6364 / 6207 pairs/s, max pass alone 100 /
+    // 91 / 77 / 88 us; 640x960 (25 tiles per workgroup) keeps 256: 12 949 against 12 792 pairs/s)
+    if (target == kMaxPassTarget && w.tiles / choose_splits(N, w.panels, w.tiles, kMaxPassTarget) >= 32) target = kMaxPassSlots;
+    w.splits0 = choose_splits(N, w.panels, w.tiles, target);
+  }
 #ifdef FM_TUNE_ENV
   if (const char* e = getenv("FM_TARGET_WGS0")) w.splits0 = choose_splits(N, w.panels, w.tiles, atoi(e) > 0 ? atoi(e) : kMaxPassTarget);
 #endif
