@@ -30,7 +30,8 @@ int choose_splits(int N, int panels, int tiles, int target) {
 static int choose_screen_chunks(int N, int Lp, int nunits, int* units_per_chunk, bool alone) {
   const long nrb = (long)N * (Lp / 32);
   // (FM_MODE_ALONE, a pair or two: 8-unit chunks - 3.5 us faster alone at one 640x480 pair, 7 % slower on four streams)
-  const int cu = nrb * ((nunits + 63) / 64) >= 4096 ? 64 : (alone && nrb * ((nunits + 7) / 8) <= 8192 ? 8 : 32);
+  // (round 6: 64-unit chunks from 1024 items on - a 640x960 pair, 1520 items: 13 624 against 13 306 pairs/s at 32 units)
+  const int cu = nrb * ((nunits + 63) / 64) >= 1024 ? 64 : (alone && nrb * ((nunits + 7) / 8) <= 8192 ? 8 : 32);
   *units_per_chunk = cu;
   return (nunits + cu - 1) / cu;
 }
