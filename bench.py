@@ -799,6 +799,9 @@ def main():
     ap.add_argument("--cu-mask", default="", choices=["", "blocks", "interleaved"],
                     help="experiment: every stream gets its own quarter (1 / streams) of the compute units "
                          "(hipExtStreamCreateWithCUMask): contiguous blocks of the mask bits, or interleaved bits")
+    ap.add_argument("--alone", action="store_true",
+                    help="diagnostic: every step passes FM_MODE_ALONE (grids sized for a kernel alone on the device); the JSON "
+                         "line then says so in config.launch")
     ap.add_argument("--stub-step", action="store_true",
                     help="test hook: run the launcher / rank protocol with a CPU stand-in for the HIP step (no GPU needed; "
                          "the JSON line is marked as a stub and carries no measurement)")
@@ -844,6 +847,7 @@ def main():
         pairs.append(Pair(wl, 1000 * (rank + 1) + 17 * p, a.window, dev, a.dist,
                           share=pairs[p % nstreams] if p >= nstreams else None, layout=a.layout, fine_path=a.fine_path))
         pairs[-1].fuse_maps = pairs[-1].fuse_maps and not a.no_fuse_maps
+        pairs[-1].alone = a.alone
 
     # Steps are independent pairs: consecutive steps go round-robin to `--streams` HIP streams so that
     # the (mostly latency-bound, small-grid) kernels of different pairs overlap on the chip.  Every input
@@ -980,7 +984,7 @@ def main():
                       "products, 22 significant bits",
         "data": "synthetic",
         "config": {"workload": f"{wl['label']}, {a.window}x{a.window} fine window, '{a.dist}' descriptors",
-                   "pairs_per_step_per_gpu": pairs_per_step, "launch": "eager" if a.no_graph else "hipGraph replay",
+                   "pairs_per_step_per_gpu": pairs_per_step, "launch": ("eager" if a.no_graph else "hipGraph replay") + (" [DIAGNOSTIC: FM_MODE_ALONE on every step]" if a.alone else ""),
                    "concurrent_streams": nstreams, "matches_per_pair": round(m_avg, 1),
                    "launches_per_step": launches, "pair_block": [pair_lo, pair_hi],
                    "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 4)},
