@@ -79,3 +79,24 @@ def test_bench_under_a_launcher_environment_prints_the_distributed_block():
     d = out["distributed"]
     assert d["backend"].startswith("nccl") and d["world_size"] == 1 and len(d["device_uuids"]) == 1
     assert out["n_gpus"] == 1 and out["gathered_records"] > 3000 and out["gather_ms"] > 0 and out["verified"]
+
+
+def test_two_ranks_on_one_gpu_run_the_hip_step_and_gather_over_gloo():
+    """`python bench.py --gpus 2` (the launcher form the driver uses for N > 1: the parent starts torch.distributed.run
+    itself) with FM_BENCH_BACKEND=gloo: two ranks share the one GPU of the test box, each runs the real HIP step on its own
+    block of pairs, the match lists of the timed steps are packed on the device, gathered over gloo in pair order, and rank
+    0 prints ONE JSON line that says so.  Everything of the N > 1 path except RCCL between several devices."""
+    env = dict(os.environ, FM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "4",
+                        "--quick", "--skip-cpu", "--pairs", "4"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["verified"]
+    d = out["distributed"]
+    assert d["backend"].startswith("gloo") and d["world_size"] == 2 and len(d["device_uuids"]) == 2
+    assert out["gathered_records"] > 2 * 4 * 3000          # both ranks' lists (4 input sets each, ~3.8 k matches per pair)
+    assert out["config"]["pair_block"] == [0, 1]           # rank 0's block of the 2-pair global step

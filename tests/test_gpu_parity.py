@@ -736,6 +736,31 @@ def test_one_c_call_on_the_known_answer_cases():
     assert st == _lib.FM_E_RANGE
 
 
+def test_alone_hint_changes_launch_geometry_only():
+    """FM_MODE_ALONE (the caller has the GPU to itself: two max-pass workgroups per CU, 8-unit screening chunks) is a hint
+    about the device - the outputs must be the bits of the call without it, on peaked, flat and mixed data, one pair and
+    a small batch; and the synchronous ops.coarse_match passes it by default."""
+    for name, dist, nb in (("cfg2_peaky", "peaky", 1), ("cfg2_mixed", "mixed", 1), ("cfg1_borderline", "borderline", 3)):
+        g = load_golden(name)
+        inp = case_inputs(g['meta'], dist, with_fine=False)
+        f0 = torch.as_tensor(np.repeat(inp['f0'], nb, 0), device=DEV)
+        f1 = torch.as_tensor(np.repeat(inp['f1'], nb, 0), device=DEV)
+        a = _np(ops.coarse_match(f0, f1, inp['hw_c'], inp['hw_c'], 8.0, alone=True))
+        b = _np(ops.coarse_match(f0, f1, inp['hw_c'], inp['hw_c'], 8.0, alone=False))
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (name, k)
+        sel = a['b_ids'] == 0
+        _assert_coarse({k: v[sel] for k, v in a.items()}, g)
+    # the asynchronous form: the mode bit reaches the C call and the workspace size does not depend on it
+    inp = case_inputs(load_golden("cfg2_peaky")['meta'], "peaky", with_fine=False)
+    t0, t1 = torch.as_tensor(inp['f0'], device=DEV), torch.as_tensor(inp['f1'], device=DEV)
+    x = ops.coarse_match_async(t0, t1, inp['hw_c'], inp['hw_c'], 8.0, alone=True)
+    y = ops.coarse_match_async(t0, t1, inp['hw_c'], inp['hw_c'], 8.0, alone=False)
+    mx, my = x.read_count(), y.read_count()
+    assert mx == my and x.workspace.numel() == y.workspace.numel()
+    assert torch.equal(x.i_ids[:mx], y.i_ids[:my]) and torch.equal(x.mconf[:mx], y.mconf[:my])
+
+
 def test_coarse_without_cell_maps_gives_the_same_matches():
     """FM_MODE_NO_CELL_MAPS only drops the cell -> match maps (for callers that never run the cell-ordered crops)."""
     f0, f1 = synth.coarse_descriptors(44, 2, 20 * 30, 128, "peaky")
