@@ -1126,6 +1126,10 @@ def extras(a, wl, dev, streams, flops):
             rate, ver, m_pp = stream_rate(w3, a.window, dev, "peaky", w3["n"], 2, steps=6, nsets=2)
             res = {"value": round(rate, 2), "unit": "image-pairs/s", "pairs_per_step": w3["n"],
                    "verified": ver["ok"] if ver else None, "verification": ver, "matches_per_pair": round(m_pp, 1)}
+            # the same batch with channels-last fine maps (no copy of image 1, no in-place NCHW window loads): what the
+            # reference's NCHW hand-over costs at the batch
+            rate_cl, ver_cl, _ = stream_rate(w3, a.window, dev, "peaky", w3["n"], 2, steps=6, nsets=2, layout="nhwc", fine_path="maps")
+            res["channels_last_maps"] = {"value": round(rate_cl, 2), "unit": "image-pairs/s", "verified": ver_cl["ok"] if ver_cl else None}
             # the coarse correlation's roofline at the batch - the regime in which the matrix cores decide: event-timed
             # launches of the max pass and the screening kernels on a filled workspace, algorithmic 2 N L S C flop
             with torch.cuda.stream(streams[0]):
