@@ -27,6 +27,7 @@ def _free_port():
 def test_match_records_from_the_hip_path_go_through_rccl_all_gathers():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    saved = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(_free_port())
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -62,6 +63,11 @@ def test_match_records_from_the_hip_path_go_through_rccl_all_gathers():
         assert float(t[0]) == 3.5 and got == ["rank 0"]
     finally:
         dist.destroy_process_group()
+        for k, v in saved.items():             # (the rendezvous variables must not leak into later tests' child processes)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_bench_under_a_launcher_environment_prints_the_distributed_block():
