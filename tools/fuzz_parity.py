@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, nargs="*", default=None, help="run these case numbers only")
+    ap.add_argument("--conf", action="store_true", help="also request data['conf_matrix'] and compare the whole matrix (T = 0.1 cases)")
+    ap.add_argument("--half", action="store_true", help="hand the descriptors over as float16 / bfloat16 (oracle on the up-cast values)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     dev = torch.device("cuda:0")
@@ -48,15 +50,27 @@ def main():
         if l != s_:          # rectangular: the partners of the rows beyond min(l, s) are missing
             pass
         hw_i = (8 * h0, 8 * w0)
+        hdt = None
+        if a.half:
+            hdt = torch.float16 if case % 2 else torch.bfloat16
+            f0 = torch.as_tensor(f0).to(hdt).float().numpy()      # the values the half-precision tensors hold
+            f1 = torch.as_tensor(f1).to(hdt).float().numpy()
         ref = orc.coarse_match(f0, f1, hw_i, (h0, w0), (h1, w1), thr=thr, border_rm=border, temperature=temp)
-        out = ops.coarse_match(torch.as_tensor(f0, device=dev), torch.as_tensor(f1, device=dev), (h0, w0), (h1, w1),
-                               hw_i[0] / h0, thr, border, temp)
-        got = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith('_')}
+        t0, t1 = torch.as_tensor(f0, device=dev), torch.as_tensor(f1, device=dev)
+        if hdt is not None:
+            t0, t1 = t0.to(hdt), t1.to(hdt)
+        want_conf = a.conf and temp >= 0.1
+        out = ops.coarse_match(t0, t1, (h0, w0), (h1, w1), hw_i[0] / h0, thr, border, temp, conf_matrix=want_conf)
+        got = {k: v.cpu().numpy() for k, v in out.items() if not k.startswith('_') and k != 'conf_matrix'}
         r = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in ref.items()}
         og, orf, err = compare_match_sets(got, r)
         flips = [(k, v) for k, v in og + orf if abs(v - thr) > 2e-5]
         msg = f"case {case:3d} n={n} {h0}x{w0}/{h1}x{w1} C={c} {dist:10s} thr={thr} b={border} T={temp} W={w}: M={len(r['i_ids'])} conf err {err:.1e}"
         ok = not flips and err <= 1e-5
+        if want_conf:
+            cerr = float((out['conf_matrix'].cpu() - orc.conf_matrix(torch.as_tensor(f0), torch.as_tensor(f1), temp)).abs().max())
+            msg += f" conf_matrix err {cerr:.1e}"
+            ok = ok and cerr <= 1e-5
         if not flips and err > 1e-5:
             # beyond the bar against the float32 oracle: where does float64 put the entries?  (the reference's own float32
             # sums are up to ~1e-5 from float64 at low temperatures / large S: BASELINE.md section 4's exception)
