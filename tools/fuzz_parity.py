@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, nargs="*", default=None, help="run these case numbers only")
     ap.add_argument("--conf", action="store_true", help="also request data['conf_matrix'] and compare the whole matrix (T = 0.1 cases)")
+    ap.add_argument("--ties", action="store_true", help="duplicate a few descriptors in either image: exactly tied conf entries "
+                                                       "(coarse_matching_new.py:105-106 keeps all of them)")
     ap.add_argument("--half", action="store_true", help="hand the descriptors over as float16 / bfloat16 (oracle on the up-cast values)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
@@ -49,6 +51,11 @@ def main():
         f0, f1 = np.ascontiguousarray(f0[:, :l]), np.ascontiguousarray(f1[:, :s_])
         if l != s_:          # rectangular: the partners of the rows beyond min(l, s) are missing
             pass
+        if a.ties:
+            for img, length in ((f1, s_), (f0, l)):
+                for _ in range(int(rng.integers(0, 4))):
+                    b_, src, dst = int(rng.integers(0, n)), int(rng.integers(0, length)), int(rng.integers(0, length))
+                    img[b_, dst] = img[b_, src]
         hw_i = (8 * h0, 8 * w0)
         hdt = None
         if a.half:
@@ -97,6 +104,20 @@ def main():
             fe = max(float((k0.cpu() - r0).abs().max()), float((k1.cpu() - r1).abs().max()))
             msg += f" fine err {fe:.1e}"
             ok = ok and fe <= 1e-3
+            # the other routes to the same numbers: list-ordered crops + fm_fine_match, the cell-ordered pair crop, channels-last maps
+            tf0, tf1 = torch.as_tensor(ff0, device=dev), torch.as_tensor(ff1, device=dev)
+            win0 = ops.gather_windows(tf0, out['b_ids'], out['i_ids'], w, 4, w0)
+            win1 = ops.gather_windows(tf1, out['b_ids'], out['j_ids'], w, 4, w1)
+            q0, q1 = ops.fine_match(win0, win1, mix0, mix1, out['mkpts0_c'], out['mkpts1_c'], 2.0)
+            p0, p1 = ops.gather_windows_pair(tf0, tf1, out['b_ids'], out['i_ids'], out['j_ids'], w, 4, (h0, w0), (h1, w1),
+                                             out['_coarse_buffers'].cell_maps())
+            c0, c1 = ops.fine_match_maps(tf0.contiguous(memory_format=torch.channels_last), tf1.contiguous(memory_format=torch.channels_last),
+                                         out['b_ids'], out['i_ids'], out['j_ids'], w, 4, w0, w1, mix0, mix1, out['mkpts0_c'], out['mkpts1_c'], 2.0)
+            same = (torch.equal(q0, k0) and torch.equal(q1, k1) and torch.equal(p0, win0) and torch.equal(p1, win1)
+                    and torch.equal(c0, k0) and torch.equal(c1, k1)
+                    and torch.equal(win0.cpu(), w0t) and torch.equal(win1.cpu(), w1t))
+            msg += " routes identical" if same else " ROUTES DIFFER"
+            ok = ok and same
         print(("ok   " if ok else "FAIL ") + msg + (f" flips {flips[:3]}" if flips else ""), flush=True)
         bad += 0 if ok else 1
     print(f"{a.cases - bad} / {a.cases} cases agree with the oracle")
